@@ -1,0 +1,144 @@
+"""Golden-vector generator -- TEST INFRASTRUCTURE ONLY.
+
+Runs the REAL reference (/root/reference, imported read-only; exists only in the
+build container) on the synthetic weights/inputs of oracle/synth.py and writes
+small fixtures to tests/golden/.  The GPU box has no /root/reference: tests read
+only the committed fixtures.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+
+What is pinned:
+  * state_dict names/shapes of UNetMore_DDPM == unet_ref.param_shapes       
+  * schedule buffers betas/alphas/alphas_prev                               (ncsnpp_more.py:735-743)
+  * one UNet forward: final eps + a strided probe of every module's output  (ncsnpp_more.py:251-392, 590-718)
+  * ddpm_sampler / ddim_sampler end-to-end with an injected noise sequence  (models/__init__.py:102-340)
+  * upfirdn2d_native for the two FIR uses + a generic case                  (op/upfirdn2d.py:163-204)
+"""
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+from oracle import synth, unet_ref  # noqa: E402
+
+
+def probe(t, n=97):
+    """Deterministic strided sample + moments of a tensor (keeps fixtures small)."""
+    f = t.detach().reshape(-1).double()
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return dict(shape=list(t.shape), mean=f.mean().item(), absmean=f.abs().mean().item(),
+                sample=f[idx].float().clone(), idx=idx.clone())
+
+
+def build_ref_net(config):
+    sys.path.insert(0, REF)
+    from models.better.ncsnpp_more import UNetMore_DDPM
+    config.device = "cpu"
+    net = UNetMore_DDPM(config).eval()
+    return net
+
+
+def check_names(net, config):
+    want = unet_ref.param_shapes(unet_ref.hot_cfg(config))
+    have = {k: tuple(v.shape) for k, v in net.named_parameters()}
+    assert list(have.keys()) == list(want.keys()), (set(have) ^ set(want))
+    assert have == want
+    bufs = [k for k, _ in net.named_buffers()]
+    assert sorted(bufs) == sorted(["betas", "alphas", "alphas_prev", "unet.sigmas"]), bufs
+
+
+class NoiseInjector:
+    """Replace torch.randn_like (as seen from the reference's `models` module) by a
+    pre-drawn sequence: call k returns noise[k]."""
+
+    def __init__(self, noise):
+        self.noise, self.k = noise, 0
+
+    def __call__(self, like, *a, **kw):
+        z = self.noise[self.k].to(like)
+        self.k += 1
+        assert z.shape == like.shape
+        return z
+
+
+def gen_model_case(name, batch, steps_kinds):
+    import models as ref_models
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    check_names(net, config)
+    sd = synth.make_state_dict(config, seed=123)
+    missing = net.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and set(missing.missing_keys) <= {"betas", "alphas", "alphas_prev", "unet.sigmas"}
+    x, cond = synth.make_inputs(config, batch, seed=0)
+    out = dict(config_name=name, batch=batch)
+    out["betas"], out["alphas"], out["alphas_prev"] = net.betas.clone(), net.alphas.clone(), net.alphas_prev.clone()
+
+    # ---- one forward with per-module probes
+    taps = {}
+    hooks = []
+    for i, m in enumerate(net.unet.all_modules):
+        hooks.append(m.register_forward_hook(lambda mod, inp, o, i=i: taps.__setitem__(i, probe(o))))
+    t = torch.tensor([(37 * (b + 1)) % 1000 for b in range(batch)]).long()   # distinct labels per row
+    with torch.no_grad():
+        eps = net(x, t, cond=cond)
+    for h in hooks:
+        h.remove()
+    out["fwd_t"], out["fwd_eps"], out["fwd_taps"] = t, eps.clone(), taps
+
+    # ---- samplers with injected noise
+    for kind, subsample, extra in steps_kinds:
+        sampler = dict(ddpm=ref_models.ddpm_sampler, ddim=ref_models.ddim_sampler)[kind]
+        noise = synth.make_noise(config, batch, subsample + 1, seed=2)
+        inj = NoiseInjector(noise)
+        orig = torch.randn_like
+        torch.randn_like = inj
+        try:
+            res = sampler(x.clone(), net, cond=cond, final_only=True, denoise=True, subsample_steps=subsample,
+                          clip_before=True, verbose=False, log=False, **extra)
+        finally:
+            torch.randn_like = orig
+        key = f"{kind}_{subsample}" + ("".join(f"_{k}{v}" for k, v in extra.items()) if extra else "")
+        out["sampler_" + key] = dict(result=res.clone(), n_noise=inj.k)
+        print(f"  {name}: {key}: out range [{res.min():.4f}, {res.max():.4f}], noise draws {inj.k}")
+    os.makedirs(OUT, exist_ok=True)
+    torch.save(out, os.path.join(OUT, f"{name}_b{batch}.pt"))
+    print(f"wrote {name}_b{batch}.pt  eps std {eps.std():.4f}")
+
+
+def gen_fir():
+    sys.path.insert(0, REF)
+    from models.better import up_or_down_sampling as uds
+    from models.better.op.upfirdn2d import upfirdn2d_native
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    k = torch.tensor(uds._setup_kernel([1, 3, 3, 1]))
+    out = dict(x=x,
+               up=uds.upsample_2d(x, [1, 3, 3, 1], factor=2),
+               down=uds.downsample_2d(x, [1, 3, 3, 1], factor=2),
+               kernel=k,
+               generic=upfirdn2d_native(x, k * 3.0, 3, 3, 2, 2, 2, 1, 2, 1),   # up 3, down 2, pad (2,1)
+               generic_args=dict(up=3, down=2, pad0=2, pad1=1, gain=3.0))
+    torch.save(out, os.path.join(OUT, "fir.pt"))
+    print("wrote fir.pt")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    os.makedirs(OUT, exist_ok=True)
+    gen_fir()
+    gen_model_case("tiny", 3, [("ddpm", 10, {}), ("ddim", 10, {}), ("ddpm", 10, dict(t_min=0.35))])
+    gen_model_case("tiny_spade", 2, [("ddpm", 10, {})])
+    gen_model_case("smmnist_big5", 2, [("ddpm", 100, {})])          # BASELINE config 1 (plumbing, CPU)
+
+
+if __name__ == "__main__":
+    main()

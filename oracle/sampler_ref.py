@@ -1,0 +1,83 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/unet_ref.py header).
+
+Restatement of the reference's DDPM / DDIM sampling loops
+(models/__init__.py:206-340 `ddpm_sampler`, :102-203 `ddim_sampler`) for the
+non-gamma path, with the per-step Gaussian noise supplied by a callable so CPU
+and GPU runs can consume the *same* noise sequence.
+
+Parity status: PINNED against the reference samplers by oracle/gen_golden.py
+(tests/golden/sampler_*.pt).
+"""
+import numpy as np
+import torch
+
+
+def subsampled_schedule(alphas, alphas_prev, betas, subsample_steps):
+    """models/__init__.py:229-237.  Returns (steps, alphas, alphas_prev, betas)."""
+    steps = np.arange(len(betas))
+    if subsample_steps is not None and subsample_steps < len(alphas):
+        skip = len(alphas) // subsample_steps
+        steps = torch.tensor(list(range(0, len(alphas), skip)))
+        alphas = alphas.index_select(0, steps)
+        alphas_prev = torch.cat([alphas[1:], torch.tensor([1.0]).to(alphas)])
+        betas = 1.0 - torch.div(alphas, alphas_prev)
+    return steps, alphas, alphas_prev, betas
+
+
+@torch.no_grad()
+def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=False, denoise=True,
+           subsample_steps=None, clip_before=True, t_min=-1, noise_fn=None, frac_steps=None):
+    """kind='ddpm': models/__init__.py:266-333.  kind='ddim': :142-198.
+    noise_fn(i, like) -> tensor shaped like `like` (i = -1 for the t_min re-noise draw)."""
+    assert kind in ("ddpm", "ddim")
+    if noise_fn is None:
+        noise_fn = lambda i, like: torch.randn_like(like)
+    steps, alphas, alphas_prev, betas = subsampled_schedule(
+        scorenet.alphas, scorenet.alphas_prev, scorenet.betas, subsample_steps)
+    if frac_steps is not None and kind == "ddpm":                     # :250-254
+        steps = steps[int((1 - frac_steps) * len(steps)):]
+        alphas, alphas_prev, betas = alphas[steps], alphas_prev[steps], betas[steps]
+
+    images = []
+    started = False
+    L = len(steps)
+    for i, step in enumerate(steps):
+        if step < t_min * len(alphas):                                # :269-270
+            continue
+        if not started and t_min > 0:                                 # :272-279
+            z = noise_fn(-1, x_mod)
+            x_mod = alphas[i].sqrt() * x_mod + (1 - alphas[i]).sqrt() * z
+        started = True
+
+        c_beta, c_alpha, c_alpha_prev = betas[i], alphas[i], alphas_prev[i]
+        labels = (step * torch.ones(x_mod.shape[0])).long()           # :283
+        grad = scorenet(x_mod, labels, cond=cond)                     # :284
+
+        x0 = (1 / c_alpha.sqrt()) * (x_mod - (1 - c_alpha).sqrt() * grad)   # :287
+        if clip_before:
+            x0 = x0.clip_(-1, 1)                                      # :288-289
+        if kind == "ddpm":
+            x_mod = (c_alpha_prev.sqrt() * c_beta / (1 - c_alpha)) * x0 \
+                + ((1 - c_beta).sqrt() * (1 - c_alpha_prev) / (1 - c_alpha)) * x_mod   # :290
+        else:
+            x_mod = c_alpha_prev.sqrt() * x0 + (1 - c_alpha_prev).sqrt() * grad        # :168
+
+        if not final_only:
+            images.append(x_mod.clone())
+
+        if kind == "ddpm" and i + 1 != L:                             # :311-328
+            noise = noise_fn(i, x_mod)
+            if just_beta:
+                x_mod = x_mod + c_beta.sqrt() * noise
+            else:
+                x_mod = x_mod + ((1 - c_alpha_prev) / (1 - c_alpha) * c_beta).sqrt() * noise
+
+    if denoise:                                                       # :331-335 (label L-1, sic)
+        last = ((L - 1) * torch.ones(x_mod.shape[0])).long()
+        x_mod = x_mod - (1 - alphas[-1]).sqrt() * scorenet(x_mod, last, cond=cond)
+        if not final_only:
+            images.append(x_mod.clone())
+
+    if final_only:
+        return x_mod.unsqueeze(0)
+    return torch.stack(images)

@@ -1,0 +1,108 @@
+"""CPU: the oracle restatement vs fixtures produced by the real reference
+(oracle/gen_golden.py).  Tolerances follow SURVEY 8c's measured noise floor."""
+import os
+
+import pytest
+import torch
+
+from oracle import sampler_ref, synth, unet_ref
+
+
+def load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+@pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt"])
+def test_schedule_bit_exact(golden_dir, fx):
+    g = load(golden_dir, fx)
+    c = unet_ref.hot_cfg(synth.make_config(g["config_name"]))
+    betas, alphas, alphas_prev = unet_ref.make_schedule(c)
+    assert torch.equal(betas, g["betas"])
+    assert torch.equal(alphas, g["alphas"])
+    assert torch.equal(alphas_prev, g["alphas_prev"])
+
+
+@pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt"])
+def test_forward_matches_reference(golden_dir, fx):
+    g = load(golden_dir, fx)
+    config = synth.make_config(g["config_name"])
+    sd = synth.make_state_dict(config, seed=123)
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    taps = {}
+    with torch.no_grad():
+        eps = unet_ref.unet_forward(sd, config, x, g["fwd_t"], cond, taps=taps)
+    ref = g["fwd_eps"]
+    assert eps.shape == ref.shape
+    assert (eps - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    # every module output, via the strided probes
+    assert sorted(taps.keys()) == sorted(g["fwd_taps"].keys())
+    for i, p in g["fwd_taps"].items():
+        mine = taps[i]
+        assert list(mine.shape) == p["shape"], i
+        got = mine.reshape(-1)[p["idx"]]
+        torch.testing.assert_close(got, p["sample"], rtol=1e-4, atol=2e-5, msg=f"module {i}")
+        assert abs(mine.double().mean().item() - p["mean"]) <= 1e-5 + 1e-4 * abs(p["absmean"])
+
+
+def _injector(noise):
+    k = [0]
+
+    def fn(i, like):
+        z = noise[k[0]]
+        k[0] += 1
+        return z
+    return fn, k
+
+
+@pytest.mark.parametrize("fx,key,kind,sub,extra", [
+    ("tiny_b3.pt", "ddpm_10", "ddpm", 10, {}),
+    ("tiny_b3.pt", "ddim_10", "ddim", 10, {}),
+    ("tiny_b3.pt", "ddpm_10_t_min0.35", "ddpm", 10, dict(t_min=0.35)),
+    ("tiny_spade_b2.pt", "ddpm_10", "ddpm", 10, {}),
+    ("smmnist_big5_b2.pt", "ddpm_100", "ddpm", 100, {}),      # BASELINE config 1, full 101 forwards
+])
+def test_sampler_matches_reference(golden_dir, fx, key, kind, sub, extra):
+    g = load(golden_dir, fx)
+    config = synth.make_config(g["config_name"])
+    net = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123))
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    noise = synth.make_noise(config, g["batch"], sub + 1, seed=2)
+    fn, k = _injector(noise)
+    out = sampler_ref.sample(x.clone(), net, cond=cond, kind=kind, final_only=True, denoise=True,
+                             subsample_steps=sub, clip_before=True, noise_fn=fn, **extra)
+    ref = g["sampler_" + key]["result"]
+    assert k[0] == g["sampler_" + key]["n_noise"]
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() <= 1e-4
+
+
+def test_fir_closed_forms(golden_dir):
+    g = load(golden_dir, "fir.pt")
+    torch.testing.assert_close(unet_ref.fir_up2(g["x"]), g["up"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(unet_ref.fir_down2(g["x"]), g["down"], rtol=1e-5, atol=1e-6)
+    a = g["generic_args"]
+    got = unet_ref.upfirdn2d_generic(g["x"], g["kernel"] * a["gain"], a["up"], a["down"], a["pad0"], a["pad1"])
+    torch.testing.assert_close(got, g["generic"], rtol=1e-5, atol=1e-6)
+    # the two hot-path uses expressed through the generic op (up_or_down_sampling.py:222-225, 255-258)
+    k = g["kernel"]
+    torch.testing.assert_close(unet_ref.upfirdn2d_generic(g["x"], k * 4, 2, 1, 2, 1), g["up"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(unet_ref.upfirdn2d_generic(g["x"], k, 1, 2, 1, 1), g["down"], rtol=1e-5, atol=1e-6)
+
+
+def test_conv_unfold_restatement():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 9, 9, generator=g)
+    for ks in (1, 3):
+        w = torch.randn(7, 5, ks, ks, generator=g)
+        b = torch.randn(7, generator=g)
+        torch.testing.assert_close(unet_ref.conv2d_unfold(x, w, b), unet_ref.conv2d(x, w, b), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,n_mod,n_param", [
+    ("smmnist_big5_ngf96", 43, 376), ("cityscapes_big", 50, None), ("bair_big_spade", 43, 716)])
+def test_topology_counts(name, n_mod, n_param):
+    """SURVEY 9.2 / 9.5 / 9.9 module and key counts (state_dict keys = params + 4 buffers)."""
+    c = unet_ref.hot_cfg(synth.make_config(name))
+    assert len(unet_ref.module_plan(c)) == n_mod
+    if n_param is not None:
+        assert len(unet_ref.param_shapes(c)) == n_param
