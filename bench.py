@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""Headline benchmark: sampled frames/s (whole job) of the DDPM sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE full sampler call over one batch: `ddpm_sampler` with subsample=100 (100 UNet forwards + fused updates
++ the denoise forward = 101 forwards) on BASELINE.json configs[1]: smmnist_DDPM_big5 with ngf=96, 64x64, 5 cond + 5
+predicted frames, batch 64 per GPU, synthetic random weights / inputs, on-device Philox noise.  Frames = B * 5 per
+step per GPU; `value` = frames of all ranks / max-over-ranks wall time (weak scaling: per-GPU batch fixed).
+Inputs are resident in HBM before the timed region.  One JSON line on stdout (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_config(name):
+    """BASELINE.json configs as reference-schema namespaces (hot-path keys; SURVEY section 0 override table)."""
+    from mcvd_pytorch_amd import dict2namespace
+    data = dict(image_size=64, channels=1, num_frames=5, num_frames_cond=5, num_frames_future=0)
+    model = dict(version="DDPM", arch="unetmore", type="v1", time_conditional=True, dropout=0.1, sigma_dist="linear",
+                 sigma_begin=0.02, sigma_end=0.0001, num_classes=1000, ngf=96, ch_mult=[1, 2, 3, 4], num_res_blocks=2,
+                 attn_resolutions=[8, 16, 32], n_head_channels=96, spade=False, spade_dim=128)
+    if name == "smmnist_big5_ngf96":
+        pass
+    elif name == "smmnist_big5":
+        model.update(ngf=64, n_head_channels=64)
+    elif name == "kth64_big_ngf128":
+        data.update(num_frames_cond=10)
+        model.update(ngf=128, n_head_channels=128)
+    elif name == "cityscapes_big":
+        data.update(image_size=128, channels=3, num_frames_cond=2)
+        model.update(ngf=128, n_head_channels=128, ch_mult=[1, 1, 2, 3, 4])
+    else:
+        raise KeyError(name)
+    return dict2namespace(dict(data=data, model=model, sampling=dict(subsample=100, denoise=True, clip_before=True)))
+
+
+def cpu_baseline(config, state_dict, subsample, budget_s=20.0):
+    """The CPU port of the reference sampler (oracle/, torch CPU fp32, all host cores) timed on a bounded sample of the
+    same workload: B=4, as many sampler steps as fit the budget (each step = one identical UNet forward + update),
+    extrapolated linearly to the 101 forwards of a full call.  kind="port": the Python reference cannot travel."""
+    from oracle import sampler_ref, unet_ref
+    from mcvd_pytorch_amd import synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 4
+    net = unet_ref.OracleScoreNet(config, {k: v.float().cpu() for k, v in state_dict.items()})
+    x, cond = synthetic.random_inputs(config, 0, B)
+    t = torch.full((B,), 500).long()
+    with torch.no_grad():
+        net(x, t, cond=cond)                                    # warm-up
+    n_steps, t0 = 0, time.perf_counter()
+
+    class Stop(Exception):
+        pass
+
+    def counting(xx, yy, cond=None):
+        nonlocal n_steps
+        if time.perf_counter() - t0 > budget_s and n_steps >= 3:
+            raise Stop()
+        n_steps += 1
+        return net(xx, yy, cond=cond)
+    counting.alphas, counting.alphas_prev, counting.betas = net.alphas, net.alphas_prev, net.betas
+    try:
+        sampler_ref.sample(x, counting, cond=cond, kind="ddpm", final_only=True, denoise=True, subsample_steps=subsample)
+    except Stop:
+        pass
+    dt = time.perf_counter() - t0
+    per_fwd = dt / max(n_steps, 1)
+    fps = B * config.data.num_frames / (per_fwd * (subsample + 1))
+    return dict(value=round(fps, 4), unit="frames/s", cores=cores, kind="port",
+                sample=f"oracle ddpm_sampler, B={B}, {n_steps} of {subsample + 1} forwards timed ({dt:.1f}s), "
+                       f"extrapolated linearly; torch {torch.__version__} CPU, {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="smmnist_big5_ngf96")
+    ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
+    ap.add_argument("--subsample", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    from mcvd_pytorch_amd import HipScoreNet, ddpm_sampler, synthetic
+    from mcvd_pytorch_amd.dist import broadcast_weights, gather_rows, shard_rows
+
+    config = make_config(args.config)
+    config.device = f"cuda:{local}"
+    net = HipScoreNet(config)
+    sd = None
+    if rank == 0:
+        sd = synthetic.random_state_dict(net, seed=123)
+        net.load_state_dict(sd, strict=True)
+    broadcast_weights(net, src=0)                    # ONE RCCL broadcast of the packed blob (no-op at N=1)
+    net.set_option("profile", 1)
+
+    B = args.batch
+    total = B * world
+    b0, b1 = shard_rows(total, rank, world)
+    x, cond = synthetic.random_inputs(config, b0, b1 - b0)
+    x, cond = x.cuda(), cond.cuda()
+    nfr = config.data.num_frames
+
+    def one_step(i):
+        out = ddpm_sampler(x, net, cond=cond, final_only=True, denoise=True, subsample_steps=args.subsample,
+                           clip_before=True, verbose=False, log=False, seed=1000 + i, sample_offset=b0)
+        return gather_rows(out[0], total)            # final gather of the generated frames
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(-1 - i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frames = one_step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    assert torch.isfinite(frames).all() and frames.shape[0] == total
+    value = args.steps * total * nfr / dt
+
+    # ---- per-op HIP-event timings of one forward inside the timed region (first forward of the last step)
+    import ctypes as C
+    from mcvd_pytorch_amd import _lib
+    n = _lib.lib.mcvd_model_profile_read(net._model, None, None, None, None, None, 0)
+    kinds, kss = (C.c_int * n)(), (C.c_int * n)()
+    ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    _lib.check(0 if _lib.lib.mcvd_model_profile_read(net._model, kinds, kss, ms, fl, by, n) == n else -1, "profile_read")
+    names = {0: "temb_mlp", 1: "dense_all", 2: "gn_coef", 3: "conv", 4: "fir2", 5: "attention"}
+    agg = {}
+    for i in range(n):
+        key = names[kinds[i]] + (f"{kss[i]}x{kss[i]}" if kinds[i] == 3 else "")
+        a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        a["launches"] += 1; a["ms"] += ms[i]; a["flops"] += fl[i]; a["bytes"] += by[i]
+    fwd_ms = sum(a["ms"] for a in agg.values())
+    breakdown = {k: dict(launches=a["launches"], ms=round(a["ms"], 3), share=round(a["ms"] / fwd_ms, 4),
+                         tflops=round(a["flops"] / a["ms"] / 1e9, 2), gbs=round(a["bytes"] / a["ms"] / 1e6, 1))
+                 for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    c3 = agg["conv3x3"]
+    achieved = c3["flops"] / c3["ms"] / 1e9
+    roofline = dict(bound="mfma", kernel="conv_mfma_kernel<3x3> (implicit-GEMM, v_mfma_f32_32x32x2_f32)",
+                    achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                    launches=c3["launches"], avg_launch_us=round(1e3 * c3["ms"] / c3["launches"], 1),
+                    flops_per_launch_avg=c3["flops"] / c3["launches"], forward_ms_events=round(fwd_ms, 3),
+                    breakdown=breakdown)
+
+    if rank == 0:
+        res = dict(metric="sampled frames/sec (whole node), SMMNIST 64x64 DDPM 100-step", value=round(value, 3),
+                   unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(1e3 * dt / args.steps, 2), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="f32", data="synthetic",
+                   config=dict(workload=f"{args.config}: ddpm_sampler subsample={args.subsample} (+1 denoise forward), "
+                                        f"64x64, 5 cond + 5 pred frames, batch {B}/GPU, random-init weights, Philox noise",
+                               global_batch=total, frames_per_step=total * nfr, forwards_per_step=args.subsample + 1,
+                               parallelism=f"sample-sharded x{world} (1 weight broadcast + 1 final all_gather)"),
+                   roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(config, sd, args.subsample)
+                res["cpu_baseline"]["speedup"] = round(value / res["cpu_baseline"]["value"], 1)
+            except Exception as e:      # the baseline is reporting only; never lose the GPU line
+                res["cpu_baseline"] = dict(value=None, unit="frames/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e}")
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+/*
+ * mcvd_hip.h -- C ABI of libmcvd_hip.so: MI355X (gfx950) native implementation of the
+ * MCVD DDPM/DDIM sampling hot path (conditional `unetmore` UNet + sampler loop).
+ *
+ * Plain pointers and sizes only; no torch types.  All tensor pointers are fp32,
+ * contiguous NCHW, DEVICE memory unless a parameter says "host".  Every function
+ * returns 0 on success or a negative MCVD_E* code and never throws across the ABI;
+ * mcvd_last_error() gives the message (reference convention: Python exceptions /
+ * assert, e.g. models/better/ncsnpp_more.py:382, models/better/layerspp.py:227).
+ *
+ * Ownership: the caller owns x / cond / eps / noise buffers; the library owns its
+ * parameter blob, packed weights, caches and workspace.  Nothing is allocated inside
+ * the step loop once a batch size has been seen.  One mcvd_ctx per device; calls on
+ * one ctx are externally serialised; different ctxs may be used concurrently.  All
+ * work is enqueued on the HIP stream given to the ctx (reference: the native op runs
+ * on at::cuda::getCurrentCUDAStream, models/better/op/upfirdn2d_kernel.cu:213-215).
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   mcvd_model_create/set_param/finalize  <- get_model + load_state_dict,
+ *                                            runners/ncsn_runner.py:180-195, :923-932
+ *   mcvd_unet_forward                     <- UNetMore_DDPM.forward, models/better/ncsnpp_more.py:753-770
+ *   mcvd_sampler_run                      <- ddpm_sampler / ddim_sampler, models/__init__.py:206-340 / :102-203
+ *   mcvd_sampler_update                   <- the per-step update algebra, models/__init__.py:287-290, :165-168, :324-328
+ *   mcvd_upfirdn2d                        <- pybind upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0..pad_y1),
+ *                                            models/better/op/upfirdn2d.cpp:12-23
+ *   mcvd_model_export_blob/import_blob    <- nn.DataParallel's per-forward replicate (runners/ncsn_runner.py:924);
+ *                                            here ONE broadcast of the packed blob at load time
+ */
+#ifndef MCVD_HIP_H
+#define MCVD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCVD_OK 0
+#define MCVD_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define MCVD_EHIP (-2)     /* HIP runtime error */
+#define MCVD_ESTATE (-3)   /* call order violated (e.g. forward before finalize, missing parameter) */
+#define MCVD_ENOMEM (-4)
+
+#define MCVD_MAX_LEVELS 8
+
+typedef struct mcvd_ctx mcvd_ctx;
+typedef struct mcvd_model mcvd_model;
+
+/* The hot-path keys of the reference YAML schema (configs/[name].yml, data.* and model.*). */
+typedef struct mcvd_unet_desc {
+    int32_t image_size;        /* data.image_size */
+    int32_t channels;          /* data.channels */
+    int32_t num_frames;        /* data.num_frames (frames predicted per block) */
+    int32_t num_frames_cond;   /* data.num_frames_cond + data.num_frames_future (ncsnpp_more.py:47) */
+    int32_t ngf;               /* model.ngf */
+    int32_t n_levels;          /* len(model.ch_mult) */
+    int32_t ch_mult[MCVD_MAX_LEVELS];
+    int32_t num_res_blocks;    /* model.num_res_blocks */
+    int32_t n_attn;            /* len(model.attn_resolutions) */
+    int32_t attn_resolutions[MCVD_MAX_LEVELS];
+    int32_t n_head_channels;   /* model.n_head_channels (-1: single head) */
+    int32_t spade;             /* model.spade */
+    int32_t spade_dim;         /* model.spade_dim */
+    int32_t num_classes;       /* model.num_classes (T) */
+    int32_t sigma_dist;        /* 0 = linear, 1 = cosine (models/__init__.py:16-35) */
+    float sigma_begin;         /* model.sigma_begin */
+    float sigma_end;           /* model.sigma_end */
+} mcvd_unet_desc;
+
+/* sampler kinds / flags (models/__init__.py) */
+#define MCVD_SAMPLER_DDPM 0
+#define MCVD_SAMPLER_DDIM 1
+#define MCVD_FLAG_DENOISE 1      /* denoise=True  (:331-333) */
+#define MCVD_FLAG_CLIP_BEFORE 2  /* clip_before=True (:288-289) */
+#define MCVD_FLAG_JUST_BETA 4    /* just_beta=True (:325-326) */
+
+/* ---- context ---------------------------------------------------------------------- */
+int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out);
+void mcvd_ctx_destroy(mcvd_ctx* ctx);
+int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
+/* options: "naive_conv", "naive_attn" (0/1: route through the simple one-thread-per-output HIP kernels, used by the
+ * tests to triangulate), "conv_shape" (-1 auto; 0/1/2 force the 256/128/64-pixel conv tile), "profile" (0/1, see
+ * mcvd_model_profile_read), "graph" (0/1: hipGraph replay of the forward). */
+int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value);
+const char* mcvd_last_error(mcvd_ctx* ctx); /* ctx may be NULL: last error of this thread */
+const char* mcvd_version(void);
+
+/* ---- model ------------------------------------------------------------------------ */
+/* ctx may be NULL: a plan-only model (parameter table, schedule, launch count; no device memory) for GPU-less host tests. */
+int mcvd_model_create(mcvd_ctx* ctx, const mcvd_unet_desc* desc, mcvd_model** out);
+void mcvd_model_destroy(mcvd_model* m);
+/* Parameters are addressed by their reference state_dict names ("unet.all_modules.3.Conv_0.weight");
+ * a leading "module." (DataParallel prefix, runners/ncsn_runner.py:426-433) is accepted and ignored. */
+int mcvd_model_num_params(mcvd_model* m);
+int mcvd_model_param_info(mcvd_model* m, int index, const char** name, int64_t shape[4], int* ndim,
+                          int64_t* blob_offset_floats);
+int mcvd_model_set_param(mcvd_model* m, const char* name, const float* data, const int64_t* shape, int ndim,
+                         int data_on_device);
+/* The raw parameter blob (all parameters, state_dict order, fp32): for the one-shot RCCL broadcast. */
+int mcvd_model_blob_floats(mcvd_model* m, int64_t* n_floats);
+int mcvd_model_export_blob(mcvd_model* m, float* dst_device);
+int mcvd_model_import_blob(mcvd_model* m, const float* src_device); /* marks every parameter as set */
+/* Pack/transposes weights into kernel layouts, builds the static op plan. */
+int mcvd_model_finalize(mcvd_model* m);
+/* Schedule buffers exactly as UNetMore_DDPM registers them (ncsnpp_more.py:735-743); host pointers, n = num_classes. */
+int mcvd_model_get_schedule(mcvd_model* m, float* betas_host, float* alphas_host, float* alphas_prev_host, int n);
+/* Overwrite the schedule buffers (host pointers, n = num_classes).  The library's own default restates the reference in C;
+ * hosts that already hold the reference's buffers (a loaded checkpoint: state_dict keys betas/alphas/alphas_prev) pass them. */
+int mcvd_model_set_schedule(mcvd_model* m, const float* betas_host, const float* alphas_host, const float* alphas_prev_host,
+                            int n);
+/* Sinusoid frequency table of get_timestep_embedding (layers.py:504-518); host pointer, n = ngf/2.
+ * Optional: the library computes exp(-k ln(1e4)/(half-1)) itself; callers that need bit-identity with another
+ * libm (torch's vectorised expf) may overwrite it. */
+int mcvd_model_set_temb_freqs(mcvd_model* m, const float* freqs_host, int n);
+
+/* eps = UNet(x, labels, cond).  x:[B, C*nf, S, S]  labels:[B] int64  cond:[B, C*nc, S, S] (NULL iff nc==0)  eps like x. */
+int mcvd_unet_forward(mcvd_model* m, const float* x, const int64_t* labels, const float* cond, float* eps_out, int B);
+/* Number of kernels one forward enqueues at this batch size (for tests / DESIGN.md). */
+int mcvd_model_num_launches(mcvd_model* m, int B);
+
+/* Measurement aid (bench.py roofline): with ctx option "profile"=1 the first UNet forward of every mcvd_sampler_run is bracketed
+ * op by op with HIP events on the ctx stream (no extra synchronisation).  This call synchronises and returns, per op of that
+ * forward: kind (0 temb,1 dense,2 groupnorm-coef,3 conv,4 fir,5 attention), conv kernel size (else 0), elapsed ms, algorithmic
+ * flops and algorithmic bytes.  Call with kinds == NULL to get the op count.  Returns the op count or a negative error. */
+int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, double* flops, double* bytes, int cap);
+
+/* Debug/test aid: copy the output tensor of reference module `module` (index in all_modules, ncsnpp_more.py:249) from the
+ * last forward at batch size B into dst_device ([B, C, H, H], capacity in floats).  The workspace keeps every intermediate of a
+ * forward, so this needs no re-execution.  Module 1 returns SiLU(temb) [B, 4*ngf] (C = 4*ngf, H = 0). */
+int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst_device, int64_t capacity, int* C, int* H);
+
+/* ---- sampler ---------------------------------------------------------------------- */
+/* The whole L-step loop on device: schedule subsampling (:229-237), labels, forward, x0/clip/posterior (+noise),
+ * t_min re-noise (:269-280), denoise pass with label L-1 (:331-333).  x_inout:[B,C*nf,S,S] is overwritten.
+ * noise: NULL -> counter-based Philox keyed by (seed, sample_offset + row, step) so results do not depend on how rows are
+ * sharded over GPUs; else [n_draws, B, C*nf, S, S] consumed in draw order (t_min draw first, then one per step). */
+int mcvd_sampler_run(mcvd_model* m, int kind, float* x_inout, const float* cond, const float* noise, uint64_t seed,
+                     uint64_t sample_offset, int subsample_steps, int flags, float t_min, int B);
+/* One fused update (host-driven loops, final_only=False / verbose paths).  Coefficients are the fp32 scalars the
+ * reference computes: x0 = c_x0a*(x - c_x0b*eps); clip; x = c_mean0*x0 + c_mean1*(ddpm: x | ddim: eps) + c_noise*z. */
+int mcvd_sampler_update(mcvd_ctx* ctx, int kind, float* x_inout, const float* eps, const float* noise, float c_x0a,
+                        float c_x0b, float c_mean0, float c_mean1, float c_noise, int clip, int64_t n);
+/* z ~ N(0,1) from the same Philox stream mcvd_sampler_run uses: out:[B, per_sample]. */
+int mcvd_randn(mcvd_ctx* ctx, float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B,
+               int64_t per_sample);
+
+/* ---- stand-alone ops (unit parity against the oracle; also the reference's only native op) ----------------- */
+/* upfirdn2d on [N, C, H, W] planes; kernel:[kh,kw] HOST pointer.  out:[N,C,oh,ow], oh=(H*up+pad0+pad1-kh)/down+1. */
+int mcvd_upfirdn2d(mcvd_ctx* ctx, const float* in, const float* kernel_host, int kh, int kw, int up, int down, int pad0,
+                   int pad1, float* out, int N, int C, int H, int W);
+/* y = act_scale( conv_{ks}( prologue(x) ) + bias [+ res] ) with prologue(x) = silu?(coefA*x + coefB) per (b, channel).
+ * x0:[B,C0,H,W], x1:[B,C1,H,W] (virtual channel concat; x1 may be NULL), w:[Cout,C0+C1,ks,ks] reference layout (device),
+ * coef:[B, C0+C1, 2] or NULL, res:[B,Cout,H,W] or NULL. */
+int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
+                   int Cout, int ks, const float* coef, int act, const float* res, float out_scale, float* y, int B, int H,
+                   int W);
+/* GroupNorm statistics folded to per-(b,c) affine coefficients: y = A*x + B.
+ * mode 0: plain (A=rstd, B=-mean*rstd); mode 1: temb scale/shift, emb:[B, emb_stride] with scale at emb_off+c and shift at
+ * emb_off+C+c (layerspp.py:521-535); mode 2: affine weight/bias:[C] (torch GroupNorm affine=True). */
+int mcvd_op_gn_coef(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int C1, int groups, float eps, int mode,
+                    const float* p0, const float* p1, int emb_stride, int emb_off, float* coef_out, int B, int HW);
+/* Multi-head self-attention core on qkv:[B, 3C, HW] (q rows 0..C-1, k rows C..2C-1, v rows 2C..3C-1, heads are
+ * contiguous channel chunks, layerspp.py:237-244) -> out:[B, C, HW]. */
+int mcvd_op_attention(mcvd_ctx* ctx, const float* qkv, float* out, int B, int C, int heads, int HW);
+/* FIR x2 resample with k=[1,3,3,1] (up: gain 4) and optional prologue silu?(A*x+B): the fused form used in ResBlocks. */
+int mcvd_op_fir2(mcvd_ctx* ctx, const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCVD_HIP_H */

@@ -1,0 +1,72 @@
+"""Config plumbing: the reference's YAML schema is accepted unchanged (main.py:76-91, :359-367)."""
+import argparse
+
+from . import _lib
+
+
+def dict2namespace(config):
+    """Nested dict -> nested argparse.Namespace (reference: main.py:359-367)."""
+    namespace = argparse.Namespace()
+    for key, value in config.items():
+        setattr(namespace, key, dict2namespace(value) if isinstance(value, dict) else value)
+    return namespace
+
+
+def load_config(path, config_mod=()):
+    """YAML file + `--config_mod sec.key=val` overrides (reference: main.py:76-91)."""
+    import yaml
+    with open(path, "r") as f:
+        cfg = yaml.safe_load(f)
+    for mod in config_mod:
+        key, val = mod.split("=", 1)
+        sec, k = key.split(".", 1)
+        try:
+            val = eval(val, {"__builtins__": {}}, {})      # numbers / lists / booleans, like the reference's eval
+        except Exception:
+            pass
+        cfg[sec][k] = val
+    return dict2namespace(cfg)
+
+
+_UNSUPPORTED_FLAGS = ("cond_emb", "noise_in_cond", "gamma", "output_all_frames")
+
+
+def desc_from_config(config):
+    """mcvd_unet_desc from config.data / config.model (keys: SURVEY section 5 'config')."""
+    d, m = config.data, config.model
+    arch = getattr(m, "arch", "unetmore")
+    if arch != "unetmore":
+        raise NotImplementedError(f"model.arch={arch!r}: only 'unetmore' (2-D) is on the accelerated path")
+    for flag in _UNSUPPORTED_FLAGS:
+        if getattr(m, flag, False):
+            raise NotImplementedError(f"model.{flag}=True is not supported by the HIP path")
+    if not getattr(m, "time_conditional", True):
+        raise NotImplementedError("model.time_conditional=False is not supported by the HIP path")
+    desc = _lib.UNetDesc()
+    desc.image_size = int(d.image_size)
+    desc.channels = int(d.channels)
+    desc.num_frames = int(d.num_frames)
+    desc.num_frames_cond = int(d.num_frames_cond) + int(getattr(d, "num_frames_future", 0))
+    desc.ngf = int(m.ngf)
+    ch_mult = [int(v) for v in m.ch_mult]
+    attn = [int(v) for v in m.attn_resolutions]
+    if len(ch_mult) > _lib.MAX_LEVELS or len(attn) > _lib.MAX_LEVELS:
+        raise ValueError("too many levels")
+    desc.n_levels = len(ch_mult)
+    for i, v in enumerate(ch_mult):
+        desc.ch_mult[i] = v
+    desc.num_res_blocks = int(m.num_res_blocks)
+    desc.n_attn = len(attn)
+    for i, v in enumerate(attn):
+        desc.attn_resolutions[i] = v
+    desc.n_head_channels = int(getattr(m, "n_head_channels", -1))
+    desc.spade = 1 if getattr(m, "spade", False) else 0
+    desc.spade_dim = int(getattr(m, "spade_dim", 128))
+    desc.num_classes = int(m.num_classes)
+    dist = getattr(m, "sigma_dist", "linear")
+    if dist not in ("linear", "cosine"):
+        raise NotImplementedError(f"sigma_dist={dist!r}")
+    desc.sigma_dist = 0 if dist == "linear" else 1
+    desc.sigma_begin = float(m.sigma_begin)
+    desc.sigma_end = float(m.sigma_end)
+    return desc

@@ -1,0 +1,488 @@
+// extern "C" surface of libmcvd_hip.so (see include/mcvd_hip.h).  Nothing here throws.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "model.h"
+
+using namespace mcvd;
+
+#define API_TRY try {
+#define API_CATCH                                             \
+    }                                                         \
+    catch (const std::bad_alloc&) {                           \
+        mcvd::set_error("out of host memory");                \
+        return MCVD_ENOMEM;                                   \
+    }                                                         \
+    catch (...) {                                             \
+        mcvd::set_error("unexpected C++ exception");          \
+        return MCVD_EINVAL;                                   \
+    }
+
+extern "C" {
+
+const char* mcvd_version(void) { return "mcvd_hip 0.1 (gfx950)"; }
+
+const char* mcvd_last_error(mcvd_ctx*) { return mcvd::get_error(); }
+
+int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
+    API_TRY
+    MCVD_REQUIRE(out, "ctx_create: out is NULL");
+    int n = 0;
+    MCVD_HIP_CHECK(hipGetDeviceCount(&n));
+    MCVD_REQUIRE(device >= 0 && device < n, "ctx_create: device %d not in [0,%d)", device, n);
+    MCVD_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MCVD_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    MCVD_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "this library is built for gfx950 only; device %d is %s", device,
+                 prop.gcnArchName);
+    mcvd_ctx* c = new mcvd_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    const char* e = getenv("MCVD_NAIVE");
+    if (e) {
+        const int v = atoi(e);
+        c->naive_conv = v & 1;
+        c->naive_attn = (v >> 1) & 1;
+    }
+    *out = c;
+    return 0;
+    API_CATCH
+}
+
+void mcvd_ctx_destroy(mcvd_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    delete ctx;
+}
+
+int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream) {
+    MCVD_REQUIRE(ctx, "ctx is NULL");
+    ctx->stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
+    MCVD_REQUIRE(ctx && key, "ctx/key is NULL");
+    if (!strcmp(key, "naive_conv")) ctx->naive_conv = value;
+    else if (!strcmp(key, "naive_attn")) ctx->naive_attn = value;
+    else if (!strcmp(key, "graph")) ctx->graph = value;
+    else if (!strcmp(key, "conv_shape")) ctx->conv_shape = value;
+    else if (!strcmp(key, "profile")) ctx->profile = value;
+    else {
+        set_error("unknown option '%s'", key);
+        return MCVD_EINVAL;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ model
+static void default_schedule(mcvd_model* m) {
+    // models/__init__.py:24-32 + ncsnpp_more.py:735-743 in fp32.  torch.linspace is symmetric about the midpoint
+    // (ATen RangeFactories: start + step*i for i < steps/2, end - step*(steps-1-i) otherwise).
+    const int T = m->d.num_classes;
+    m->betas.assign(T, 0.f);
+    m->alphas.assign(T, 0.f);
+    m->alphas_prev.assign(T, 0.f);
+    if (m->d.sigma_dist == 0) {
+        const float start = m->d.sigma_begin, end = m->d.sigma_end;
+        const float step = (end - start) / (float)(T - 1);
+        for (int i = 0; i < T; ++i) m->betas[i] = (i < T / 2) ? start + step * (float)i : end - step * (float)(T - 1 - i);
+        float p = 1.0f;                      // alphas = cumprod(1 - betas.flip(0)).flip(0)
+        for (int i = T - 1; i >= 0; --i) {
+            p = p * (1.0f - m->betas[i]);
+            m->alphas[i] = p;
+        }
+        for (int i = 0; i < T; ++i) m->alphas_prev[i] = (i + 1 < T) ? m->alphas[i + 1] : 1.0f;
+    } else {
+        // cosine: t = linspace(T, 0, T+1)/T ; f = cos((t+s)/(1+s)*pi/2)^2 ; alphas = f[:-1]/f[-1]
+        std::vector<float> f(T + 1);
+        const float s = 0.008f;
+        for (int i = 0; i <= T; ++i) {
+            const float t = (float)(T - i) / (float)T;
+            const float c = cosf((t + s) / (1.0f + s) * (float)(M_PI / 2));
+            f[i] = c * c;
+        }
+        for (int i = 0; i < T; ++i) m->alphas[i] = f[i] / f[T];
+        for (int i = 0; i < T; ++i) m->alphas_prev[i] = (i + 1 < T) ? m->alphas[i + 1] : 1.0f;
+        for (int i = 0; i < T; ++i) m->betas[i] = 1.0f - m->alphas[i] / m->alphas_prev[i];
+    }
+    // layers.py:507-510: exp(arange(half) * -(log(10000)/(half-1))) in fp32
+    const int half = m->d.ngf / 2;
+    m->freqs.assign(half, 0.f);
+    const float e = (float)(-(log(10000.0) / (double)(half - 1)));
+    for (int k = 0; k < half; ++k) m->freqs[k] = expf((float)k * e);
+}
+
+int mcvd_model_create(mcvd_ctx* ctx, const mcvd_unet_desc* desc, mcvd_model** out) {
+    API_TRY
+    MCVD_REQUIRE(desc && out, "model_create: NULL argument");
+    MCVD_REQUIRE(desc->sigma_dist == 0 || desc->sigma_dist == 1, "desc: sigma_dist=%d", desc->sigma_dist);
+    mcvd_model* m = new mcvd_model();
+    m->ctx = ctx;
+    m->d = *desc;
+    if (m->build_plan()) {
+        delete m;
+        return MCVD_EINVAL;
+    }
+    default_schedule(m);
+    if (ctx) {      // ctx == NULL: plan-only model (parameter table, schedule, launch count) for GPU-less host tests
+        hipError_t e = hipMalloc((void**)&m->blob, (size_t)m->blob_floats * sizeof(float));
+        if (e != hipSuccess) {
+            set_error("hipMalloc(param blob, %lld floats): %s", (long long)m->blob_floats, hipGetErrorString(e));
+            delete m;
+            return MCVD_EHIP;
+        }
+        MCVD_HIP_CHECK(hipMemsetAsync(m->blob, 0, (size_t)m->blob_floats * sizeof(float), ctx->stream));
+    }
+    *out = m;
+    return 0;
+    API_CATCH
+}
+
+void mcvd_model_destroy(mcvd_model* m) {
+    if (!m) return;
+    if (m->ctx) (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->blob) (void)hipFree(m->blob);
+    if (m->packed) (void)hipFree(m->packed);
+    if (m->arena) (void)hipFree(m->arena);
+    if (m->labels) (void)hipFree(m->labels);
+    if (m->eps_buf) (void)hipFree(m->eps_buf);
+    for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+    delete m;
+}
+
+int mcvd_model_num_params(mcvd_model* m) { return m ? (int)m->params.size() : MCVD_EINVAL; }
+
+int mcvd_model_param_info(mcvd_model* m, int index, const char** name, int64_t shape[4], int* ndim,
+                          int64_t* blob_offset_floats) {
+    MCVD_REQUIRE(m && index >= 0 && index < (int)m->params.size(), "param_info: index %d out of range", index);
+    const ParamInfo& p = m->params[index];
+    if (name) *name = p.name.c_str();
+    if (shape) memcpy(shape, p.shape, sizeof(p.shape));
+    if (ndim) *ndim = p.ndim;
+    if (blob_offset_floats) *blob_offset_floats = p.off;
+    return 0;
+}
+
+int mcvd_model_set_param(mcvd_model* m, const char* name, const float* data, const int64_t* shape, int ndim,
+                         int data_on_device) {
+    API_TRY
+    MCVD_REQUIRE(m && name && data, "set_param: NULL argument");
+    MCVD_REQUIRE(m->ctx, "set_param: plan-only model (created without a ctx)");
+    const int i = m->find_param(name);
+    MCVD_REQUIRE(i >= 0, "set_param: unknown parameter '%s'", name);
+    ParamInfo& p = m->params[i];
+    bool same = (ndim == p.ndim);
+    for (int k = 0; same && k < ndim; ++k) same = (shape[k] == p.shape[k]);
+    MCVD_REQUIRE(same, "set_param: shape mismatch for '%s'", name);
+    MCVD_HIP_CHECK(hipMemcpyAsync(m->blob + p.off, data, (size_t)p.numel * sizeof(float),
+                                  data_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->ctx->stream));
+    if (!data_on_device) MCVD_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));   // caller may free the host buffer
+    p.set = true;
+    m->finalized = false;
+    return 0;
+    API_CATCH
+}
+
+int mcvd_model_blob_floats(mcvd_model* m, int64_t* n_floats) {
+    MCVD_REQUIRE(m && n_floats, "blob_floats: NULL argument");
+    *n_floats = m->blob_floats;
+    return 0;
+}
+
+int mcvd_model_export_blob(mcvd_model* m, float* dst_device) {
+    MCVD_REQUIRE(m && dst_device && m->ctx, "export_blob: NULL argument");
+    MCVD_HIP_CHECK(hipMemcpyAsync(dst_device, m->blob, (size_t)m->blob_floats * sizeof(float), hipMemcpyDeviceToDevice,
+                                  m->ctx->stream));
+    return 0;
+}
+
+int mcvd_model_import_blob(mcvd_model* m, const float* src_device) {
+    MCVD_REQUIRE(m && src_device && m->ctx, "import_blob: NULL argument");
+    MCVD_HIP_CHECK(hipMemcpyAsync(m->blob, src_device, (size_t)m->blob_floats * sizeof(float), hipMemcpyDeviceToDevice,
+                                  m->ctx->stream));
+    for (auto& p : m->params) p.set = true;
+    m->finalized = false;
+    return 0;
+}
+
+int mcvd_model_finalize(mcvd_model* m) {
+    API_TRY
+    MCVD_REQUIRE(m && m->ctx, "finalize: NULL model or plan-only model");
+    for (const auto& p : m->params) MCVD_REQUIRE(p.set, "finalize: parameter '%s' was never set", p.name.c_str());
+    hipStream_t s = m->ctx->stream;
+    if (!m->packed) MCVD_HIP_CHECK(hipMalloc((void**)&m->packed, (size_t)m->packed_floats * sizeof(float)));
+    MCVD_HIP_CHECK(hipMemsetAsync(m->packed, 0, (size_t)m->packed_floats * sizeof(float), s));
+    for (const ConvPack& p : m->packs) {
+        for (size_t j = 0; j < p.weights.size(); ++j) {
+            const ParamInfo& w = m->params[m->find_param(p.weights[j].c_str())];
+            const ParamInfo& b = m->params[m->find_param(p.biases[j].c_str())];
+            if (int rc = launch_pack_conv_weight(m->blob + w.off, m->packed + p.wp, p.Cout_each, p.Cin, p.ks, p.CinP, p.CoutP,
+                                                 p.nin, (int)j * p.Cout_each, s))
+                return rc;
+            MCVD_HIP_CHECK(hipMemcpyAsync(m->packed + p.bias + j * p.Cout_each, m->blob + b.off,
+                                          (size_t)p.Cout_each * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    for (const DenseEntry& e : m->dense) {
+        const ParamInfo& w = m->params[m->find_param(e.weight.c_str())];
+        const ParamInfo& b = m->params[m->find_param(e.bias.c_str())];
+        if (int rc = launch_transpose_into(m->blob + w.off, m->packed + m->dense_wt, 2 * e.ch, m->T, m->NE, e.emb_off, s)) return rc;
+        MCVD_HIP_CHECK(hipMemcpyAsync(m->packed + m->dense_bias + e.emb_off, m->blob + b.off, (size_t)2 * e.ch * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s));
+    }
+    MCVD_HIP_CHECK(hipMemcpyAsync(m->packed + m->freqs_off, m->freqs.data(), m->freqs.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, s));
+    MCVD_HIP_CHECK(hipStreamSynchronize(s));
+    m->finalized = true;
+    return 0;
+    API_CATCH
+}
+
+int mcvd_model_get_schedule(mcvd_model* m, float* betas, float* alphas, float* alphas_prev, int n) {
+    MCVD_REQUIRE(m && n == m->d.num_classes, "get_schedule: n must equal num_classes");
+    if (betas) memcpy(betas, m->betas.data(), n * sizeof(float));
+    if (alphas) memcpy(alphas, m->alphas.data(), n * sizeof(float));
+    if (alphas_prev) memcpy(alphas_prev, m->alphas_prev.data(), n * sizeof(float));
+    return 0;
+}
+
+int mcvd_model_set_schedule(mcvd_model* m, const float* betas, const float* alphas, const float* alphas_prev, int n) {
+    MCVD_REQUIRE(m && betas && alphas && alphas_prev && n == m->d.num_classes, "set_schedule: bad arguments");
+    m->betas.assign(betas, betas + n);
+    m->alphas.assign(alphas, alphas + n);
+    m->alphas_prev.assign(alphas_prev, alphas_prev + n);
+    return 0;
+}
+
+int mcvd_model_set_temb_freqs(mcvd_model* m, const float* freqs_host, int n) {
+    MCVD_REQUIRE(m && freqs_host && n == m->d.ngf / 2, "set_temb_freqs: n must equal ngf/2");
+    m->freqs.assign(freqs_host, freqs_host + n);
+    if (m->packed && m->ctx) {
+        MCVD_HIP_CHECK(hipMemcpyAsync(m->packed + m->freqs_off, m->freqs.data(), n * sizeof(float), hipMemcpyHostToDevice,
+                                      m->ctx->stream));
+        MCVD_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    }
+    return 0;
+}
+
+int mcvd_unet_forward(mcvd_model* m, const float* x, const int64_t* labels, const float* cond, float* eps_out, int B) {
+    API_TRY
+    MCVD_REQUIRE(m, "forward: NULL model");
+    return m->forward(x, labels, cond, eps_out, B);
+    API_CATCH
+}
+
+int mcvd_model_num_launches(mcvd_model* m, int) { return m ? (int)m->ops.size() : MCVD_EINVAL; }
+
+// Per-op timings of the last event-instrumented forward (option "profile").  Arrays of length >= n_ops:
+// kind (OpKind), ks (conv kernel size or 0), ms, algorithmic flops, algorithmic bytes (inputs + outputs + weights once).
+int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, double* flops, double* bytes, int cap) {
+    MCVD_REQUIRE(m && m->ctx, "profile_read: NULL model");
+    const int n = (int)m->ops.size();
+    if (!kinds) return n;
+    MCVD_REQUIRE(cap >= n, "profile_read: capacity %d < %d ops", cap, n);
+    MCVD_REQUIRE(m->ev.size() == 2 * (size_t)n && m->profile_B > 0, "profile_read: no instrumented forward recorded");
+    MCVD_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    const double B = m->profile_B;
+    for (int i = 0; i < n; ++i) {
+        const Op& op = m->ops[i];
+        float t = 0.f;
+        MCVD_HIP_CHECK(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
+        kinds[i] = (int)op.kind;
+        ks[i] = op.kind == OP_CONV ? op.ks : 0;
+        ms[i] = t;
+        const double HW = (double)op.H * op.W;
+        const double cin = op.src0.C + (op.src1.kind == REF_NONE ? 0 : op.src1.C);
+        double f = 0, by = 0;
+        switch (op.kind) {
+            case OP_CONV:
+                f = 2.0 * B * HW * op.Cout * cin * op.ks * op.ks;
+                by = 4.0 * (B * HW * (cin + op.Cout + (op.res.kind != REF_NONE ? op.Cout : 0)) + cin * op.ks * op.ks * op.Cout);
+                break;
+            case OP_GN: by = 4.0 * B * HW * cin; f = 4.0 * B * HW * cin; break;       // one algorithmic read (2nd pass hits L2)
+            case OP_FIR: {
+                const double o = op.up ? 4.0 : 0.25;
+                by = 4.0 * B * HW * op.src0.C * (1.0 + o);
+                f = B * HW * op.src0.C * o * (op.up ? 8.0 : 32.0);
+                break;
+            }
+            case OP_ATTN:
+                f = 4.0 * B * HW * HW * op.Cout;                                     // QK^T + PV
+                by = 4.0 * B * HW * op.Cout * 4.0;                                    // q,k,v in + o out
+                break;
+            case OP_TEMB: f = 2.0 * B * (m->d.ngf * m->T + (double)m->T * m->T); by = 4.0 * (m->d.ngf * m->T + (double)m->T * m->T); break;
+            case OP_DENSE: f = 2.0 * B * m->T * m->NE; by = 4.0 * ((double)m->T * m->NE + B * m->NE); break;
+            default: break;
+        }
+        flops[i] = f;
+        bytes[i] = by;
+    }
+    return n;
+}
+
+int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst, int64_t capacity, int* C, int* H) {
+    MCVD_REQUIRE(m && dst && B > 0 && B <= m->arena_B, "module_output: run a forward at batch >= B first");
+    const Op* last = nullptr;
+    for (const Op& op : m->ops)
+        if (op.module == module && op.dst.kind == REF_ARENA) last = &op;
+    MCVD_REQUIRE(last, "module_output: module %d has no workspace output", module);
+    const int c = last->dst.C;
+    int h = last->H;
+    if (last->kind == OP_FIR) h = last->up ? 2 * h : h / 2;
+    if (last->kind == OP_TEMB || last->kind == OP_DENSE) h = 0;
+    const int64_t per = h ? (int64_t)c * h * h : c;
+    MCVD_REQUIRE(per * B <= capacity, "module_output: capacity %lld < %lld", (long long)capacity, (long long)(per * B));
+    MCVD_HIP_CHECK(hipMemcpyAsync(dst, m->arena + last->dst.off * (int64_t)B, (size_t)per * B * sizeof(float),
+                                  hipMemcpyDeviceToDevice, m->ctx->stream));
+    if (C) *C = c;
+    if (H) *H = h;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ sampler
+int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const float* noise, uint64_t seed,
+                     uint64_t sample_offset, int subsample_steps, int flags, float t_min, int B) {
+    API_TRY
+    MCVD_REQUIRE(m && x && B > 0, "sampler_run: bad arguments");
+    MCVD_REQUIRE(kind == MCVD_SAMPLER_DDPM || kind == MCVD_SAMPLER_DDIM, "sampler_run: kind %d", kind);
+    MCVD_REQUIRE(m->finalized, "sampler_run before mcvd_model_finalize");
+    const int T = m->d.num_classes;
+    // schedule subsampling, models/__init__.py:229-237
+    std::vector<int> steps;
+    std::vector<float> al, alp, be;
+    if (subsample_steps > 0 && subsample_steps < T) {
+        const int skip = T / subsample_steps;
+        for (int t = 0; t < T; t += skip) steps.push_back(t);
+        const int L = (int)steps.size();
+        al.resize(L); alp.resize(L); be.resize(L);
+        for (int i = 0; i < L; ++i) al[i] = m->alphas[steps[i]];
+        for (int i = 0; i < L; ++i) alp[i] = (i + 1 < L) ? al[i + 1] : 1.0f;
+        for (int i = 0; i < L; ++i) be[i] = 1.0f - al[i] / alp[i];
+    } else {
+        for (int t = 0; t < T; ++t) steps.push_back(t);
+        al = m->alphas; alp = m->alphas_prev; be = m->betas;
+    }
+    const int L = (int)steps.size();
+    const int64_t per = (int64_t)m->d.channels * m->d.num_frames * m->d.image_size * m->d.image_size;
+    const int64_t n = per * B;
+    if (int rc = m->ensure_workspace(B)) return rc;
+    hipStream_t s = m->ctx->stream;
+    m->profile_armed = true;          // with option "profile": the first forward of this call is event-instrumented
+    const int use_philox = noise ? 0 : 1;
+    uint64_t draw = 0;
+    bool started = false;
+    for (int i = 0; i < L; ++i) {
+        if ((double)steps[i] < (double)t_min * (double)L) continue;                       // :269-270
+        const float a = al[i], ap = alp[i], b = be[i];
+        if (!started && t_min > 0.0f) {                                                   // :272-279
+            if (int rc = launch_renoise(x, noise ? noise + draw * n : nullptr, sqrtf(a), sqrtf(1.0f - a), n, use_philox, seed,
+                                        sample_offset, draw, per, s))
+                return rc;
+            ++draw;
+        }
+        started = true;
+        if (int rc = launch_fill_labels(m->labels, steps[i], B, s)) return rc;           // :283
+        if (int rc = m->forward(x, m->labels, cond, m->eps_buf, B)) return rc;           // :284
+        const float c_x0a = 1.0f / sqrtf(a), c_x0b = sqrtf(1.0f - a);                    // :287
+        float c0, c1, cn = 0.0f;
+        if (kind == MCVD_SAMPLER_DDPM) {
+            c0 = sqrtf(ap) * b / (1.0f - a);                                             // :290
+            c1 = sqrtf(1.0f - b) * (1.0f - ap) / (1.0f - a);
+            if (i + 1 != L)                                                              // :311-328
+                cn = (flags & MCVD_FLAG_JUST_BETA) ? sqrtf(b) : sqrtf((1.0f - ap) / (1.0f - a) * b);
+        } else {
+            c0 = sqrtf(ap);                                                              // :168
+            c1 = sqrtf(1.0f - ap);
+        }
+        const bool draws = (kind == MCVD_SAMPLER_DDPM) && (i + 1 != L);
+        if (int rc = launch_sampler_update(kind, x, m->eps_buf, (noise && draws) ? noise + draw * n : nullptr, c_x0a, c_x0b, c0,
+                                           c1, cn, (flags & MCVD_FLAG_CLIP_BEFORE) ? 1 : 0, n, (draws && use_philox) ? 1 : 0,
+                                           seed, sample_offset, draw, per, s))
+            return rc;
+        if (draws) ++draw;
+    }
+    if (flags & MCVD_FLAG_DENOISE) {                                                      // :331-333, label L-1 (sic)
+        if (int rc = launch_fill_labels(m->labels, L - 1, B, s)) return rc;
+        if (int rc = m->forward(x, m->labels, cond, m->eps_buf, B)) return rc;
+        if (int rc = launch_axpy_out(x, m->eps_buf, sqrtf(1.0f - al[L - 1]), n, s)) return rc;
+    }
+    return 0;
+    API_CATCH
+}
+
+int mcvd_sampler_update(mcvd_ctx* ctx, int kind, float* x, const float* eps, const float* noise, float c_x0a, float c_x0b,
+                        float c_mean0, float c_mean1, float c_noise, int clip, int64_t n) {
+    MCVD_REQUIRE(ctx && x && eps, "sampler_update: NULL argument");
+    return launch_sampler_update(kind, x, eps, noise, c_x0a, c_x0b, c_mean0, c_mean1, c_noise, clip, n, 0, 0, 0, 0, 4,
+                                 ctx->stream);
+}
+
+int mcvd_randn(mcvd_ctx* ctx, float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample) {
+    MCVD_REQUIRE(ctx && out, "randn: NULL argument");
+    return launch_randn(out, seed, sample_offset, draw, B, per_sample, ctx->stream);
+}
+
+// ------------------------------------------------------------------------------------------------ stand-alone ops
+int mcvd_upfirdn2d(mcvd_ctx* ctx, const float* in, const float* kernel_host, int kh, int kw, int up, int down, int pad0,
+                   int pad1, float* out, int N, int C, int H, int W) {
+    API_TRY
+    MCVD_REQUIRE(ctx && in && kernel_host && out, "upfirdn2d: NULL argument");
+    MCVD_REQUIRE(up >= 1 && down >= 1 && kh >= 1 && kw >= 1, "upfirdn2d: up/down/kernel");
+    const int oh = (H * up + pad0 + pad1 - kh) / down + 1, ow = (W * up + pad0 + pad1 - kw) / down + 1;
+    MCVD_REQUIRE(oh > 0 && ow > 0, "upfirdn2d: empty output");
+    if (int rc = ctx->ensure_scratch((size_t)kh * kw * sizeof(float))) return rc;
+    MCVD_HIP_CHECK(hipMemcpyAsync(ctx->scratch, kernel_host, (size_t)kh * kw * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MCVD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return launch_upfirdn2d(in, ctx->scratch, kh, kw, up, down, pad0, pad1, out, N * C, H, W, oh, ow, ctx->stream);
+    API_CATCH
+}
+
+int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
+                   int Cout, int ks, const float* coef, int act, const float* res, float out_scale, float* y, int B, int H,
+                   int W) {
+    API_TRY
+    MCVD_REQUIRE(ctx && x0 && w && bias && y, "op_conv2d: NULL argument");
+    MCVD_REQUIRE(ks == 1 || ks == 3, "op_conv2d: ks=%d", ks);
+    ConvArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = x1 ? C1 : 0;
+    a.coef = coef; a.act = act; a.res = res; a.out_scale = out_scale; a.y = y;
+    a.B = B; a.Cin = a.C0 + a.C1; a.Cout = Cout; a.H = H; a.W = W; a.ks = ks;
+    a.cot = conv_cout_tile(Cout);
+    a.CinP = round_up(a.Cin, conv_chunk(ks));
+    a.CoutP = round_up(Cout, 32 * a.cot);
+    const size_t wfloats = (size_t)a.CinP * ks * ks * a.CoutP;
+    if (int rc = ctx->ensure_scratch((wfloats + a.CoutP) * sizeof(float))) return rc;
+    MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP) * sizeof(float), ctx->stream));
+    if (int rc = launch_pack_conv_weight(w, ctx->scratch, Cout, a.Cin, ks, a.CinP, a.CoutP, 0, 0, ctx->stream)) return rc;
+    MCVD_HIP_CHECK(hipMemcpyAsync(ctx->scratch + wfloats, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    a.wp = ctx->scratch;
+    a.bias = ctx->scratch + wfloats;
+    a.shape_hint = ctx->conv_shape;
+    return ctx->naive_conv ? launch_conv_naive(a, ctx->stream) : launch_conv_mfma(a, ctx->stream);
+    API_CATCH
+}
+
+int mcvd_op_gn_coef(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int C1, int groups, float eps, int mode,
+                    const float* p0, const float* p1, int emb_stride, int emb_off, float* coef_out, int B, int HW) {
+    MCVD_REQUIRE(ctx && x0 && coef_out, "op_gn_coef: NULL argument");
+    GnArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = x1 ? C1 : 0; a.groups = groups; a.eps = eps; a.mode = mode; a.p0 = p0; a.p1 = p1;
+    a.emb_stride = emb_stride; a.emb_off = emb_off; a.coef = coef_out; a.B = B; a.HW = HW;
+    return launch_gn_coef(a, ctx->stream);
+}
+
+int mcvd_op_attention(mcvd_ctx* ctx, const float* qkv, float* out, int B, int C, int heads, int HW) {
+    MCVD_REQUIRE(ctx && qkv && out, "op_attention: NULL argument");
+    return (ctx->naive_attn ? launch_attention_naive : launch_attention_mfma)(qkv, out, B, C, heads, HW, ctx->stream);
+}
+
+int mcvd_op_fir2(mcvd_ctx* ctx, const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W) {
+    MCVD_REQUIRE(ctx && x && y, "op_fir2: NULL argument");
+    return launch_fir2(x, coef, act, up, y, B, C, H, W, nullptr, nullptr, nullptr, ctx->stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+"""Build libmcvd_hip.so (gfx950 only) with hipcc: one object per translation unit, compiled in parallel,
+linked into mcvd_pytorch_amd/libmcvd_hip.so (in-tree, so it travels with the repo snapshot).
+
+    python -m mcvd_pytorch_amd.csrc.build [--force] [-j N]
+"""
+import argparse
+import concurrent.futures as cf
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(PKG, "libmcvd_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-I", os.path.join(ROOT, "include")]
+HOST_ONLY_FLAGS = {"model.cpp": ["-ffp-contract=off"], "api.cpp": ["-ffp-contract=off"]}
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(HERE, "*.cpp")) + glob.glob(os.path.join(HERE, "kernels", "*.cpp")))
+
+
+def headers():
+    return (glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "kernels", "*.h"))
+            + glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.abspath(__file__)])
+
+
+def compile_one(src, force):
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    newest_dep = max(os.path.getmtime(p) for p in [src] + headers())
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest_dep:
+        return obj, None
+    cmd = [HIPCC] + FLAGS + HOST_ONLY_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
+    return obj, r.stderr.strip()
+
+
+def build(force=False, jobs=None, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sources()
+    objs, rebuilt = [], 0
+    with cf.ThreadPoolExecutor(max_workers=jobs or os.cpu_count()) as ex:
+        for obj, log in ex.map(lambda s: compile_one(s, force), srcs):
+            objs.append(obj)
+            if log is not None:
+                rebuilt += 1
+                if log and verbose:
+                    print(log, file=sys.stderr)
+    if rebuilt or not os.path.exists(LIB) or force:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stderr))
+    if verbose:
+        print("libmcvd_hip.so: %d/%d objects rebuilt -> %s" % (rebuilt, len(srcs), LIB))
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("-j", type=int, default=None)
+    a = ap.parse_args()
+    build(force=a.force, jobs=a.j)

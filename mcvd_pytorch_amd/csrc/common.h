@@ -1,0 +1,107 @@
+// Internal declarations shared by the kernel translation units and the host executor.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace mcvd {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define MCVD_HIP_CHECK(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            mcvd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -2;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+#define MCVD_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            mcvd::set_error(__VA_ARGS__);  \
+            return -1;                     \
+        }                                  \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// ------------------------------------------------------------------ conv (implicit GEMM on fp32 MFMA)
+// Packed weight layout: wp[(cin * KK + tap) * CoutP + cout], cin padded to CinP (multiple of the kernel's
+// channel chunk) and cout padded to CoutP (multiple of the cout tile) with zeros.
+struct ConvArgs {
+    const float* x0;
+    const float* x1;      // second source of a virtual channel concat (may be null when C1 == 0)
+    int C0, C1;
+    const float* coef;    // [B][Cin][2] per-(sample,channel) affine (A,B), or null
+    int act;              // SiLU after the affine
+    const float* wp;      // packed weights
+    const float* bias;    // [Cout]
+    const float* res;     // residual [B][Cout][H][W] or null
+    float out_scale;
+    float* y;             // [B][Cout][H][W]
+    int B, Cin, CinP, Cout, CoutP, H, W;
+    int ks;               // 1 or 3
+    int cot;              // cout tile in units of 32 channels (1..4); CoutP % (32*cot) == 0
+    int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile (tests)
+};
+int conv_cout_tile(int Cout);                 // 32-channel units per block along Cout
+int conv_chunk(int ks);                       // input-channel chunk the MFMA kernel consumes per stage
+int launch_conv_mfma(const ConvArgs& a, hipStream_t s);
+int launch_conv_naive(const ConvArgs& a, hipStream_t s);
+// repack reference-layout weights [Cout][Cin][ks][ks] (or NIN [Cin][Cout] when nin=1) -> packed layout above
+int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, int CinP, int CoutP, int nin,
+                            int cout_off, hipStream_t s);
+
+// ------------------------------------------------------------------ GroupNorm -> affine coefficients
+struct GnArgs {
+    const float* x0;
+    const float* x1;
+    int C0, C1;
+    int groups;
+    float eps;
+    int mode;           // 0 plain, 1 temb scale/shift, 2 affine weight/bias
+    const float* p0;    // mode1: emb [B][emb_stride]; mode2: weight [C]
+    const float* p1;    // mode2: bias [C]
+    int emb_stride, emb_off;
+    float* coef;        // [B][C][2]
+    int B, HW;
+};
+int launch_gn_coef(const GnArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ attention
+int launch_attention_mfma(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
+int launch_attention_naive(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
+
+// ------------------------------------------------------------------ FIR resampling
+int launch_fir2(const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W,
+                const float* gamma, const float* beta, const float* coef2, hipStream_t s);
+int launch_upfirdn2d(const float* in, const float* kernel_dev, int kh, int kw, int up, int down, int pad0, int pad1,
+                     float* out, int NC, int H, int W, int oh, int ow, hipStream_t s);
+int launch_nearest_resize(const float* in, float* out, int BC, int H, int W, int oh, int ow, hipStream_t s);
+
+// ------------------------------------------------------------------ time embedding
+// silu_temb[b][:] = SiLU( W1 * SiLU(W0 * emb(t_b) + b0) + b1 )      (ncsnpp_more.py:273-280 + layerspp.py:521)
+int launch_temb_mlp(const int64_t* labels, const float* freqs, const float* w0, const float* b0, const float* w1,
+                    const float* b1, float* silu_temb, int B, int nf, hipStream_t s);
+// out[b][n] = sum_k act[b][k] * wt[k][n] + bias[n]   (all Dense_0 projections of a forward in one launch)
+int launch_dense_all(const float* act, const float* wt, const float* bias, float* out, int B, int K, int N,
+                     hipStream_t s);
+int launch_transpose_into(const float* w, float* wt, int rows, int cols, int ld_out, int col_off, hipStream_t s);
+
+// ------------------------------------------------------------------ sampler elementwise
+int launch_fill_labels(int64_t* labels, int64_t value, int B, hipStream_t s);
+// kind 0 ddpm / 1 ddim.  noise may be null (then c_noise must be 0 or use_philox != 0).
+int launch_sampler_update(int kind, float* x, const float* eps, const float* noise, float c_x0a, float c_x0b,
+                          float c_mean0, float c_mean1, float c_noise, int clip, int64_t n, int use_philox,
+                          uint64_t seed, uint64_t sample_offset, uint64_t draw, int64_t per_sample, hipStream_t s);
+int launch_renoise(float* x, const float* noise, float ca, float cb, int64_t n, int use_philox, uint64_t seed,
+                   uint64_t sample_offset, uint64_t draw, int64_t per_sample, hipStream_t s);
+int launch_axpy_out(float* x, const float* eps, float c, int64_t n, hipStream_t s);   // x -= c * eps
+int launch_randn(float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample,
+                 hipStream_t s);
+
+}  // namespace mcvd

@@ -1,0 +1,114 @@
+// conv dispatch (tile-shape heuristic), the simple one-thread-per-output HIP kernel used to triangulate the
+// MFMA kernel in tests, and the weight repacking kernel.
+#include <stdlib.h>
+
+#include "conv_mfma.h"
+
+namespace mcvd {
+
+int conv_cout_tile(int Cout) {
+    if (Cout % 96 == 0) return 3;
+    if (Cout % 128 == 0) return 4;
+    if (Cout % 64 == 0) return 2;
+    return 1;
+}
+
+int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
+    MCVD_REQUIRE(a.ks == 1 || a.ks == 3, "conv: kernel size %d unsupported", a.ks);
+    MCVD_REQUIRE(a.W >= 8 && (a.W & (a.W - 1)) == 0 && a.W <= 256, "conv: W=%d must be a power of two in [8,256]", a.W);
+    MCVD_REQUIRE(a.cot >= 1 && a.cot <= 4, "conv: cout tile %d", a.cot);
+    static const int forced = env_int("MCVD_CONV_SHAPE", -1);
+    static const int min_blocks = env_int("MCVD_CONV_MIN_BLOCKS", 400);
+    const long px = (long)a.B * a.H * a.W;
+    const int ntc = a.CoutP / (32 * a.cot);
+    auto blocks = [&](int bpx) { return ((px + bpx - 1) / bpx) * ntc; };
+    auto fits = [&](int bpx) { return bpx % a.W == 0 && (bpx / a.W <= a.H ? a.H % (bpx / a.W) == 0 : (bpx / a.W) % a.H == 0); };
+    int shape;
+    const int want = (a.shape_hint >= 0 && a.shape_hint <= 2) ? a.shape_hint : forced;
+    if (want >= 0 && want <= 2 && fits(want == 0 ? 256 : want == 1 ? 128 : 64)) shape = want;
+    else if (fits(256) && blocks(256) >= min_blocks) shape = 0;
+    else if (fits(128) && blocks(128) >= min_blocks) shape = 1;
+    else if (fits(64)) shape = 2;
+    else if (fits(128)) shape = 1;
+    else shape = 0;
+    typedef int (*fn_t)(const ConvArgs&, int, hipStream_t);
+    static const fn_t tab3[4] = {conv3_cot1, conv3_cot2, conv3_cot3, conv3_cot4};
+    static const fn_t tab1[4] = {conv1_cot1, conv1_cot2, conv1_cot3, conv1_cot4};
+    return (a.ks == 3 ? tab3 : tab1)[a.cot - 1](a, shape, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Naive direct convolution: one thread per output element, fp32 FMA chain in (ci, tap) order.
+__global__ void conv_naive_kernel(ConvArgs a) {
+    const long n = (long)a.B * a.Cout * a.H * a.W;
+    const int HW = a.H * a.W;
+    const int KK = a.ks * a.ks;
+    const int pad = a.ks / 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % a.W);
+        const int y = (int)((i / a.W) % a.H);
+        const int co = (int)((i / HW) % a.Cout);
+        const int b = (int)(i / ((long)HW * a.Cout));
+        float acc = 0.0f;
+        for (int ci = 0; ci < a.Cin; ++ci) {
+            const float* src = (ci < a.C0) ? a.x0 + ((long)b * a.C0 + ci) * HW : a.x1 + ((long)b * a.C1 + (ci - a.C0)) * HW;
+            float ca = 1.0f, cb = 0.0f;
+            if (a.coef) { ca = a.coef[((long)b * a.Cin + ci) * 2]; cb = a.coef[((long)b * a.Cin + ci) * 2 + 1]; }
+            for (int t = 0; t < KK; ++t) {
+                const int yy = y + t / a.ks - pad, xx = x + t % a.ks - pad;
+                if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+                float v = src[yy * a.W + xx];
+                if (a.coef) v = v * ca + cb;
+                if (a.act) v = silu_f(v);
+                acc = fmaf(a.wp[((long)ci * KK + t) * a.CoutP + co], v, acc);
+            }
+        }
+        float v = acc + a.bias[co];
+        if (a.res) v += a.res[i];
+        a.y[i] = v * a.out_scale;
+    }
+}
+
+int launch_conv_naive(const ConvArgs& a, hipStream_t s) {
+    const long n = (long)a.B * a.Cout * a.H * a.W;
+    const int blocks = (int)((n + 255) / 256 > 65535 * 8 ? 65535 * 8 : (n + 255) / 256);
+    hipLaunchKernelGGL(conv_naive_kernel, dim3(blocks), dim3(256), 0, s, a);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// [Cout][Cin][ks][ks] (nn.Conv2d) or [Cin][Cout] (NIN.W, layers.py:538)  ->  wp[(ci*KK + tap)*CoutP + cout_off + co]
+__global__ void pack_conv_weight_kernel(const float* w, float* wp, int Cout, int Cin, int KK, int CoutP, int nin,
+                                        int cout_off) {
+    const long n = (long)Cout * Cin * KK;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int co, ci, t;
+        if (nin) {                    // i = ci*Cout + co
+            co = (int)(i % Cout); ci = (int)(i / Cout); t = 0;
+        } else {                      // i = (co*Cin + ci)*KK + t
+            t = (int)(i % KK); ci = (int)((i / KK) % Cin); co = (int)(i / ((long)KK * Cin));
+        }
+        wp[((long)ci * KK + t) * CoutP + cout_off + co] = w[i];
+    }
+}
+
+int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, int CinP, int CoutP, int nin,
+                            int cout_off, hipStream_t s) {
+    (void)CinP;
+    const long n = (long)Cout * Cin * ks * ks;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, s, w, wp, Cout, Cin, ks * ks, CoutP, nin,
+                       cout_off);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mcvd

@@ -1,0 +1,5 @@
+// instantiation unit: 3x3 conv, 32-channel cout tile (split out for parallel compilation)
+#include "conv_mfma.h"
+namespace mcvd {
+int conv3_cot1(const ConvArgs& a, int shape, hipStream_t s) { return conv_mfma_dispatch_shape<3, 8, 1>(a, shape, s); }
+}  // namespace mcvd

@@ -1,0 +1,331 @@
+// Fused conv (3x3 / 1x1) as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, gfx950).
+//
+//   y[b, co, p] = out_scale * ( bias[co] + res[b, co, p] + sum_{ci,tap} W[co, ci, tap] * f(x)[b, ci, p + tap] )
+//   f(x)[b, ci, .] = silu?( A[b,ci] * x[b,ci,.] + B[b,ci] )      (GroupNorm + temb scale/shift folded to A,B)
+//
+// MFMA roles: A-operand = weights (rows = output channels), B-operand = activations (cols = pixels), so an
+// accumulator register holds 32 consecutive pixels of one output channel across lanes -> NCHW stores and
+// residual loads are 128-byte coalesced rows.
+//
+// Work decomposition (256 threads = 4 wave64):
+//   pixel tile  = BPX pixels = whole image rows (full width, so left/right halo is always the zero padding),
+//   cout tile   = 32*COT output channels,
+//   K loop      = input-channel chunks of CK channels staged in LDS (im2col is implicit: the 9 taps are LDS
+//                 address offsets into the staged halo patch),
+//   SPLIT=false : the 4 waves split the pixel tile (PXT 32-pixel sub-tiles each),
+//   SPLIT=true  : the 4 waves split K inside each chunk and reduce through LDS (small-resolution layers,
+//                 where M = B*H*W is too small to fill 256 CUs otherwise).
+// Pipeline: global->register prefetch of chunk i+1 is issued before the MFMAs of chunk i; the prologue
+// transform is applied on the way from registers to LDS.
+#pragma once
+#include "../common.h"
+
+namespace mcvd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float silu_f(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+}
+
+struct ConvGeom {
+    int RT;        // image rows per pixel tile
+    int rpi;       // rows per image inside a tile (= min(RT, H))
+    int nimg;      // images per tile (RT / rpi)
+    int P;         // LDS row pitch (floats)
+    int IS;        // LDS floats per (channel, image)
+    int PS;        // LDS floats per channel
+    int n_ptiles;  // pixel tiles in the grid
+};
+
+template <int KS, int CK, int COT, int PXT, bool SPLIT>
+struct ConvCfg {
+    static constexpr int KK = KS * KS;
+    static constexpr int HALO = (KS == 3) ? 1 : 0;
+    static constexpr int BPX = SPLIT ? PXT * 32 : 4 * PXT * 32;
+    static constexpr int BCO = COT * 32;
+    static constexpr int MAXA = (KS == 3) ? 4 : (CK * BPX / 4 + 255) / 256;
+    static constexpr int WCOUNT = CK * KK * BCO / 4;          // float4 per weight chunk
+    static constexpr int MAXW = (WCOUNT + 255) / 256;
+};
+
+template <int KS, int CK, int COT, int PXT, bool SPLIT>
+__global__ __launch_bounds__(256, (COT * PXT >= 6) ? 1 : 2) void conv_mfma_kernel(ConvArgs a, ConvGeom g) {
+    using Cfg = ConvCfg<KS, CK, COT, PXT, SPLIT>;
+    constexpr int KK = Cfg::KK, HALO = Cfg::HALO, BCO = Cfg::BCO, MAXA = Cfg::MAXA, MAXW = Cfg::MAXW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sW = smem + CK * g.PS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int Cin = a.Cin;
+
+    const int ptile = blockIdx.x;
+    const int co0 = blockIdx.y * BCO;
+    const long grow0 = (long)ptile * g.RT;        // first row of the tile in flattened (b, y) row space
+    const int b0 = (int)(grow0 / H);
+    const int y0 = (int)(grow0 - (long)b0 * H);
+
+    // ---------------- per-thread staging slots (chunk invariant) ----------------
+    const int W4 = W >> 2;
+    const int rows_l = g.rpi + 2 * HALO;
+    const int per_cin = g.nimg * rows_l * W4;
+    const int countA = CK * per_cin;
+    int a_lds[MAXA], a_goff[MAXA], a_cb[MAXA];     // a_cb = (cin_l << 16) | (img << 1) | inimage ; -1 = unused slot
+#pragma unroll
+    for (int s = 0; s < MAXA; ++s) {
+        const int e = s * 256 + tid;
+        if (e < countA) {
+            const int cin_l = e / per_cin;
+            const int rem = e - cin_l * per_cin;
+            const int rowi = rem / W4;
+            const int c4 = rem - rowi * W4;
+            const int img = rowi / rows_l;
+            const int rl = rowi - img * rows_l;
+            const int yy = y0 + rl - HALO;
+            const int inimg = (yy >= 0 && yy < H && (b0 + img) < a.B) ? 1 : 0;
+            a_lds[s] = cin_l * g.PS + img * g.IS + rl * g.P + (HALO ? 4 : 0) + c4 * 4;
+            a_goff[s] = yy * W + c4 * 4;
+            a_cb[s] = (cin_l << 16) | (img << 1) | inimg;
+        } else {
+            a_lds[s] = 0; a_goff[s] = 0; a_cb[s] = -1;
+        }
+    }
+    int w_goff[MAXW];
+#pragma unroll
+    for (int s = 0; s < MAXW; ++s) {
+        const int e = s * 256 + tid;
+        const int row = e / (BCO / 4);
+        const int c4 = e - row * (BCO / 4);
+        w_goff[s] = (e < Cfg::WCOUNT) ? row * a.CoutP + co0 + c4 * 4 : -1;
+    }
+
+    // zero the activation patch once: halo columns (and unused pad) stay zero for the whole kernel
+    for (int i = tid; i < CK * g.PS; i += 256) sA[i] = 0.0f;
+
+    f32x4 ra[MAXA];      // native vector types: plain load/store, no struct memcpy (keeps them in VGPRs)
+    f32x2 rc[MAXA];
+    f32x4 rw[MAXW];
+
+    // Loads are unconditional (invalid slots read a safe in-bounds address and are discarded at write time) so the
+    // staging registers are always defined; plain macros (not lambdas) keep them out of scratch.
+#define MCVD_LOAD_CHUNK(ch)                                                                                          \
+    {                                                                                                                \
+        const int cbase = (ch) * CK;                                                                                 \
+        _Pragma("unroll") for (int s = 0; s < MAXA; ++s) {                                                           \
+            const int c = cbase + (a_cb[s] >> 16);                                                                   \
+            const int b = b0 + ((a_cb[s] >> 1) & 0x7fff);                                                            \
+            const bool ok = (a_cb[s] >= 0) && (a_cb[s] & 1) && (c < Cin);                                            \
+            const float* src = a.x0;                                                                                 \
+            const float* csrc = a.coef ? a.coef : a.bias;                                                            \
+            if (ok) {                                                                                                \
+                src = ((c < a.C0) ? a.x0 + ((long)b * a.C0 + c) * HW                                                 \
+                                  : a.x1 + ((long)b * a.C1 + (c - a.C0)) * HW) + a_goff[s];                          \
+                if (a.coef) csrc = a.coef + ((long)b * Cin + c) * 2;                                                 \
+            }                                                                                                        \
+            ra[s] = *reinterpret_cast<const f32x4*>(src);                                                            \
+            rc[s] = *reinterpret_cast<const f32x2*>(csrc);                                                           \
+        }                                                                                                            \
+        const float* wsrc = a.wp + (long)cbase * KK * a.CoutP;                                                       \
+        _Pragma("unroll") for (int s = 0; s < MAXW; ++s)                                                             \
+            rw[s] = *reinterpret_cast<const f32x4*>(wsrc + (w_goff[s] >= 0 ? w_goff[s] : 0));                        \
+    }
+#define MCVD_WRITE_CHUNK(ch)                                                                                         \
+    {                                                                                                                \
+        const int cbase = (ch) * CK;                                                                                 \
+        _Pragma("unroll") for (int s = 0; s < MAXA; ++s) {                                                           \
+            if (a_cb[s] >= 0) {                                                                                      \
+                f32x4 v = ra[s];                                                                                     \
+                const bool live = (a_cb[s] & 1) && (cbase + (a_cb[s] >> 16) < Cin);                                  \
+                if (live) {                                                                                          \
+                    if (a.coef) {                                                                                    \
+                        v.x = v.x * rc[s].x + rc[s].y; v.y = v.y * rc[s].x + rc[s].y;                                \
+                        v.z = v.z * rc[s].x + rc[s].y; v.w = v.w * rc[s].x + rc[s].y;                                \
+                    }                                                                                                \
+                    if (a.act) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }       \
+                } else {                                                                                             \
+                    v = f32x4{0.f, 0.f, 0.f, 0.f}; /* zero padding applies AFTER the activation */                   \
+                }                                                                                                    \
+                *reinterpret_cast<f32x4*>(sA + a_lds[s]) = v;                                                        \
+            }                                                                                                        \
+        }                                                                                                            \
+        _Pragma("unroll") for (int s = 0; s < MAXW; ++s) {                                                           \
+            if (w_goff[s] >= 0) *reinterpret_cast<f32x4*>(sW + (s * 256 + tid) * 4) = rw[s];                         \
+        }                                                                                                            \
+    }
+
+    // ---------------- this lane's MFMA operand addresses ----------------
+    const int wpx0 = SPLIT ? 0 : wave * PXT * 32;
+    int pixoff[PXT];
+#pragma unroll
+    for (int pt = 0; pt < PXT; ++pt) {
+        const int m = wpx0 + pt * 32 + l31;
+        const int rowt = m / W;
+        const int c = m - rowt * W;
+        const int img = rowt / g.rpi;
+        const int r = rowt - img * g.rpi;
+        pixoff[pt] = img * g.IS + (r + HALO) * g.P + (HALO ? 4 : 0) + c + half * g.PS;
+    }
+    const int woff = half * KK * BCO + l31;
+
+    f32x16 acc[COT][PXT];
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.0f;
+
+    const int nchunks = a.CinP / CK;
+    MCVD_LOAD_CHUNK(0);
+    __syncthreads();              // zero fill done
+    MCVD_WRITE_CHUNK(0);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks) MCVD_LOAD_CHUNK(ch + 1);
+        // ---- MFMA over this chunk
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int tapoff = HALO ? ((tap / 3) - 1) * g.P + ((tap % 3) - 1) : 0;
+            constexpr int NKP = CK / 2;
+#pragma unroll
+            for (int kq = 0; kq < (SPLIT ? NKP / 4 : NKP); ++kq) {
+                const int kp = SPLIT ? (wave + 4 * kq) : kq;
+                float aw[COT], bx[PXT];
+#pragma unroll
+                for (int ct = 0; ct < COT; ++ct) aw[ct] = sW[(2 * kp * KK + tap) * BCO + ct * 32 + woff];
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt) bx[pt] = sA[2 * kp * g.PS + pixoff[pt] + tapoff];
+#pragma unroll
+                for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ct], bx[pt], acc[ct][pt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (ch + 1 < nchunks) {
+            MCVD_WRITE_CHUNK(ch + 1);
+            __syncthreads();
+        }
+    }
+
+    // ---------------- split-K reduction across the 4 waves (through LDS) ----------------
+    if (SPLIT) {
+        float* red = smem;      // 3 * 1024 floats, LDS is free now (last barrier above passed)
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt) {
+                if (wave > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(wave - 1) * 1024 + r * 64 + lane] = acc[ct][pt][r];
+                }
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[ct][pt][r] += red[r * 64 + lane] + red[1024 + r * 64 + lane] + red[2048 + r * 64 + lane];
+                }
+                __syncthreads();
+            }
+        if (wave != 0) return;
+    }
+
+    // ---------------- epilogue: bias, residual, scale, coalesced NCHW stores ----------------
+    long pbase[PXT];
+#pragma unroll
+    for (int pt = 0; pt < PXT; ++pt) {
+        const int m = wpx0 + pt * 32 + l31;
+        const int rowt = m / W;
+        const int c = m - rowt * W;
+        const int img = rowt / g.rpi;
+        const int r = rowt - img * g.rpi;
+        const int b = b0 + img;
+        pbase[pt] = (b < a.B) ? (long)b * a.Cout * HW + (long)(y0 + r) * W + c : -1;
+    }
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int co = co0 + ct * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+            if (co < a.Cout) {
+                const float bv = a.bias[co];
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt) {
+                    if (pbase[pt] >= 0) {
+                        const long idx = pbase[pt] + (long)co * HW;
+                        float v = acc[ct][pt][rg] + bv;
+                        if (a.res) v += a.res[idx];
+                        a.y[idx] = v * a.out_scale;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Host-side geometry + launch for one instantiation.
+template <int KS, int CK, int COT, int PXT, bool SPLIT>
+int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
+    using Cfg = ConvCfg<KS, CK, COT, PXT, SPLIT>;
+    ConvGeom g;
+    const int BPX = Cfg::BPX;
+    MCVD_REQUIRE(BPX % a.W == 0, "conv: pixel tile %d not a multiple of W=%d", BPX, a.W);
+    g.RT = BPX / a.W;
+    g.rpi = g.RT < a.H ? g.RT : a.H;
+    MCVD_REQUIRE(g.RT % g.rpi == 0 && a.H % g.rpi == 0, "conv: tile rows %d vs H=%d", g.RT, a.H);
+    g.nimg = g.RT / g.rpi;
+    if (Cfg::HALO) {
+        g.P = (a.W == 8) ? 20 : a.W + 8;
+        g.IS = (g.rpi + 2) * g.P;
+    } else {
+        g.P = a.W;
+        g.IS = g.rpi * g.P;
+    }
+    g.PS = round_up(g.nimg * g.IS, 4);
+    const long rows = (long)a.B * a.H;
+    g.n_ptiles = (int)((rows + g.RT - 1) / g.RT);
+    const int countA = CK * g.nimg * (g.rpi + 2 * Cfg::HALO) * (a.W / 4);
+    MCVD_REQUIRE(countA <= Cfg::MAXA * 256, "conv: staging slots exceeded (%d > %d)", countA, Cfg::MAXA * 256);
+    MCVD_REQUIRE(a.CinP % CK == 0 && a.CoutP % Cfg::BCO == 0, "conv: packed dims (%d,%d) vs chunk %d tile %d",
+                 a.CinP, a.CoutP, CK, Cfg::BCO);
+    size_t lds = (size_t)(CK * g.PS + CK * Cfg::KK * Cfg::BCO) * sizeof(float);
+    if (SPLIT && lds < 3 * 1024 * sizeof(float)) lds = 3 * 1024 * sizeof(float);
+    MCVD_REQUIRE(lds <= 64 * 1024, "conv: LDS %zu > 64KiB", lds);
+    dim3 grid(g.n_ptiles, a.CoutP / Cfg::BCO);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, CK, COT, PXT, SPLIT>), grid, dim3(256), lds, s, a, g);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// one translation unit per (KS, COT) instantiates the three tile shapes
+template <int KS, int CK, int COT>
+int conv_mfma_dispatch_shape(const ConvArgs& a, int shape, hipStream_t s) {
+    switch (shape) {
+        case 0: return conv_mfma_launch<KS, CK, COT, 2, false>(a, s);   // 256-pixel tile
+        case 1: return conv_mfma_launch<KS, CK, COT, 1, false>(a, s);   // 128-pixel tile
+        case 2: return conv_mfma_launch<KS, CK, COT, 2, true>(a, s);    // 64-pixel tile, waves split K
+    }
+    set_error("conv: bad shape id %d", shape);
+    return -1;
+}
+
+int conv3_cot1(const ConvArgs&, int, hipStream_t);
+int conv3_cot2(const ConvArgs&, int, hipStream_t);
+int conv3_cot3(const ConvArgs&, int, hipStream_t);
+int conv3_cot4(const ConvArgs&, int, hipStream_t);
+int conv1_cot1(const ConvArgs&, int, hipStream_t);
+int conv1_cot2(const ConvArgs&, int, hipStream_t);
+int conv1_cot3(const ConvArgs&, int, hipStream_t);
+int conv1_cot4(const ConvArgs&, int, hipStream_t);
+
+}  // namespace mcvd

@@ -1,0 +1,143 @@
+// FIR x2 resampling with the [1,3,3,1] kernel (ResBlock up/down paths, up_or_down_sampling.py:196-258 -> upfirdn2d),
+// fused with the optional GroupNorm/temb/SiLU prologue; the reference's generic native op upfirdn2d; nearest resize
+// (SPADE segmap, layerspp.py:165).  All HBM-bound elementwise kernels: one thread per 4 consecutive outputs.
+#include "../common.h"
+
+namespace mcvd {
+
+__device__ __forceinline__ float silu1(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+struct FirArgs {
+    const float* x; const float* coef; int act; int up; float* y; int B, C, H, W;
+    const float* gamma; const float* beta; const float* coef2;
+};
+
+// value of the (activated) input plane at (yy, xx); zero outside (padding applies after the activation)
+__device__ __forceinline__ float fir_src(const FirArgs& a, const float* plane, long pidx, int yy, int xx, float cA,
+                                         float cB, float sA, float sB) {
+    if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) return 0.0f;
+    float v = plane[yy * a.W + xx];
+    if (a.coef) v = v * cA + cB;
+    if (a.gamma) {
+        const long gi = pidx + (long)yy * a.W + xx;
+        v = v * (1.0f + a.gamma[gi]) + a.beta[gi];
+        v = v * sA + sB;
+    }
+    if (a.act) v = silu1(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void fir2_kernel(FirArgs a) {
+    const int OH = a.up ? a.H * 2 : a.H / 2, OW = a.up ? a.W * 2 : a.W / 2;
+    const int OW4 = OW >> 2;
+    const long n4 = (long)a.B * a.C * OH * OW4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int ox0 = (int)(i % OW4) * 4;
+        const int oy = (int)((i / OW4) % OH);
+        const long bc = i / ((long)OW4 * OH);
+        const long pidx = bc * a.H * a.W;
+        const float* plane = a.x + pidx;
+        float cA = 1.f, cB = 0.f, sA = 1.f, sB = 0.f;
+        if (a.coef) { cA = a.coef[bc * 2]; cB = a.coef[bc * 2 + 1]; }
+        if (a.coef2) { sA = a.coef2[bc * 2]; sB = a.coef2[bc * 2 + 1]; }
+        float o[4];
+        if (a.up) {
+            // per axis: y[2n] = x[n-1]/4 + 3x[n]/4 ; y[2n+1] = 3x[n]/4 + x[n+1]/4     
+            const int ny = oy >> 1;
+            const int ya = (oy & 1) ? ny : ny - 1, yb = (oy & 1) ? ny + 1 : ny;      // rows with weights (wa, wb)
+            const float wya = (oy & 1) ? 0.75f : 0.25f, wyb = (oy & 1) ? 0.25f : 0.75f;
+            const int nx0 = ox0 >> 1;
+            float col[4];                                                           // vertical blend of cols nx0-1..nx0+2
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = nx0 - 1 + j;
+                col[j] = wya * fir_src(a, plane, pidx, ya, xx, cA, cB, sA, sB) + wyb * fir_src(a, plane, pidx, yb, xx, cA, cB, sA, sB);
+            }
+            o[0] = 0.25f * col[0] + 0.75f * col[1];
+            o[1] = 0.75f * col[1] + 0.25f * col[2];
+            o[2] = 0.25f * col[1] + 0.75f * col[2];
+            o[3] = 0.75f * col[2] + 0.25f * col[3];
+        } else {
+            // per axis: y[m] = (x[2m-1] + 3x[2m] + 3x[2m+1] + x[2m+2]) / 8
+            float col[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int xx = 2 * ox0 - 1 + j;
+                const float v0 = fir_src(a, plane, pidx, 2 * oy - 1, xx, cA, cB, sA, sB);
+                const float v1 = fir_src(a, plane, pidx, 2 * oy, xx, cA, cB, sA, sB);
+                const float v2 = fir_src(a, plane, pidx, 2 * oy + 1, xx, cA, cB, sA, sB);
+                const float v3 = fir_src(a, plane, pidx, 2 * oy + 2, xx, cA, cB, sA, sB);
+                col[j] = (v0 + 3.0f * v1 + 3.0f * v2 + v3) * 0.125f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = (col[2 * k] + 3.0f * col[2 * k + 1] + 3.0f * col[2 * k + 2] + col[2 * k + 3]) * 0.125f;
+        }
+        *reinterpret_cast<float4*>(a.y + (bc * OH + oy) * OW + ox0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int launch_fir2(const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W,
+                const float* gamma, const float* beta, const float* coef2, hipStream_t s) {
+    MCVD_REQUIRE((up ? W * 2 : W / 2) % 4 == 0 && H % 2 == 0, "fir2: H=%d W=%d unsupported", H, W);
+    FirArgs a{x, coef, act, up, y, B, C, H, W, gamma, beta, coef2};
+    const long n4 = (long)B * C * (up ? H * 2 : H / 2) * ((up ? W * 2 : W / 2) / 4);
+    const int blocks = (int)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(fir2_kernel, dim3(blocks), dim3(256), 0, s, a);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Generic upfirdn2d (op/upfirdn2d.py:163-204): zero-insert upsample, pad/crop, correlate with the flipped kernel, decimate.
+__global__ void upfirdn2d_kernel(const float* in, const float* k, int kh, int kw, int up, int down, int pad0, float* out,
+                                 int NC, int H, int W, int oh, int ow) {
+    const long n = (long)NC * oh * ow;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+        const long pc = i / ((long)ow * oh);
+        const float* plane = in + pc * H * W;
+        float acc = 0.0f;
+        for (int a = 0; a < kh; ++a) {
+            const int qy = oy * down + a - pad0;                  // coordinate in the zero-inserted image
+            if (qy < 0 || qy >= H * up || qy % up) continue;
+            for (int b = 0; b < kw; ++b) {
+                const int qx = ox * down + b - pad0;
+                if (qx < 0 || qx >= W * up || qx % up) continue;
+                acc += k[(kh - 1 - a) * kw + (kw - 1 - b)] * plane[(qy / up) * W + qx / up];
+            }
+        }
+        out[i] = acc;
+    }
+}
+
+int launch_upfirdn2d(const float* in, const float* kernel_dev, int kh, int kw, int up, int down, int pad0, int pad1,
+                     float* out, int NC, int H, int W, int oh, int ow, hipStream_t s) {
+    (void)pad1;
+    const long n = (long)NC * oh * ow;
+    const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3(blocks), dim3(256), 0, s, in, kernel_dev, kh, kw, up, down, pad0, out, NC, H,
+                       W, oh, ow);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// F.interpolate(mode='nearest'): src = floor(dst * in/out)
+__global__ void nearest_kernel(const float* in, float* out, int BC, int H, int W, int oh, int ow) {
+    const long n = (long)BC * oh * ow;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+        const long pc = i / ((long)ow * oh);
+        const int sy = (int)(((long)oy * H) / oh), sx = (int)(((long)ox * W) / ow);
+        out[i] = in[pc * H * W + sy * W + sx];
+    }
+}
+
+int launch_nearest_resize(const float* in, float* out, int BC, int H, int W, int oh, int ow, hipStream_t s) {
+    const long n = (long)BC * oh * ow;
+    const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+    hipLaunchKernelGGL(nearest_kernel, dim3(blocks), dim3(256), 0, s, in, out, BC, H, W, oh, ow);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mcvd

@@ -1,0 +1,176 @@
+// Sampler elementwise kernels: label fill, the fused DDPM/DDIM update (models/__init__.py:287-290, :165-168,
+// :324-328), the t_min re-noise (:279), the final denoise (:333), and a counter-based Philox4x32-10 + Box-Muller
+// normal generator keyed by (seed, GLOBAL sample index, draw, element) so the stream does not depend on how the
+// batch is sharded over GPUs.  The arithmetic keeps the reference's operation order with explicit non-fused
+// multiplies/adds (CPU torch does not contract to FMA).
+#include "../common.h"
+
+namespace mcvd {
+
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                             uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+// 4 standard normals for counter (sample, draw, elem4)
+__device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint64_t sample, uint64_t draw, uint64_t elem4) {
+    uint32_t c0 = (uint32_t)elem4, c1 = (uint32_t)(elem4 >> 32) ^ (uint32_t)(draw << 8), c2 = (uint32_t)sample,
+             c3 = (uint32_t)(sample >> 32) ^ (uint32_t)(draw >> 24);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);    // (0,1)
+    const float u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float s0, cs0, s1, cs1;
+    sincosf(6.283185307179586f * u1, &s0, &cs0);
+    sincosf(6.283185307179586f * u3, &s1, &cs1);
+    return make_float4(r0 * cs0, r0 * s0, r1 * cs1, r1 * s1);
+}
+
+__global__ void fill_labels_kernel(int64_t* labels, int64_t v, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) labels[i] = v;
+}
+int launch_fill_labels(int64_t* labels, int64_t value, int B, hipStream_t s) {
+    hipLaunchKernelGGL(fill_labels_kernel, dim3((B + 255) / 256), dim3(256), 0, s, labels, value, B);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+struct UpdArgs {
+    int kind; float* x; const float* eps; const float* noise; float c_x0a, c_x0b, c_mean0, c_mean1, c_noise; int clip;
+    int64_t n; int use_philox; uint64_t seed, sample_offset, draw; int64_t per_sample;
+};
+
+__global__ __launch_bounds__(256) void sampler_update_kernel(UpdArgs a) {
+    const int64_t n4 = a.n >> 2;
+    for (int64_t i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 xv = reinterpret_cast<const float4*>(a.x)[i];
+        const float4 ev = reinterpret_cast<const float4*>(a.eps)[i];
+        float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.c_noise != 0.0f) {
+            if (a.use_philox) {
+                const int64_t e = i * 4;
+                const int64_t row = e / a.per_sample;
+                zv = philox_normal4(a.seed, a.sample_offset + (uint64_t)row, a.draw, (uint64_t)((e - row * a.per_sample) >> 2));
+            } else {
+                zv = reinterpret_cast<const float4*>(a.noise)[i];
+            }
+        }
+        float xs[4] = {xv.x, xv.y, xv.z, xv.w}, es[4] = {ev.x, ev.y, ev.z, ev.w}, zs[4] = {zv.x, zv.y, zv.z, zv.w}, o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // x0 = (1/sqrt(a)) * (x - sqrt(1-a)*eps)                                   :287 / :165
+            float x0 = __fmul_rn(a.c_x0a, __fsub_rn(xs[j], __fmul_rn(a.c_x0b, es[j])));
+            if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                              // :288-289
+            // ddpm: c_mean0*x0 + c_mean1*x (:290)      ddim: c_mean0*x0 + c_mean1*eps (:168)
+            const float second = (a.kind == 0) ? xs[j] : es[j];
+            float v = __fadd_rn(__fmul_rn(a.c_mean0, x0), __fmul_rn(a.c_mean1, second));
+            if (a.c_noise != 0.0f) v = __fadd_rn(v, __fmul_rn(a.c_noise, zs[j]));       // :326/:328
+            o[j] = v;
+        }
+        reinterpret_cast<float4*>(a.x)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static int grid_for(int64_t n4) { return (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256); }
+
+int launch_sampler_update(int kind, float* x, const float* eps, const float* noise, float c_x0a, float c_x0b,
+                          float c_mean0, float c_mean1, float c_noise, int clip, int64_t n, int use_philox,
+                          uint64_t seed, uint64_t sample_offset, uint64_t draw, int64_t per_sample, hipStream_t s) {
+    MCVD_REQUIRE(n % 4 == 0 && (per_sample % 4 == 0 || !use_philox), "sampler_update: n must be a multiple of 4");
+    MCVD_REQUIRE(c_noise == 0.0f || use_philox || noise, "sampler_update: noise needed");
+    UpdArgs a{kind, x, eps, noise, c_x0a, c_x0b, c_mean0, c_mean1, c_noise, clip, n, use_philox, seed, sample_offset, draw,
+              per_sample};
+    hipLaunchKernelGGL(sampler_update_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, a);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// x = ca*x + cb*z      (t_min re-noise, models/__init__.py:279)
+__global__ __launch_bounds__(256) void renoise_kernel(float* x, const float* noise, float ca, float cb, int64_t n,
+                                                       int use_philox, uint64_t seed, uint64_t sample_offset,
+                                                       uint64_t draw, int64_t per_sample) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 xv = reinterpret_cast<float4*>(x)[i];
+        float4 zv;
+        if (use_philox) {
+            const int64_t e = i * 4;
+            const int64_t row = e / per_sample;
+            zv = philox_normal4(seed, sample_offset + (uint64_t)row, draw, (uint64_t)((e - row * per_sample) >> 2));
+        } else {
+            zv = reinterpret_cast<const float4*>(noise)[i];
+        }
+        xv.x = __fadd_rn(__fmul_rn(ca, xv.x), __fmul_rn(cb, zv.x));
+        xv.y = __fadd_rn(__fmul_rn(ca, xv.y), __fmul_rn(cb, zv.y));
+        xv.z = __fadd_rn(__fmul_rn(ca, xv.z), __fmul_rn(cb, zv.z));
+        xv.w = __fadd_rn(__fmul_rn(ca, xv.w), __fmul_rn(cb, zv.w));
+        reinterpret_cast<float4*>(x)[i] = xv;
+    }
+}
+
+int launch_renoise(float* x, const float* noise, float ca, float cb, int64_t n, int use_philox, uint64_t seed,
+                   uint64_t sample_offset, uint64_t draw, int64_t per_sample, hipStream_t s) {
+    MCVD_REQUIRE(n % 4 == 0, "renoise: n must be a multiple of 4");
+    MCVD_REQUIRE(use_philox || noise, "renoise: noise needed");
+    hipLaunchKernelGGL(renoise_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, x, noise, ca, cb, n, use_philox, seed,
+                       sample_offset, draw, per_sample);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// x = x - c*eps       (denoise, models/__init__.py:333)
+__global__ __launch_bounds__(256) void axpy_out_kernel(float* x, const float* eps, float c, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 xv = reinterpret_cast<float4*>(x)[i];
+        const float4 ev = reinterpret_cast<const float4*>(eps)[i];
+        xv.x = __fsub_rn(xv.x, __fmul_rn(c, ev.x));
+        xv.y = __fsub_rn(xv.y, __fmul_rn(c, ev.y));
+        xv.z = __fsub_rn(xv.z, __fmul_rn(c, ev.z));
+        xv.w = __fsub_rn(xv.w, __fmul_rn(c, ev.w));
+        reinterpret_cast<float4*>(x)[i] = xv;
+    }
+}
+
+int launch_axpy_out(float* x, const float* eps, float c, int64_t n, hipStream_t s) {
+    MCVD_REQUIRE(n % 4 == 0, "axpy: n must be a multiple of 4");
+    hipLaunchKernelGGL(axpy_out_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, x, eps, c, n);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw,
+                                                     int64_t n, int64_t per_sample) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i * 4;
+        const int64_t row = e / per_sample;
+        reinterpret_cast<float4*>(out)[i] =
+            philox_normal4(seed, sample_offset + (uint64_t)row, draw, (uint64_t)((e - row * per_sample) >> 2));
+    }
+}
+
+int launch_randn(float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample,
+                 hipStream_t s) {
+    MCVD_REQUIRE(per_sample % 4 == 0, "randn: per_sample must be a multiple of 4");
+    const int64_t n = (int64_t)B * per_sample;
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, out, seed, sample_offset, draw, n, per_sample);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mcvd

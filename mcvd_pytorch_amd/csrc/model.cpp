@@ -1,0 +1,527 @@
+// Static op plan for the `unetmore` UNet (reference: models/better/ncsnpp_more.py:70-249 construction order,
+// :251-392 forward order), parameter blob, weight packing and the forward executor.
+#include "model.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace mcvd {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+static int gn_groups(int ch) {      // layerspp.py:474-476 (also :212-214, :128-130)
+    int g = std::min(ch / 4, 32);
+    while (g > 1 && ch % g != 0) --g;
+    return g < 1 ? 1 : g;
+}
+
+static int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+
+}  // namespace mcvd
+
+using namespace mcvd;
+
+int mcvd_ctx::ensure_scratch(size_t bytes) {
+    if (bytes <= scratch_bytes) return 0;
+    if (scratch) {
+        MCVD_HIP_CHECK(hipStreamSynchronize(stream));
+        MCVD_HIP_CHECK(hipFree(scratch));
+        scratch = nullptr;
+        scratch_bytes = 0;
+    }
+    MCVD_HIP_CHECK(hipMalloc((void**)&scratch, bytes));
+    scratch_bytes = bytes;
+    return 0;
+}
+
+int mcvd_model::add_param(const std::string& name, std::initializer_list<int64_t> shape) {
+    ParamInfo p;
+    p.name = name;
+    p.ndim = (int)shape.size();
+    p.numel = 1;
+    int i = 0;
+    for (int64_t s : shape) {
+        p.shape[i++] = s;
+        p.numel *= s;
+    }
+    p.off = blob_floats;
+    blob_floats += align4(p.numel);
+    pindex[name] = (int)params.size();
+    params.push_back(p);
+    return (int)params.size() - 1;
+}
+
+int mcvd_model::find_param(const char* name) const {
+    std::string n(name);
+    if (n.rfind("module.", 0) == 0) n = n.substr(7);      // DataParallel prefix (ncsn_runner.py:426-433)
+    auto it = pindex.find(n);
+    return it == pindex.end() ? -1 : it->second;
+}
+
+namespace {
+
+struct Act {
+    TRef a, b;      // b.kind == REF_NONE unless this is a virtual concat [a, b]
+    int H = 0;
+    int C() const { return a.C + b.C; }
+};
+
+struct Builder {
+    mcvd_model& m;
+    int64_t arena = 0;
+    int64_t packed = 0;
+    explicit Builder(mcvd_model& mm) : m(mm) {}
+
+    TRef alloc_floats(int64_t per_sample, int C) {
+        TRef r;
+        r.kind = REF_ARENA;
+        r.off = arena;
+        r.C = C;
+        arena += align4(per_sample);
+        return r;
+    }
+    TRef alloc(int C, int H) { return alloc_floats((int64_t)C * H * H, C); }
+    int64_t alloc_packed(int64_t floats) {
+        const int64_t o = packed;
+        packed += align4(floats);
+        return o;
+    }
+
+    int dense_entry(const std::string& prefix, int ch) {
+        m.add_param(prefix + ".Dense_0.weight", {2 * ch, m.T});
+        m.add_param(prefix + ".Dense_0.bias", {2 * ch});
+        DenseEntry e{prefix + ".Dense_0.weight", prefix + ".Dense_0.bias", ch, m.NE};
+        m.NE += 2 * ch;
+        m.dense.push_back(e);
+        return e.emb_off;
+    }
+
+    // registers weights (possibly several fused along Cout) and fills the conv fields of `op`
+    void conv_pack(Op& op, const std::vector<std::string>& wnames, const std::vector<std::string>& bnames, int Cout_each,
+                   int Cin, int ks, int nin) {
+        ConvPack p;
+        p.weights = wnames;
+        p.biases = bnames;
+        p.Cout_each = Cout_each;
+        p.Cin = Cin;
+        p.ks = ks;
+        p.nin = nin;
+        const int Cout = Cout_each * (int)wnames.size();
+        p.CinP = round_up(Cin, conv_chunk(ks));
+        const int cot = conv_cout_tile(Cout);
+        p.CoutP = round_up(Cout, 32 * cot);
+        p.wp = alloc_packed((int64_t)p.CinP * ks * ks * p.CoutP);
+        p.bias = alloc_packed(p.CoutP);
+        m.packs.push_back(p);
+        op.ks = ks;
+        op.Cout = Cout;
+        op.CinP = p.CinP;
+        op.CoutP = p.CoutP;
+        op.cot = cot;
+        op.wp = p.wp;
+        op.bias = p.bias;
+    }
+
+    Op gn_op(int module, const Act& x, float eps, int mode, int emb_off, int64_t p0, int64_t p1, const TRef& coef) {
+        Op op{};
+        op.kind = OP_GN;
+        op.module = module;
+        op.src0 = x.a;
+        op.src1 = x.b;
+        op.H = op.W = x.H;
+        op.groups = gn_groups(x.C());
+        op.eps = eps;
+        op.gn_mode = mode;
+        op.emb_off = emb_off;
+        op.p0 = p0;
+        op.p1 = p1;
+        op.coef = coef;
+        return op;
+    }
+
+    // layerspp.py:553-624 ResnetBlockBigGANppGN
+    int res_block(int idx, const Act& x, int cin, int cout, bool up, bool down, Act* out) {
+        const std::string P = "unet.all_modules." + std::to_string(idx);
+        MCVD_REQUIRE(x.C() == cin, "plan: module %d expects %d channels, got %d", idx, cin, x.C());
+        MCVD_REQUIRE(!(up || down) || x.b.kind == REF_NONE, "plan: resample block %d fed by a concat", idx);
+        const bool conv2 = (cin != cout) || up || down;
+        const int e0 = dense_entry(P + ".actnorm0", cin);
+        m.add_param(P + ".Conv_0.weight", {cout, cin, 3, 3});
+        m.add_param(P + ".Conv_0.bias", {cout});
+        const int e1 = dense_entry(P + ".actnorm1", cout);
+        m.add_param(P + ".Conv_1.weight", {cout, cout, 3, 3});
+        m.add_param(P + ".Conv_1.bias", {cout});
+        if (conv2) {
+            m.add_param(P + ".Conv_2.weight", {cout, cin, 1, 1});
+            m.add_param(P + ".Conv_2.bias", {cout});
+        }
+        const int H = x.H, Ho = up ? 2 * H : (down ? H / 2 : H);
+        const float rs2 = 1.0f / (float)sqrt(2.0);
+
+        TRef coef0 = alloc_floats(2 * cin, cin);
+        m.ops.push_back(gn_op(idx, x, 1e-5f, 1, e0, -1, -1, coef0));
+
+        Act h1;
+        h1.H = Ho;
+        h1.a = alloc(cout, Ho);
+        TRef shortcut_src0 = x.a, shortcut_src1 = x.b;
+        if (up || down) {
+            TRef hA = alloc(cin, Ho), xr = alloc(cin, Ho);
+            Op f{};
+            f.kind = OP_FIR; f.module = idx; f.src0 = x.a; f.H = f.W = H; f.coef = coef0; f.act = 1; f.up = up ? 1 : 0; f.dst = hA;
+            m.ops.push_back(f);
+            Op f2 = f;
+            f2.coef = TRef{}; f2.act = 0; f2.dst = xr;
+            m.ops.push_back(f2);
+            Op c{};
+            c.kind = OP_CONV; c.module = idx; c.src0 = hA; c.H = c.W = Ho; c.dst = h1.a;
+            conv_pack(c, {P + ".Conv_0.weight"}, {P + ".Conv_0.bias"}, cout, cin, 3, 0);
+            m.ops.push_back(c);
+            shortcut_src0 = xr;
+            shortcut_src1 = TRef{};
+        } else {
+            Op c{};
+            c.kind = OP_CONV; c.module = idx; c.src0 = x.a; c.src1 = x.b; c.H = c.W = H; c.coef = coef0; c.act = 1; c.dst = h1.a;
+            conv_pack(c, {P + ".Conv_0.weight"}, {P + ".Conv_0.bias"}, cout, cin, 3, 0);
+            m.ops.push_back(c);
+        }
+        TRef coef1 = alloc_floats(2 * cout, cout);
+        m.ops.push_back(gn_op(idx, h1, 1e-5f, 1, e1, -1, -1, coef1));
+
+        TRef res;
+        if (conv2) {
+            res = alloc(cout, Ho);
+            Op c{};
+            c.kind = OP_CONV; c.module = idx; c.src0 = shortcut_src0; c.src1 = shortcut_src1; c.H = c.W = Ho; c.dst = res;
+            conv_pack(c, {P + ".Conv_2.weight"}, {P + ".Conv_2.bias"}, cout, cin, 1, 0);
+            m.ops.push_back(c);
+        } else {
+            res = x.a;      // identity shortcut (in == out, no resample => single source)
+        }
+        out->H = Ho;
+        out->a = alloc(cout, Ho);
+        out->b = TRef{};
+        Op c{};
+        c.kind = OP_CONV; c.module = idx; c.src0 = h1.a; c.H = c.W = Ho; c.coef = coef1; c.act = 1; c.res = res;
+        c.out_scale = rs2; c.dst = out->a;
+        conv_pack(c, {P + ".Conv_1.weight"}, {P + ".Conv_1.bias"}, cout, cout, 3, 0);
+        m.ops.push_back(c);
+        return 0;
+    }
+
+    // layerspp.py:207-249 AttnBlockpp
+    int attn_block(int idx, const Act& x, int ch, Act* out) {
+        const std::string P = "unet.all_modules." + std::to_string(idx);
+        MCVD_REQUIRE(x.b.kind == REF_NONE && x.C() == ch, "plan: attention block %d input", idx);
+        const int gw = m.add_param(P + ".GroupNorm_0.weight", {ch});
+        const int gb = m.add_param(P + ".GroupNorm_0.bias", {ch});
+        for (int j = 0; j < 4; ++j) {
+            m.add_param(P + ".NIN_" + std::to_string(j) + ".W", {ch, ch});
+            m.add_param(P + ".NIN_" + std::to_string(j) + ".b", {ch});
+        }
+        int heads = 1;
+        const int nhc = m.d.n_head_channels;
+        if (nhc != -1 && ch >= nhc) {
+            MCVD_REQUIRE(nhc > 0 && ch % nhc == 0, "attention: %d channels not divisible by n_head_channels %d", ch, nhc);
+            heads = ch / nhc;
+        }
+        const int H = x.H;
+        const float rs2 = 1.0f / (float)sqrt(2.0);
+        TRef coef = alloc_floats(2 * ch, ch);
+        m.ops.push_back(gn_op(idx, x, 1e-6f, 2, 0, m.params[gw].off, m.params[gb].off, coef));
+        TRef qkv = alloc(3 * ch, H);
+        Op c{};
+        c.kind = OP_CONV; c.module = idx; c.src0 = x.a; c.H = c.W = H; c.coef = coef; c.act = 0; c.dst = qkv;
+        conv_pack(c, {P + ".NIN_0.W", P + ".NIN_1.W", P + ".NIN_2.W"}, {P + ".NIN_0.b", P + ".NIN_1.b", P + ".NIN_2.b"}, ch, ch, 1, 1);
+        m.ops.push_back(c);
+        TRef o = alloc(ch, H);
+        Op a{};
+        a.kind = OP_ATTN; a.module = idx; a.src0 = qkv; a.dst = o; a.H = a.W = H; a.heads = heads; a.Cout = ch;
+        m.ops.push_back(a);
+        out->H = H;
+        out->a = alloc(ch, H);
+        out->b = TRef{};
+        Op p{};
+        p.kind = OP_CONV; p.module = idx; p.src0 = o; p.H = p.W = H; p.res = x.a; p.out_scale = rs2; p.dst = out->a;
+        conv_pack(p, {P + ".NIN_3.W"}, {P + ".NIN_3.b"}, ch, ch, 1, 1);
+        m.ops.push_back(p);
+        return 0;
+    }
+};
+
+}  // namespace
+
+int mcvd_model::build_plan() {
+    const mcvd_unet_desc& c = d;
+    MCVD_REQUIRE(c.n_levels >= 1 && c.n_levels <= MCVD_MAX_LEVELS, "desc: n_levels=%d", c.n_levels);
+    MCVD_REQUIRE(c.image_size >= 8 && (c.image_size & (c.image_size - 1)) == 0, "desc: image_size=%d must be a power of two", c.image_size);
+    MCVD_REQUIRE((c.image_size >> (c.n_levels - 1)) >= 8, "desc: lowest resolution %d < 8", c.image_size >> (c.n_levels - 1));
+    MCVD_REQUIRE(c.ngf >= 8 && c.ngf % 4 == 0 && c.ngf <= 256, "desc: ngf=%d", c.ngf);
+    MCVD_REQUIRE(c.channels > 0 && c.num_frames > 0 && c.num_frames_cond >= 0, "desc: frames/channels");
+    MCVD_REQUIRE(!c.spade, "model.spade=true is not implemented yet in this build");
+    MCVD_REQUIRE(c.num_classes >= 2, "desc: num_classes=%d", c.num_classes);
+    const int nf = c.ngf, C = c.channels, L = c.n_levels, S = c.image_size;
+    T = 4 * nf;
+    NE = 0;
+    Builder bld(*this);
+
+    // modules 0,1: time MLP (ncsnpp_more.py:88-95)
+    add_param("unet.all_modules.0.weight", {T, nf});
+    add_param("unet.all_modules.0.bias", {T});
+    add_param("unet.all_modules.1.weight", {T, T});
+    add_param("unet.all_modules.1.bias", {T});
+    Op temb{};
+    temb.kind = OP_TEMB; temb.module = 0;
+    ops.push_back(temb);
+    Op dense_op{};
+    dense_op.kind = OP_DENSE; dense_op.module = 1;
+    ops.push_back(dense_op);
+
+    auto in_attn = [&](int res) {
+        for (int i = 0; i < c.n_attn; ++i)
+            if (c.attn_resolutions[i] == res) return true;
+        return false;
+    };
+
+    // module 2: stem conv over [x, cond] (ncsnpp_more.py:188, :257)
+    int idx = 2;
+    const int cx = C * c.num_frames, cc = c.spade ? 0 : C * c.num_frames_cond;
+    add_param("unet.all_modules.2.weight", {nf, cx + cc, 3, 3});
+    add_param("unet.all_modules.2.bias", {nf});
+    std::vector<Act> hs;
+    {
+        Act h;
+        h.H = S;
+        h.a = bld.alloc(nf, S);
+        Op cv{};
+        cv.kind = OP_CONV; cv.module = idx; cv.H = cv.W = S; cv.dst = h.a;
+        cv.src0 = TRef{REF_X, 0, cx};
+        if (cc > 0) cv.src1 = TRef{REF_COND, 0, cc};
+        bld.conv_pack(cv, {"unet.all_modules.2.weight"}, {"unet.all_modules.2.bias"}, nf, cx + cc, 3, 0);
+        ops.push_back(cv);
+        hs.push_back(h);
+    }
+    ++idx;
+    int in_ch = nf;
+    int res = S;
+    for (int lv = 0; lv < L; ++lv) {
+        for (int rb = 0; rb < c.num_res_blocks; ++rb) {
+            const int out_ch = nf * c.ch_mult[lv];
+            Act h;
+            if (bld.res_block(idx++, hs.back(), in_ch, out_ch, false, false, &h)) return -1;
+            in_ch = out_ch;
+            if (in_attn(res)) {
+                Act h2;
+                if (bld.attn_block(idx++, h, in_ch, &h2)) return -1;
+                h = h2;
+            }
+            hs.push_back(h);
+        }
+        if (lv != L - 1) {
+            Act h;
+            if (bld.res_block(idx++, hs.back(), in_ch, in_ch, false, true, &h)) return -1;
+            hs.push_back(h);
+            res /= 2;
+        }
+    }
+    Act h = hs.back();
+    {
+        Act t;
+        if (bld.res_block(idx++, h, in_ch, in_ch, false, false, &t)) return -1;
+        h = t;
+        if (bld.attn_block(idx++, h, in_ch, &t)) return -1;
+        h = t;
+        if (bld.res_block(idx++, h, in_ch, in_ch, false, false, &t)) return -1;
+        h = t;
+    }
+    for (int lv = L - 1; lv >= 0; --lv) {
+        for (int rb = 0; rb < c.num_res_blocks + 1; ++rb) {
+            const int out_ch = nf * c.ch_mult[lv];
+            Act skip = hs.back();
+            hs.pop_back();
+            MCVD_REQUIRE(skip.H == h.H, "plan: skip resolution mismatch at module %d", idx);
+            Act cat;
+            cat.H = h.H;
+            cat.a = h.a;
+            cat.b = skip.a;           // torch.cat([h, hs.pop()], dim=1)  ncsnpp_more.py:356-357
+            Act t;
+            if (bld.res_block(idx++, cat, in_ch + skip.a.C, out_ch, false, false, &t)) return -1;
+            h = t;
+            in_ch = out_ch;
+        }
+        if (in_attn(h.H)) {
+            Act t;
+            if (bld.attn_block(idx++, h, in_ch, &t)) return -1;
+            h = t;
+        }
+        if (lv != 0) {
+            Act t;
+            if (bld.res_block(idx++, h, in_ch, in_ch, true, false, &t)) return -1;
+            h = t;
+        }
+    }
+    MCVD_REQUIRE(hs.empty(), "plan: skip stack not empty");
+    // final GroupNorm(affine)+SiLU, conv3x3 (ncsnpp_more.py:246-247)
+    {
+        const std::string P = "unet.all_modules." + std::to_string(idx);
+        const int gw = add_param(P + ".Norm_0.weight", {in_ch});
+        const int gb = add_param(P + ".Norm_0.bias", {in_ch});
+        TRef coef = bld.alloc_floats(2 * in_ch, in_ch);
+        ops.push_back(bld.gn_op(idx, h, 1e-5f, 2, 0, params[gw].off, params[gb].off, coef));
+        ++idx;
+        const std::string Q = "unet.all_modules." + std::to_string(idx);
+        add_param(Q + ".weight", {cx, in_ch, 3, 3});
+        add_param(Q + ".bias", {cx});
+        Op cv{};
+        cv.kind = OP_CONV; cv.module = idx; cv.src0 = h.a; cv.H = cv.W = h.H; cv.coef = coef; cv.act = 1;
+        cv.dst = TRef{REF_OUT, 0, cx};
+        bld.conv_pack(cv, {Q + ".weight"}, {Q + ".bias"}, cx, in_ch, 3, 0);
+        ops.push_back(cv);
+        ++idx;
+    }
+    // time-embedding buffers and the fused Dense_0 matrix
+    ops[0].dst = bld.alloc_floats(T, T);                 // silu(temb)   [B][T]
+    ops[1].src0 = ops[0].dst;
+    ops[1].dst = bld.alloc_floats(NE, NE);               // all (scale, shift) pairs [B][NE]
+    dense_wt = bld.alloc_packed((int64_t)T * NE);
+    dense_bias = bld.alloc_packed(NE);
+    freqs_off = bld.alloc_packed(nf / 2);
+    arena_per_sample = bld.arena;
+    packed_floats = bld.packed;
+    return 0;
+}
+
+int mcvd_model::ensure_workspace(int B) {
+    if (B <= arena_B) return 0;
+    hipStream_t s = ctx->stream;
+    MCVD_HIP_CHECK(hipStreamSynchronize(s));
+    if (arena) MCVD_HIP_CHECK(hipFree(arena));
+    if (labels) MCVD_HIP_CHECK(hipFree(labels));
+    if (eps_buf) MCVD_HIP_CHECK(hipFree(eps_buf));
+    arena = nullptr; labels = nullptr; eps_buf = nullptr; arena_B = 0;
+    const size_t per = (size_t)d.channels * d.num_frames * d.image_size * d.image_size;
+    MCVD_HIP_CHECK(hipMalloc((void**)&arena, (size_t)arena_per_sample * B * sizeof(float)));
+    MCVD_HIP_CHECK(hipMalloc((void**)&labels, (size_t)B * sizeof(int64_t)));
+    MCVD_HIP_CHECK(hipMalloc((void**)&eps_buf, per * B * sizeof(float)));
+    arena_B = B;
+    return 0;
+}
+
+float* mcvd_model::resolve(const TRef& r, const float* x, const float* cond, float* out, int B) const {
+    switch (r.kind) {
+        case REF_ARENA: return arena + r.off * (int64_t)B;
+        case REF_X: return const_cast<float*>(x);
+        case REF_COND: return const_cast<float*>(cond);
+        case REF_OUT: return out;
+        default: return nullptr;
+    }
+}
+
+int mcvd_model::launch_op(const Op& op, const float* x, const int64_t* lab, const float* cond, float* out, int B) {
+    hipStream_t s = ctx->stream;
+    switch (op.kind) {
+        case OP_TEMB: {
+            const float* w0 = blob + params[find_param("unet.all_modules.0.weight")].off;
+            const float* b0 = blob + params[find_param("unet.all_modules.0.bias")].off;
+            const float* w1 = blob + params[find_param("unet.all_modules.1.weight")].off;
+            const float* b1 = blob + params[find_param("unet.all_modules.1.bias")].off;
+            return launch_temb_mlp(lab, packed + freqs_off, w0, b0, w1, b1, resolve(op.dst, x, cond, out, B), B, d.ngf, s);
+        }
+        case OP_DENSE:
+            return launch_dense_all(resolve(op.src0, x, cond, out, B), packed + dense_wt, packed + dense_bias,
+                                    resolve(op.dst, x, cond, out, B), B, T, NE, s);
+        case OP_GN: {
+            GnArgs a{};
+            a.x0 = resolve(op.src0, x, cond, out, B);
+            a.x1 = resolve(op.src1, x, cond, out, B);
+            a.C0 = op.src0.C;
+            a.C1 = op.src1.kind == REF_NONE ? 0 : op.src1.C;
+            a.groups = op.groups;
+            a.eps = op.eps;
+            a.mode = op.gn_mode;
+            if (op.gn_mode == 1) {
+                a.p0 = resolve(ops[1].dst, x, cond, out, B);
+                a.emb_stride = NE;
+                a.emb_off = op.emb_off;
+            } else if (op.gn_mode == 2) {
+                a.p0 = blob + op.p0;
+                a.p1 = blob + op.p1;
+            }
+            a.coef = resolve(op.coef, x, cond, out, B);
+            a.B = B;
+            a.HW = op.H * op.W;
+            return launch_gn_coef(a, s);
+        }
+        case OP_CONV: {
+            ConvArgs a{};
+            a.x0 = resolve(op.src0, x, cond, out, B);
+            a.x1 = resolve(op.src1, x, cond, out, B);
+            a.C0 = op.src0.C;
+            a.C1 = op.src1.kind == REF_NONE ? 0 : op.src1.C;
+            MCVD_REQUIRE(a.x0 && (a.C1 == 0 || a.x1), "forward: module %d needs a conditioning tensor (cond is NULL)", op.module);
+            a.coef = op.coef.kind == REF_NONE ? nullptr : resolve(op.coef, x, cond, out, B);
+            a.act = op.act;
+            a.wp = packed + op.wp;
+            a.bias = packed + op.bias;
+            a.res = op.res.kind == REF_NONE ? nullptr : resolve(op.res, x, cond, out, B);
+            a.out_scale = op.out_scale;
+            a.y = resolve(op.dst, x, cond, out, B);
+            a.B = B;
+            a.Cin = a.C0 + a.C1;
+            a.CinP = op.CinP;
+            a.Cout = op.Cout;
+            a.CoutP = op.CoutP;
+            a.H = op.H;
+            a.W = op.W;
+            a.ks = op.ks;
+            a.cot = op.cot;
+            a.shape_hint = ctx->conv_shape;
+            return ctx->naive_conv ? launch_conv_naive(a, s) : launch_conv_mfma(a, s);
+        }
+        case OP_FIR:
+            return launch_fir2(resolve(op.src0, x, cond, out, B),
+                               op.coef.kind == REF_NONE ? nullptr : resolve(op.coef, x, cond, out, B), op.act, op.up,
+                               resolve(op.dst, x, cond, out, B), B, op.src0.C, op.H, op.W, nullptr, nullptr, nullptr, s);
+        case OP_ATTN:
+            return (ctx->naive_attn ? launch_attention_naive : launch_attention_mfma)(
+                resolve(op.src0, x, cond, out, B), resolve(op.dst, x, cond, out, B), B, op.Cout, op.heads, op.H * op.W, s);
+        default:
+            set_error("forward: unknown op kind %d", (int)op.kind);
+            return -1;
+    }
+}
+
+int mcvd_model::forward(const float* x, const int64_t* lab, const float* cond, float* out, int B) {
+    MCVD_REQUIRE(finalized, "forward before mcvd_model_finalize");
+    MCVD_REQUIRE(B > 0 && x && lab && out, "forward: bad arguments");
+    if (int rc = ensure_workspace(B)) return rc;
+    if (ctx->profile && profile_armed) {
+        profile_armed = false;
+        if (ev.size() != 2 * ops.size()) {
+            for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+            ev.assign(2 * ops.size(), nullptr);
+            for (auto& e : ev) MCVD_HIP_CHECK(hipEventCreate(&e));
+        }
+        profile_B = B;
+        for (size_t i = 0; i < ops.size(); ++i) {
+            MCVD_HIP_CHECK(hipEventRecord(ev[2 * i], ctx->stream));
+            if (int rc = launch_op(ops[i], x, lab, cond, out, B)) return rc;
+            MCVD_HIP_CHECK(hipEventRecord(ev[2 * i + 1], ctx->stream));
+        }
+        return 0;
+    }
+    for (const Op& op : ops)
+        if (int rc = launch_op(op, x, lab, cond, out, B)) return rc;
+    return 0;
+}

@@ -1,0 +1,124 @@
+// Host-side executor: config -> static op plan, parameter blob, weight packing, forward, sampler loop.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mcvd_hip.h"
+#include "common.h"
+
+struct mcvd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int naive_conv = 0;
+    int naive_attn = 0;
+    int graph = 0;
+    int conv_shape = -1;           // -1 auto, 0/1/2 force a conv tile shape (tests)
+    int profile = 0;               // record HIP events around every op of the first forward of each sampler call
+    float* scratch = nullptr;      // small device scratch for stand-alone ops (kernel taps, packed weights)
+    size_t scratch_bytes = 0;
+    int ensure_scratch(size_t bytes);
+};
+
+namespace mcvd {
+
+struct ParamInfo {
+    std::string name;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int ndim = 0;
+    int64_t off = 0;       // float offset in the raw parameter blob
+    int64_t numel = 0;
+    bool set = false;
+};
+
+// where a tensor lives: workspace arena (offset in floats PER SAMPLE), or one of the caller's buffers
+enum RefKind { REF_NONE = 0, REF_ARENA, REF_X, REF_COND, REF_OUT };
+struct TRef {
+    RefKind kind = REF_NONE;
+    int64_t off = 0;
+    int C = 0;
+};
+
+enum OpKind { OP_TEMB, OP_DENSE, OP_GN, OP_CONV, OP_FIR, OP_ATTN, OP_NEAREST, OP_COEF2 };
+
+struct Op {
+    OpKind kind;
+    int module = -1;           // index in all_modules (for diagnostics)
+    TRef src0, src1, dst, res;
+    int H = 0, W = 0;
+    int Cout = 0, ks = 0;
+    // GroupNorm -> coef
+    int groups = 0;
+    float eps = 0.f;
+    int gn_mode = 0;
+    int64_t p0 = -1, p1 = -1;      // raw blob offsets (affine weight/bias)
+    int emb_off = 0;
+    TRef coef;                      // [2*C] per sample
+    int act = 0;
+    // conv
+    int64_t wp = -1, bias = -1;    // packed blob offsets
+    int CinP = 0, CoutP = 0, cot = 0;
+    float out_scale = 1.f;
+    // fir
+    int up = 0;
+    // attention
+    int heads = 0;
+    // SPADE
+    TRef gamma, beta, coef2;
+};
+
+struct DenseEntry {
+    std::string weight, bias;
+    int ch;
+    int emb_off;
+};
+
+struct ConvPack {
+    std::vector<std::string> weights;   // 1 entry, or 3 for the fused q|k|v projection
+    std::vector<std::string> biases;
+    int Cout_each, Cin, ks, CinP, CoutP, nin;
+    int64_t wp, bias;
+};
+
+}  // namespace mcvd
+
+struct mcvd_model {
+    mcvd_ctx* ctx = nullptr;
+    mcvd_unet_desc d;
+    bool finalized = false;
+
+    std::vector<mcvd::ParamInfo> params;
+    std::map<std::string, int> pindex;
+    int64_t blob_floats = 0;
+    float* blob = nullptr;            // raw parameters (device)
+
+    std::vector<mcvd::Op> ops;
+    std::vector<mcvd::DenseEntry> dense;
+    std::vector<mcvd::ConvPack> packs;
+    int64_t packed_floats = 0;
+    float* packed = nullptr;          // kernel-layout weights (device)
+    int64_t dense_wt = -1, dense_bias = -1, freqs_off = -1;
+    int NE = 0;                       // total Dense_0 outputs
+    int T = 0;                        // temb width
+
+    int64_t arena_per_sample = 0;     // floats
+    float* arena = nullptr;
+    int arena_B = 0;
+    int64_t* labels = nullptr;        // [arena_B] (sampler-owned labels)
+    float* eps_buf = nullptr;         // [arena_B * C*nf*S*S] (sampler-owned eps)
+
+    std::vector<float> betas, alphas, alphas_prev, freqs;
+
+    // per-op HIP event timing (bench.py roofline): events are recorded on the ctx stream around each op of ONE forward
+    std::vector<hipEvent_t> ev;
+    bool profile_armed = false;
+    int profile_B = 0;
+
+    int build_plan();
+    int add_param(const std::string& name, std::initializer_list<int64_t> shape);
+    int find_param(const char* name) const;
+    int ensure_workspace(int B);
+    int forward(const float* x, const int64_t* labels, const float* cond, float* out, int B);
+    int launch_op(const mcvd::Op& op, const float* x, const int64_t* labels, const float* cond, float* out, int B);
+    float* resolve(const mcvd::TRef& r, const float* x, const float* cond, float* out, int B) const;
+};

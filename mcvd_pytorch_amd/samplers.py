@@ -1,0 +1,203 @@
+"""DDPM / DDIM samplers with the reference's call surface (models/__init__.py:206-209, :102-104).
+
+    sampler(x_mod, scorenet, cond=None, final_only=..., denoise=..., subsample_steps=..., clip_before=...,
+            t_min=..., verbose=..., log=..., **kwargs) -> Tensor [(1 | n_saved), B, C*nf, H, W]
+
+Unknown kwargs (`cond_mask`, `n_steps_each`, `step_lr`, `config`, ... passed by runners/ncsn_runner.py:1513-1520)
+are accepted and ignored, as in the reference.  Two execution paths, same algebra:
+
+  * device loop  (`final_only=True`, no verbose/log, no same_noise/frac_steps): the whole L-step loop runs inside
+    `mcvd_sampler_run` -- labels, UNet forward, fused x0/clip/posterior/noise update, denoise pass -- with either an
+    injected noise sequence (`noise=` kwarg, for parity runs) or the on-device counter-based Philox stream keyed by
+    (seed, global sample index, draw).
+  * host loop: mirrors the reference loop statement by statement (images list, 10x logging of norms, same_noise,
+    frac_steps, just_beta) and calls the HIP forward + the fused update kernel once per step.
+
+`scorenet` must be a HipScoreNet (optionally wrapped in something exposing `.module`); anything else raises --
+this package has no eager fallback.
+"""
+import ctypes as C
+import logging
+from functools import partial
+
+import numpy as np
+import torch
+
+from . import _lib
+from .scorenet import HipScoreNet
+
+
+def _unwrap(scorenet):
+    net = scorenet.module if hasattr(scorenet, "module") else scorenet      # models/__init__.py:211
+    if not isinstance(net, HipScoreNet):
+        raise TypeError(f"mcvd_pytorch_amd samplers need a HipScoreNet, got {type(net).__name__} (no eager fallback)")
+    return net
+
+
+def _subsample(net, subsample_steps):
+    """Schedule subsampling, models/__init__.py:229-237 (fp32, on CPU copies of the buffers)."""
+    alphas, alphas_prev, betas = net.alphas.cpu(), net.alphas_prev.cpu(), net.betas.cpu()
+    steps = np.arange(len(betas))
+    if subsample_steps is not None and subsample_steps < len(alphas):
+        skip = len(alphas) // subsample_steps
+        steps = torch.tensor(list(range(0, len(alphas), skip)))
+        alphas = alphas.index_select(0, steps)
+        alphas_prev = torch.cat([alphas[1:], torch.tensor([1.0]).to(alphas)])
+        betas = 1.0 - torch.div(alphas, alphas_prev)
+    return steps, alphas, alphas_prev, betas
+
+
+def _draw_seed():
+    """A 63-bit seed from torch's default CPU generator, so torch.manual_seed() controls the device stream."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def _f(t):
+    return float(t)          # fp32 0-dim tensor -> python float (exact)
+
+
+@torch.no_grad()
+def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False, denoise=True, subsample_steps=None,
+            same_noise=False, noise_val=None, frac_steps=None, verbose=False, log=False, clip_before=True, t_min=-1,
+            gamma=False, noise=None, seed=None, sample_offset=0, **kwargs):
+    net = _unwrap(scorenet)
+    if gamma:
+        raise NotImplementedError("gamma noise is out of scope of the HIP path (SURVEY 8f rank 4)")
+    net.sync_parameters(force=True)
+    dev = net.device
+    x = x_mod.to(device=dev, dtype=torch.float32).contiguous().clone()
+    if cond is not None:
+        cond = cond.to(device=dev, dtype=torch.float32).contiguous()
+    B = x.shape[0]
+    per = x[0].numel()
+    if noise is not None:
+        noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+    name = "DDPM" if kind == _lib.SAMPLER_DDPM else "DDIM"
+
+    fast = final_only and not verbose and not log and not same_noise and noise_val is None and frac_steps is None
+    if fast:
+        flags = (_lib.FLAG_DENOISE if denoise else 0) | (_lib.FLAG_CLIP_BEFORE if clip_before else 0) \
+            | (_lib.FLAG_JUST_BETA if just_beta else 0)
+        if noise is None and seed is None:
+            seed = _draw_seed()
+        with torch.cuda.device(dev):
+            net._bind_stream()
+            _lib.check(_lib.lib.mcvd_sampler_run(
+                net._model, kind, C.c_void_p(x.data_ptr()), C.c_void_p(cond.data_ptr()) if cond is not None else None,
+                C.c_void_p(noise.data_ptr()) if noise is not None else None, C.c_uint64(seed or 0),
+                C.c_uint64(sample_offset), int(subsample_steps) if subsample_steps is not None else 0, flags,
+                float(t_min), B), "sampler_run")
+        return x.unsqueeze(0)
+
+    # ------------------------------------------------------------------ host loop (reference :262-340 / :138-203)
+    steps, alphas, alphas_prev, betas = _subsample(net, subsample_steps)
+    if frac_steps is not None and kind == _lib.SAMPLER_DDPM:                       # :250-254
+        steps = steps[int((1 - frac_steps) * len(steps)):]
+        alphas, alphas_prev, betas = alphas[steps], alphas_prev[steps], betas[steps]
+    if same_noise and noise_val is None:
+        noise_val = x.detach().clone()                                              # :259-260
+    draw = [0]
+
+    def next_noise():
+        if noise is not None:
+            z = noise[draw[0]]
+        elif seed is not None:
+            z = torch.empty_like(x)
+            _lib.check(_lib.lib.mcvd_randn(net._ctx, C.c_void_p(z.data_ptr()), C.c_uint64(seed), C.c_uint64(sample_offset),
+                                           C.c_uint64(draw[0]), B, per), "randn")
+        else:
+            z = torch.randn_like(x)                                                 # device RNG, as the reference
+        draw[0] += 1
+        return z.contiguous()
+
+    def update(eps, z, c_x0a, c_x0b, c0, c1, cn):
+        with torch.cuda.device(dev):
+            net._bind_stream()
+            _lib.check(_lib.lib.mcvd_sampler_update(
+                net._ctx, kind, C.c_void_p(x.data_ptr()), C.c_void_p(eps.data_ptr()),
+                C.c_void_p(z.data_ptr()) if z is not None else None, c_x0a, c_x0b, c0, c1, cn, 1 if clip_before else 0,
+                x.numel()), "sampler_update")
+
+    images = []
+    x_transf = False
+    L = len(steps)
+    for i, step in enumerate(steps):
+        if step < t_min * len(alphas):                                              # :269-270
+            continue
+        c_beta, c_alpha, c_alpha_prev = betas[i], alphas[i], alphas_prev[i]
+        if not x_transf and t_min > 0:                                              # :272-279
+            z = next_noise()
+            x.mul_(_f(c_alpha.sqrt())).add_(z, alpha=_f((1 - c_alpha).sqrt()))
+        x_transf = True
+        labels = (int(step) * torch.ones(B, device=dev)).long()                     # :283
+        grad = net(x, labels, cond=cond)                                            # :284
+        c_x0a, c_x0b = _f(1 / c_alpha.sqrt()), _f((1 - c_alpha).sqrt())             # :287
+        last_step = i + 1 == L
+        if kind == _lib.SAMPLER_DDPM:
+            c0 = _f(c_alpha_prev.sqrt() * c_beta / (1 - c_alpha))                   # :290
+            c1 = _f((1 - c_beta).sqrt() * (1 - c_alpha_prev) / (1 - c_alpha))
+        else:
+            c0, c1 = _f(c_alpha_prev.sqrt()), _f((1 - c_alpha_prev).sqrt())         # :168
+        need_log = (i == 0 or (i + 1) % max(L // 10, 1) == 0) and (verbose or log)
+        add_noise = kind == _lib.SAMPLER_DDPM and not last_step
+        # The reference appends/logs x_mod BEFORE adding the step noise (:292-308 precede :324-328), so when something
+        # must observe the pre-noise state the update is issued without noise and the noise is added afterwards.
+        split = add_noise and (not final_only or need_log)
+        z, cn = None, 0.0
+        if add_noise:
+            z = noise_val if same_noise else next_noise()
+            cn = _f(c_beta.sqrt()) if just_beta else _f(((1 - c_alpha_prev) / (1 - c_alpha) * c_beta).sqrt())   # :326/:328
+        update(grad, None if split else z, c_x0a, c_x0b, c0, c1, 0.0 if split else cn)
+        if not final_only:
+            images.append(x.to("cpu"))                                              # :292-293
+        if need_log:                                                                # :295-308
+            g = -1 / (1 - c_alpha).sqrt().item() * grad
+            grad_norm = torch.norm(g.reshape(B, -1), dim=-1).mean()
+            image_norm = torch.norm(x.reshape(B, -1), dim=-1).mean()
+            grad_mean_norm = torch.norm(g.mean(dim=0).reshape(-1)) ** 2 * (1 - c_alpha).item()
+            msg = "{}: {}/{}, grad_norm: {}, image_norm: {}, grad_mean_norm: {}".format(
+                name, i + 1, L, grad_norm.item(), image_norm.item(), grad_mean_norm.item())
+            if verbose:
+                print(msg)
+            if log:
+                logging.info(msg)
+        if split:
+            x.add_(z, alpha=cn)
+
+    if denoise:                                                                     # :331-335 (label L-1, sic)
+        last_noise = ((L - 1) * torch.ones(B, device=dev)).long()
+        x = x - _f((1 - alphas[-1]).sqrt()) * net(x, last_noise, cond=cond)
+        if not final_only:
+            images.append(x.to("cpu"))
+    if final_only:
+        return x.unsqueeze(0)
+    return torch.stack(images)
+
+
+def ddpm_sampler(x_mod, scorenet, cond=None, just_beta=False, final_only=False, denoise=True, subsample_steps=None,
+                 same_noise=False, noise_val=None, frac_steps=None, verbose=False, log=False, clip_before=True,
+                 t_min=-1, gamma=False, **kwargs):
+    """Reference: models/__init__.py:206-340.  Extra kwargs understood here: `noise` ([n_draws,B,C,H,W] injected
+    sequence), `seed`, `sample_offset` (global index of row 0, for sharded runs)."""
+    return _sample(_lib.SAMPLER_DDPM, x_mod, scorenet, cond=cond, just_beta=just_beta, final_only=final_only,
+                   denoise=denoise, subsample_steps=subsample_steps, same_noise=same_noise, noise_val=noise_val,
+                   frac_steps=frac_steps, verbose=verbose, log=log, clip_before=clip_before, t_min=t_min, gamma=gamma,
+                   **kwargs)
+
+
+def ddim_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsample_steps=None, verbose=False,
+                 log=True, clip_before=True, t_min=-1, gamma=False, **kwargs):
+    """Reference: models/__init__.py:102-203."""
+    return _sample(_lib.SAMPLER_DDIM, x_mod, scorenet, cond=cond, final_only=final_only, denoise=denoise,
+                   subsample_steps=subsample_steps, verbose=verbose, log=log, clip_before=clip_before, t_min=t_min,
+                   gamma=gamma, **kwargs)
+
+
+def get_sampler(config):
+    """Reference: runners/ncsn_runner.py:2702-2714 (DDPM / DDIM versions)."""
+    version = getattr(config.model, "version", "DDPM").upper()
+    if version == "DDPM":
+        return partial(ddpm_sampler, config=config)
+    if version == "DDIM":
+        return partial(ddim_sampler, config=config)
+    raise NotImplementedError(f"sampler version {version} is not on the HIP path yet (FPNDM: SURVEY 8f rank 2)")

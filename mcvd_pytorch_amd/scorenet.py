@@ -1,0 +1,262 @@
+"""HipScoreNet: drop-in for the reference's `UNetMore_DDPM` score network on the sampling path.
+
+It offers exactly what the reference's samplers and runner touch:
+  * `scorenet(x, labels, cond=cond)` -> eps, same shape/device as x     (models/__init__.py:284)
+  * attributes `alphas`, `alphas_prev`, `betas` (1-D device tensors), `type`   (:221, :226)
+  * `load_state_dict(sd, strict=False)` with reference key names, `module.`-prefixed or bare
+    (runners/ncsn_runner.py:923-932), `eval()`, `named_parameters()`/`parameters()` so that
+    `EMAHelper.register/ema` (models/ema.py:10-29) work unchanged, `to(device)`.
+All arithmetic happens in libmcvd_hip.so (hand-written gfx950 kernels) through the C ABI; torch tensors are
+storage only.  There is no CPU / eager fallback: a non-GPU device or a missing library raises.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict, namedtuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import desc_from_config
+
+_IncompatibleKeys = namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+_BUFFER_KEYS = ("betas", "alphas", "alphas_prev", "unet.sigmas")
+
+
+def _get_sigmas(config):
+    """Noise schedule (reference: models/__init__.py:16-35), CPU fp32."""
+    T = getattr(config.model, "num_classes")
+    dist = getattr(config.model, "sigma_dist", "linear")
+    if dist == "linear":
+        return torch.linspace(config.model.sigma_begin, config.model.sigma_end, T)
+    if dist == "cosine":
+        t = torch.linspace(T, 0, T + 1) / T
+        s = 0.008
+        f = torch.cos((t + s) / (1 + s) * np.pi / 2) ** 2
+        return f[:-1] / f[-1]
+    raise NotImplementedError("sigma distribution not supported")
+
+
+def _schedule(config):
+    """betas / alphas / alphas_prev as UNetMore_DDPM registers them (ncsnpp_more.py:735-743)."""
+    if getattr(config.model, "sigma_dist", "linear") == "linear":
+        betas = _get_sigmas(config)
+        alphas = torch.cumprod(1 - betas.flip(0), 0).flip(0)
+        alphas_prev = torch.cat([alphas[1:], torch.tensor([1.0]).to(alphas)])
+    else:
+        alphas = _get_sigmas(config)
+        alphas_prev = torch.cat([alphas[1:], torch.tensor([1.0]).to(alphas)])
+        betas = 1 - alphas / alphas_prev
+    return betas.float().contiguous(), alphas.float().contiguous(), alphas_prev.float().contiguous()
+
+
+def _fptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class HipScoreNet:
+    def __init__(self, config, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipScoreNet needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.config = config
+        dev = torch.device(device if device is not None else getattr(config, "device", "cuda:0"))
+        if dev.type != "cuda":
+            raise RuntimeError(f"HipScoreNet cannot run on device {dev}")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.version = getattr(config.model, "version", "DDPM").upper()
+        self.type = getattr(config.model, "type", None) if isinstance(getattr(config.model, "type", None), str) else None
+        self.training = False
+        self._desc = desc_from_config(config)
+        self._ctx = C.c_void_p()
+        self._model = C.c_void_p()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(_lib.lib.mcvd_ctx_create(self.device.index, C.c_void_p(stream), C.byref(self._ctx)), "ctx_create")
+            _lib.check(_lib.lib.mcvd_model_create(self._ctx, C.byref(self._desc), C.byref(self._model)), "model_create")
+        # python-visible parameters (torch storage; uploaded to the library's blob by sync_parameters)
+        self._params = OrderedDict()
+        n = _lib.lib.mcvd_model_num_params(self._model)
+        name, shape, ndim, off = C.c_char_p(), (C.c_int64 * 4)(), C.c_int(), C.c_int64()
+        for i in range(n):
+            _lib.check(_lib.lib.mcvd_model_param_info(self._model, i, C.byref(name), shape, C.byref(ndim), C.byref(off)))
+            shp = tuple(shape[k] for k in range(ndim.value))
+            self._params[name.value.decode()] = torch.nn.Parameter(
+                torch.zeros(shp, dtype=torch.float32, device=self.device), requires_grad=False)
+        self._loaded = False
+        self._dirty = True
+        # schedule buffers + sinusoid table, computed exactly like the reference and handed to the library
+        betas, alphas, alphas_prev = _schedule(config)
+        self._set_schedule(betas, alphas, alphas_prev)
+        half = self._desc.ngf // 2
+        emb = math.log(10000) / (half - 1)                                   # layers.py:505-510
+        freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -emb).contiguous()
+        _lib.check(_lib.lib.mcvd_model_set_temb_freqs(self._model, _fptr(freqs), half), "set_temb_freqs")
+
+    # ---------------------------------------------------------------- nn.Module-ish surface
+    def _set_schedule(self, betas, alphas, alphas_prev):
+        T = self._desc.num_classes
+        b, a, ap = (t.detach().float().cpu().contiguous() for t in (betas, alphas, alphas_prev))
+        assert b.numel() == T and a.numel() == T and ap.numel() == T
+        _lib.check(_lib.lib.mcvd_model_set_schedule(self._model, _fptr(b), _fptr(a), _fptr(ap), T), "set_schedule")
+        self.betas, self.alphas, self.alphas_prev = b.to(self.device), a.to(self.device), ap.to(self.device)
+
+    def named_parameters(self, prefix="", recurse=True):
+        for k, v in self._params.items():
+            yield (prefix + k, v)
+
+    def parameters(self, recurse=True):
+        return iter(self._params.values())
+
+    def state_dict(self):
+        sd = OrderedDict((k, v.data) for k, v in self._params.items())
+        sd["betas"], sd["alphas"], sd["alphas_prev"] = self.betas, self.alphas, self.alphas_prev
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Reference key names; a leading 'module.' (DataParallel) is ignored."""
+        seen = set()
+        unexpected = []
+        sched = {}
+        for k, v in state_dict.items():
+            key = k[7:] if k.startswith("module.") else k
+            if key in self._params:
+                p = self._params[key]
+                if tuple(v.shape) != tuple(p.shape):
+                    raise RuntimeError(f"size mismatch for {key}: {tuple(v.shape)} vs {tuple(p.shape)}")
+                p.data.copy_(v.detach().to(dtype=torch.float32))
+                seen.add(key)
+            elif key in _BUFFER_KEYS:
+                sched[key] = v
+            else:
+                unexpected.append(k)
+        if all(k in sched for k in ("betas", "alphas", "alphas_prev")):
+            self._set_schedule(sched["betas"], sched["alphas"], sched["alphas_prev"])
+        missing = [k for k in self._params if k not in seen]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+        if not missing:
+            self._loaded = True
+        self._dirty = True
+        return _IncompatibleKeys(missing, unexpected)
+
+    def mark_dirty(self):
+        """Call after modifying parameter tensors in place (EMAHelper.ema does this through .data.copy_)."""
+        self._dirty = True
+
+    def sync_parameters(self, force=False):
+        """Upload the python-visible parameters into the library blob and repack (~1 ms).  The samplers call
+        this (forced) at the start of every sampling call, because in-place edits through `.data` cannot be observed."""
+        if not (self._dirty or force):
+            return
+        if not self._loaded:
+            raise RuntimeError("HipScoreNet: parameters were never loaded (load_state_dict first)")
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            shape = (C.c_int64 * 4)()
+            for k, p in self._params.items():
+                for i, s in enumerate(p.shape):
+                    shape[i] = s
+                _lib.check(_lib.lib.mcvd_model_set_param(self._model, k.encode(), _fptr(p.data), shape, p.dim(), 1),
+                           f"set_param({k})")
+            _lib.check(_lib.lib.mcvd_model_finalize(self._model), "finalize")
+        self._dirty = False
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("HipScoreNet is inference-only (dropout must be inactive, SURVEY 9.6-9)")
+        return self
+
+    def to(self, device=None, *args, **kwargs):
+        if device is not None and torch.device(device).type == "cuda":
+            d = torch.device(device)
+            if d.index is None or d.index == self.device.index:
+                return self
+        raise RuntimeError(f"HipScoreNet is bound to {self.device}; cannot move to {device}")
+
+    def set_option(self, key, value):
+        _lib.check(_lib.lib.mcvd_ctx_set_option(self._ctx, key.encode(), int(value)), f"set_option({key})")
+
+    # ---------------------------------------------------------------- blob (one-shot weight broadcast)
+    def blob_numel(self):
+        n = C.c_int64()
+        _lib.check(_lib.lib.mcvd_model_blob_floats(self._model, C.byref(n)))
+        return n.value
+
+    def export_blob(self):
+        self.sync_parameters()
+        t = torch.empty(self.blob_numel(), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib.mcvd_model_export_blob(self._model, _fptr(t)), "export_blob")
+        return t
+
+    def import_blob(self, blob):
+        assert blob.is_cuda and blob.dtype == torch.float32 and blob.numel() == self.blob_numel()
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            _lib.check(_lib.lib.mcvd_model_import_blob(self._model, _fptr(blob.contiguous())), "import_blob")
+            _lib.check(_lib.lib.mcvd_model_finalize(self._model), "finalize")
+            # keep the python-visible copies coherent
+            name, shape, ndim, off = C.c_char_p(), (C.c_int64 * 4)(), C.c_int(), C.c_int64()
+            for i, (k, p) in enumerate(self._params.items()):
+                _lib.check(_lib.lib.mcvd_model_param_info(self._model, i, C.byref(name), shape, C.byref(ndim), C.byref(off)))
+                p.data.copy_(blob[off.value:off.value + p.numel()].view_as(p))
+        self._loaded = True
+        self._dirty = False
+
+    # ---------------------------------------------------------------- forward
+    def _bind_stream(self):
+        _lib.check(_lib.lib.mcvd_ctx_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def _prep(self, t, name):
+        if t is None:
+            return None
+        if not t.is_cuda or t.device != self.device:
+            raise RuntimeError(f"{name} must live on {self.device} (got {t.device})")
+        return t.to(dtype=torch.float32).contiguous()
+
+    @torch.no_grad()
+    def __call__(self, x, y, cond=None, cond_mask=None):
+        """eps = UNet(x, y, cond)   (reference: UNetMore_DDPM.forward, ncsnpp_more.py:753-770)."""
+        self.sync_parameters()
+        x = self._prep(x, "x")
+        cond = self._prep(cond, "cond")
+        d = self._desc
+        B = x.shape[0]
+        if tuple(x.shape[1:]) != (d.channels * d.num_frames, d.image_size, d.image_size):
+            raise RuntimeError(f"x has shape {tuple(x.shape)}")
+        if d.num_frames_cond > 0:
+            if cond is None or tuple(cond.shape) != (B, d.channels * d.num_frames_cond, d.image_size, d.image_size):
+                raise RuntimeError("cond missing or mis-shaped")
+        y = y.to(device=self.device, dtype=torch.int64).contiguous()
+        if y.shape != (B,):
+            raise RuntimeError(f"labels have shape {tuple(y.shape)}")
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            _lib.check(_lib.lib.mcvd_unet_forward(self._model, _fptr(x), C.c_void_p(y.data_ptr()),
+                                                  _fptr(cond) if cond is not None else None, _fptr(out), B), "unet_forward")
+        return out
+
+    forward = __call__
+
+    def num_launches(self, B=1):
+        return _lib.lib.mcvd_model_num_launches(self._model, B)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_model", None):
+                _lib.lib.mcvd_model_destroy(self._model)
+                self._model = None
+            if getattr(self, "_ctx", None):
+                _lib.lib.mcvd_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+
+def get_model(config):
+    """Factory mirroring runners/ncsn_runner.py:180-195 for arch == 'unetmore'."""
+    return HipScoreNet(config, getattr(config, "device", None))

@@ -1,0 +1,284 @@
+"""GPU parity (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs and against the committed reference-generated golden fixtures.
+
+Tolerances (fp32 path): per-op / per-module rtol 1e-4 + atol 2e-5 (scaled by the tensor's magnitude); one UNet
+forward max-abs <= 1e-4 * max|eps|; final sampled frames max-abs <= 1e-4 (data range [-1, 1])."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sampler_ref, synth, unet_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, rtol=1e-4, atol=2e-5, what=""):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(want.abs().max().item(), 1e-6)
+    err = (got - want).abs().max().item()
+    assert err <= atol * max(scale, 1.0) + rtol * scale, f"{what}: max-abs err {err:.3e} (scale {scale:.3e})"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tests.hiputil import Ctx
+    return Ctx()
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # (B, C0, C1, Cout, H, ks, coef, act, res, shape)
+    (2, 10, 0, 96, 64, 3, False, 0, False, -1),     # stem-like, Cin not a multiple of the chunk
+    (2, 5, 5, 96, 64, 3, False, 0, False, 0),       # stem as virtual concat [x, cond]
+    (2, 96, 0, 96, 64, 3, True, 1, True, 0),        # ResBlock Conv_1 @64 with GN+SiLU prologue, residual, 1/sqrt2
+    (2, 96, 0, 96, 64, 3, True, 1, True, 1),
+    (2, 96, 0, 96, 64, 3, True, 1, True, 2),
+    (3, 192, 96, 192, 32, 3, True, 1, False, -1),   # up-path concat input
+    (3, 64, 0, 128, 16, 3, True, 1, False, 0),      # COT=4
+    (3, 64, 0, 128, 16, 3, True, 1, True, 1),
+    (3, 64, 0, 64, 16, 3, True, 1, True, 2),        # COT=2, split-K
+    (5, 40, 24, 96, 8, 3, True, 1, True, 0),        # 8x8: several images per tile, B not a multiple of the tile
+    (5, 40, 24, 96, 8, 3, True, 1, True, 1),
+    (5, 40, 24, 96, 8, 3, True, 1, True, 2),
+    (2, 96, 0, 5, 64, 3, True, 1, False, -1),       # final conv, Cout=5
+    (1, 32, 0, 32, 128, 3, True, 1, True, 0),       # 128x128 rows
+    (1, 32, 0, 32, 128, 3, True, 1, True, 1),
+    (2, 96, 0, 192, 32, 1, False, 0, False, -1),    # 1x1 shortcut
+    (2, 96, 96, 192, 32, 1, False, 0, False, 0),    # 1x1 shortcut over a concat
+    (2, 192, 0, 576, 32, 1, True, 0, False, 1),     # fused q|k|v projection with GN affine prologue (no SiLU)
+    (3, 128, 0, 128, 8, 1, False, 0, True, 2),      # NIN_3 with residual, split-K
+    (3, 72, 0, 64, 16, 1, False, 0, True, -1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "B{}_c{}+{}_o{}_H{}_k{}_s{}".format(c[0], c[1], c[2], c[3], c[4], c[5], c[9]))
+@pytest.mark.parametrize("naive", [0, 1], ids=["mfma", "naive"])
+def test_conv2d(ctx, case, naive):
+    B, C0, C1, Cout, H, ks, use_coef, act, use_res, shape = case
+    g = _g(11)
+    x0 = torch.randn(B, C0, H, H, generator=g)
+    x1 = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    Cin = C0 + C1
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    bias = 0.1 * torch.randn(Cout, generator=g)
+    coef = torch.stack([1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], dim=-1) if use_coef else None
+    res = torch.randn(B, Cout, H, H, generator=g) if use_res else None
+    scale = 0.70710678 if use_res else 1.0
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    if use_coef:
+        xin = xin * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]
+    if act:
+        xin = unet_ref.silu(xin)
+    want = F.conv2d(xin, w, bias, padding=ks // 2)
+    if use_res:
+        want = want + res
+    want = want * scale
+    ctx.opt("naive_conv", naive)
+    ctx.opt("conv_shape", shape)
+    dev = lambda t: t.cuda().contiguous() if t is not None else None
+    got = ctx.conv2d(dev(x0), dev(w), dev(bias), x1=dev(x1), coef=dev(coef), act=act, res=dev(res), scale=scale)
+    ctx.opt("naive_conv", 0)
+    ctx.opt("conv_shape", -1)
+    _close(got, want, what=f"conv {case}")
+
+
+# ------------------------------------------------------------------------------------------------ group norm
+@pytest.mark.parametrize("B,C0,C1,H,mode", [(2, 96, 0, 64, 1), (3, 384, 288, 16, 1), (2, 192, 0, 32, 2), (5, 40, 24, 8, 0),
+                                            (2, 10, 11, 8, 2)])
+def test_gn_coef(ctx, B, C0, C1, H, mode):
+    g = _g(5)
+    C = C0 + C1
+    x0 = torch.randn(B, C0, H, H, generator=g) * 1.7 + 0.4
+    x1 = torch.randn(B, C1, H, H, generator=g) * 0.6 - 0.2 if C1 else None
+    x = torch.cat([x0, x1], 1) if C1 else x0
+    G = unet_ref.gn_groups(C)
+    eps = 1e-5 if mode == 1 else 1e-6
+    xn = unet_ref.group_norm_plain(x, G, eps)
+    emb = torch.randn(B, 3 * C + 7, generator=g) * 0.5
+    wgt, bia = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    if mode == 1:
+        want = xn * (1 + emb[:, 5:5 + C, None, None]) + emb[:, 5 + C:5 + 2 * C, None, None]
+        coef = ctx.gn_coef(x0.cuda(), G, eps, 1, x1=x1.cuda() if C1 else None, p0=emb.cuda(), emb_stride=emb.shape[1], emb_off=5)
+    elif mode == 2:
+        want = xn * wgt[None, :, None, None] + bia[None, :, None, None]
+        coef = ctx.gn_coef(x0.cuda(), G, eps, 2, x1=x1.cuda() if C1 else None, p0=wgt.cuda(), p1=bia.cuda())
+    else:
+        want = xn
+        coef = ctx.gn_coef(x0.cuda(), G, eps, 0, x1=x1.cuda() if C1 else None)
+    coef = coef.cpu()
+    got = x * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]
+    _close(got, want, what="gn_coef")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,C,heads,H", [(2, 64, 2, 8), (2, 192, 2, 32), (3, 288, 3, 16), (2, 384, 4, 8), (2, 256, 2, 16),
+                                         (1, 64, 1, 16)])
+@pytest.mark.parametrize("naive", [0, 1], ids=["mfma", "naive"])
+def test_attention(ctx, B, C, heads, H, naive):
+    g = _g(9)
+    S = H * H
+    qkv = torch.randn(B, 3 * C, S, generator=g)
+    qkv[:, :C] *= 1.5           # make the softmax peaky enough to exercise the online rescale
+    D = C // heads
+    q, k, v = (qkv[:, i * C:(i + 1) * C].reshape(B * heads, D, S) for i in range(3))
+    w = torch.softmax(torch.matmul(q.transpose(1, 2), k) * (int(D) ** (-0.5)), dim=-1)
+    want = torch.matmul(v, w.transpose(1, 2)).reshape(B, C, S)
+    ctx.opt("naive_attn", naive)
+    got = ctx.attention(qkv.cuda(), heads)
+    ctx.opt("naive_attn", 0)
+    _close(got, want, what="attention")
+
+
+# ------------------------------------------------------------------------------------------------ FIR / upfirdn2d
+@pytest.mark.parametrize("up", [0, 1])
+@pytest.mark.parametrize("pro", [0, 1])
+def test_fir2(ctx, up, pro):
+    g = _g(4)
+    B, C, H = 3, 12, 16
+    x = torch.randn(B, C, H, H, generator=g)
+    coef = torch.stack([1 + 0.3 * torch.randn(B, C, generator=g), 0.3 * torch.randn(B, C, generator=g)], dim=-1)
+    xin = unet_ref.silu(x * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]) if pro else x
+    want = unet_ref.fir_up2(xin) if up else unet_ref.fir_down2(xin)
+    got = ctx.fir2(x.cuda(), up, coef=coef.cuda() if pro else None, act=pro)
+    _close(got, want, rtol=1e-5, atol=2e-6, what="fir2")
+
+
+def test_upfirdn2d_against_reference_golden(ctx, golden_dir):
+    """The reference's own native op (op/upfirdn2d.py:163-204), fixtures from upfirdn2d_native."""
+    g = torch.load(os.path.join(golden_dir, "fir.pt"), weights_only=False)
+    k = g["kernel"]
+    _close(ctx.upfirdn2d(g["x"].cuda(), k * 4, 2, 1, 2, 1), g["up"], rtol=1e-5, atol=2e-6, what="upsample_2d")
+    _close(ctx.upfirdn2d(g["x"].cuda(), k, 1, 2, 1, 1), g["down"], rtol=1e-5, atol=2e-6, what="downsample_2d")
+    a = g["generic_args"]
+    _close(ctx.upfirdn2d(g["x"].cuda(), k * a["gain"], a["up"], a["down"], a["pad0"], a["pad1"]), g["generic"], rtol=1e-5,
+           atol=2e-6, what="upfirdn2d generic")
+    _close(ctx.fir2(g["x"].cuda(), 1), g["up"], rtol=1e-5, atol=2e-6, what="fir2 up vs reference")
+    _close(ctx.fir2(g["x"].cuda(), 0), g["down"], rtol=1e-5, atol=2e-6, what="fir2 down vs reference")
+
+
+def test_philox_stream_is_shard_invariant(ctx):
+    """Rows are keyed by GLOBAL sample index: a shard reproduces the same rows of the full batch."""
+    full = ctx.randn(8, 4096, 1234, 0, 3)
+    part = ctx.randn(3, 4096, 1234, 5, 3)
+    assert torch.equal(full[5:8], part)
+    z = ctx.randn(64, 16384, 7, 0, 0)
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
+    assert not torch.equal(ctx.randn(2, 4096, 1234, 0, 3), ctx.randn(2, 4096, 1234, 0, 4))
+
+
+# ------------------------------------------------------------------------------------------------ whole network
+def _net(name):
+    from mcvd_pytorch_amd.scorenet import HipScoreNet
+    config = synth.make_config(name)
+    config.device = "cuda:0"
+    sd = synth.make_state_dict(config, seed=123)
+    net = HipScoreNet(config)
+    missing = net.load_state_dict({"module." + k: v for k, v in sd.items()}, strict=False)     # DataParallel-style keys
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return config, sd, net.eval()
+
+
+@pytest.mark.parametrize("fx", ["tiny_b3.pt", "smmnist_big5_b2.pt"])
+@pytest.mark.parametrize("naive", [0, 3], ids=["mfma", "naive"])
+def test_forward_vs_reference_golden(golden_dir, fx, naive):
+    """One UNet forward vs the REAL reference's output (fixture) and, module by module, vs the oracle."""
+    from tests.hiputil import module_output
+    g = torch.load(os.path.join(golden_dir, fx), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    net.set_option("naive_conv", naive & 1)
+    net.set_option("naive_attn", (naive >> 1) & 1)
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    t = g["fwd_t"]
+    eps = net(x.cuda(), t.cuda(), cond=cond.cuda())
+    torch.cuda.synchronize()
+    taps = {}
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t, cond, taps=taps)
+    bad = []
+    for i in sorted(taps):
+        if i == 0:
+            continue
+        want = unet_ref.silu(taps[1]) if i == 1 else taps[i]
+        if i == len(taps) - 1:
+            got = eps
+        else:
+            try:
+                got = module_output(net, i, g["batch"])
+            except RuntimeError:
+                continue            # module without a workspace output (final norm is fused into the last conv)
+        sc = max(want.abs().max().item(), 1e-6)
+        err = (got.cpu() - want).abs().max().item()
+        if err > 2e-5 + 1e-4 * sc:
+            bad.append((i, err, sc))
+    assert not bad, f"modules off (index, max-abs err, scale): {bad[:8]}"
+    refg = g["fwd_eps"]
+    assert (eps.cpu() - refg).abs().max().item() <= 1e-4 * refg.abs().max().item()
+    assert (eps.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("fx,key,kind,sub,extra", [
+    ("tiny_b3.pt", "ddpm_10", "ddpm", 10, {}),
+    ("tiny_b3.pt", "ddim_10", "ddim", 10, {}),
+    ("tiny_b3.pt", "ddpm_10_t_min0.35", "ddpm", 10, dict(t_min=0.35)),
+    ("smmnist_big5_b2.pt", "ddpm_100", "ddpm", 100, {}),          # BASELINE config 1: 100 steps + denoise
+])
+@pytest.mark.parametrize("path", ["device_loop", "host_loop"])
+def test_sampler_vs_reference_golden(golden_dir, fx, key, kind, sub, extra, path):
+    """Full sampler with the injected noise sequence vs the reference sampler's output (fixture)."""
+    from mcvd_pytorch_amd.samplers import ddim_sampler, ddpm_sampler
+    g = torch.load(os.path.join(golden_dir, fx), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    noise = synth.make_noise(config, g["batch"], sub + 1, seed=2)
+    sampler = ddpm_sampler if kind == "ddpm" else ddim_sampler
+    kw = dict(final_only=True) if path == "device_loop" else dict(final_only=False)
+    out = sampler(x.cuda(), net, cond=cond.cuda(), denoise=True, subsample_steps=sub, clip_before=True, verbose=False,
+                  log=False, noise=noise.cuda(), cond_mask=None, n_steps_each=0, step_lr=0.0, config=config, **kw, **extra)
+    ref = g["sampler_" + key]["result"]
+    if path == "host_loop":
+        assert out.device.type == "cpu" and out.shape[0] > 1        # reference returns the stacked CPU images (:340)
+        out = out[-1:].clone()
+    else:
+        assert out.is_cuda and out.shape[0] == 1
+    assert out.shape == ref.shape
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 1e-4, f"final frames max-abs err {err:.3e}"
+
+
+def test_config2_shapes_mfma_vs_naive_and_properties():
+    """BASELINE config 2 width (ngf=96) at a batch the oracle would take minutes for: MFMA path vs the simple HIP
+    kernels (same inputs), plus size-independent properties: per-sample independence (row permutation equivariance)
+    and shard invariance of the on-device noise stream in a full sampler call."""
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    config, sd, net = _net("smmnist_big5_ngf96")
+    B = 6
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = torch.tensor([990, 500, 10, 0, 730, 250])
+    xc, cc, tc = x.cuda(), cond.cuda(), t.cuda()
+    eps = net(xc, tc, cond=cc)
+    net.set_option("naive_conv", 1)
+    net.set_option("naive_attn", 1)
+    eps_naive = net(xc, tc, cond=cc)
+    net.set_option("naive_conv", 0)
+    net.set_option("naive_attn", 0)
+    assert (eps - eps_naive).abs().max().item() <= 1e-4 * eps_naive.abs().max().item()
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x[:2], t[:2], cond[:2])
+    assert (eps[:2].cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    perm = torch.tensor([3, 0, 5, 1, 4, 2]).cuda()
+    eps_p = net(xc[perm].contiguous(), tc[perm].contiguous(), cond=cc[perm].contiguous())
+    assert (eps_p - eps[perm]).abs().max().item() <= 1e-5 * eps.abs().max().item()
+    # sharded == unsharded with the Philox stream keyed by global sample index
+    full = ddpm_sampler(xc, net, cond=cc, final_only=True, subsample_steps=5, seed=77)
+    part = ddpm_sampler(xc[4:].contiguous(), net, cond=cc[4:].contiguous(), final_only=True, subsample_steps=5, seed=77,
+                        sample_offset=4)
+    assert (full[0, 4:] - part[0]).abs().max().item() <= 2e-5
+    assert full.abs().max().item() < 4.0
