@@ -57,7 +57,9 @@ def cpu_baseline(config, state_dict, subsample, budget_s=20.0):
     extrapolated linearly to the 101 forwards of a full call.  kind="port": the Python reference cannot travel."""
     from oracle import sampler_ref, unet_ref
     from mcvd_pytorch_amd import synthetic
-    cores = os.cpu_count() or 1
+    # oneDNN/MKL stop scaling (and collapse through oversubscription) far below the 256 hardware threads of the GPU
+    # box: 16 threads is what the survey container's 8-thread figure extrapolates to sensibly; `cores` reports it.
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     B = 4
     net = unet_ref.OracleScoreNet(config, {k: v.float().cpu() for k, v in state_dict.items()})

@@ -125,6 +125,9 @@ int mcvd_model_num_launches(mcvd_model* m, int B);
  * flops and algorithmic bytes.  Call with kinds == NULL to get the op count.  Returns the op count or a negative error. */
 int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, double* flops, double* bytes, int cap);
 
+/* Static description of op i of the plan: info = {kind, reference module index, conv ks, H, Cin, Cout, has_residual, has_prologue}. */
+int mcvd_model_op_info(mcvd_model* m, int i, int info[8]);
+
 /* Debug/test aid: copy the output tensor of reference module `module` (index in all_modules, ncsnpp_more.py:249) from the
  * last forward at batch size B into dst_device ([B, C, H, H], capacity in floats).  The workspace keeps every intermediate of a
  * forward, so this needs no re-execution.  Module 1 returns SiLU(temb) [B, 4*ngf] (C = 4*ngf, H = 0). */

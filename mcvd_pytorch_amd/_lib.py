@@ -1,10 +1,13 @@
 """ctypes binding of libmcvd_hip.so (C ABI: include/mcvd_hip.h).
 
 The product path has NO fallback: if the shared library is missing or fails to load, importing this
-module raises.  Build it with `python -m mcvd_pytorch_amd.csrc.build` (or `__graft_entry__.build()`).
+module raises.  Build it with `python mcvd_pytorch_amd/csrc/build.py` (or `__graft_entry__.build()`).
 """
 import ctypes as C
 import os
+
+import torch  # noqa: F401  -- MUST precede the CDLL: libmcvd_hip.so then binds to the HIP runtime torch already loaded
+#                              (two libamdhip64 copies in one process do not both see the device)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmcvd_hip.so")
@@ -47,6 +50,7 @@ _PROTOS = {
     "mcvd_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     "mcvd_model_num_launches": (_i, [_vp, _i]),
     "mcvd_model_profile_read": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "mcvd_model_op_info": (_i, [_vp, _i, C.POINTER(_i)]),
     "mcvd_model_module_output": (_i, [_vp, _i, _i, _vp, _i64, C.POINTER(_i), C.POINTER(_i)]),
     "mcvd_sampler_run": (_i, [_vp, _i, _vp, _vp, _vp, _u64, _u64, _i, _i, _f, _i]),
     "mcvd_sampler_update": (_i, [_vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _i64]),
@@ -64,7 +68,7 @@ EXPORTS = tuple(_PROTOS.keys())
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m mcvd_pytorch_amd.csrc.build` "
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python mcvd_pytorch_amd/csrc/build.py` "
             "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _PROTOS.items():

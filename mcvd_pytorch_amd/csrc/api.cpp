@@ -324,6 +324,16 @@ int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, doub
     return n;
 }
 
+// info: kind, module, ks, H, Cin, Cout, has_res, has_coef
+int mcvd_model_op_info(mcvd_model* m, int i, int info[8]) {
+    MCVD_REQUIRE(m && info && i >= 0 && i < (int)m->ops.size(), "op_info: index %d", i);
+    const Op& op = m->ops[i];
+    info[0] = (int)op.kind; info[1] = op.module; info[2] = op.ks; info[3] = op.H;
+    info[4] = op.src0.C + (op.src1.kind == REF_NONE ? 0 : op.src1.C); info[5] = op.Cout;
+    info[6] = op.res.kind != REF_NONE; info[7] = op.coef.kind != REF_NONE;
+    return 0;
+}
+
 int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst, int64_t capacity, int* C, int* H) {
     MCVD_REQUIRE(m && dst && B > 0 && B <= m->arena_B, "module_output: run a forward at batch >= B first");
     const Op* last = nullptr;

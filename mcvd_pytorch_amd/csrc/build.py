@@ -1,7 +1,7 @@
 """Build libmcvd_hip.so (gfx950 only) with hipcc: one object per translation unit, compiled in parallel,
 linked into mcvd_pytorch_amd/libmcvd_hip.so (in-tree, so it travels with the repo snapshot).
 
-    python -m mcvd_pytorch_amd.csrc.build [--force] [-j N]
+    python mcvd_pytorch_amd/csrc/build.py [--force] [-j N]
 """
 import argparse
 import concurrent.futures as cf

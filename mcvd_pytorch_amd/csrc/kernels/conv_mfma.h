@@ -52,7 +52,7 @@ struct ConvCfg {
 };
 
 template <int KS, int CK, int COT, int PXT, bool SPLIT>
-__global__ __launch_bounds__(256, (COT * PXT >= 6) ? 1 : 2) void conv_mfma_kernel(ConvArgs a, ConvGeom g) {
+__global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT)) ? 1 : 2) void conv_mfma_kernel(ConvArgs a, ConvGeom g) {
     using Cfg = ConvCfg<KS, CK, COT, PXT, SPLIT>;
     constexpr int KK = Cfg::KK, HALO = Cfg::HALO, BCO = Cfg::BCO, MAXA = Cfg::MAXA, MAXW = Cfg::MAXW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -175,13 +175,67 @@ __global__ __launch_bounds__(256, (COT * PXT >= 6) ? 1 : 2) void conv_mfma_kerne
     }
     const int woff = half * KK * BCO + l31;
 
+    // Output coordinates of this lane's accumulator columns: 32-bit per-lane element offsets (pixel + the half-wave's
+    // 4-channel shift); the per-register channel offset is wave-uniform and lives in SGPRs (saddr-form global ops).
+    unsigned voff[PXT];
+    bool pvalid[PXT];
+#pragma unroll
+    for (int pt = 0; pt < PXT; ++pt) {
+        const int m = wpx0 + pt * 32 + l31;
+        const int rowt = m / W;
+        const int c = m - rowt * W;
+        const int img = rowt / g.rpi;
+        const int r = rowt - img * g.rpi;
+        const int b = b0 + img;
+        pvalid[pt] = b < a.B;
+        voff[pt] = (unsigned)((long)b * a.Cout * HW + (long)(y0 + r) * W + c + (long)4 * half * HW);
+    }
+
+    // Accumulators start at bias (+ residual): the residual/bias loads overlap the first staging loads instead of
+    // sitting, latency-exposed, in the epilogue.  All loads are UNCONDITIONAL (safe addresses + select): a load under a
+    // per-lane predicate makes hipcc branch around it and wait vmcnt(0) per element -- 96 serialised round trips.
+    // a.bias is zero-padded to CoutP.  (SPLIT keeps bias/residual for the reducer's epilogue: small layers, and the
+    // up-front loads would cost the split kernel its second wave per SIMD.)
+    const bool full_tile = co0 + BCO <= a.Cout;      // wave-uniform
+    unsigned roff[PXT];                              // residual offsets, clamped to a valid element for dead lanes
+#pragma unroll
+    for (int pt = 0; pt < PXT; ++pt) roff[pt] = pvalid[pt] ? voff[pt] : (unsigned)(4 * half * HW);
     f32x16 acc[COT][PXT];
 #pragma unroll
     for (int ct = 0; ct < COT; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < PXT; ++pt)
+        for (int rg = 0; rg < 16; ++rg) {
+            const int cos = co0 + ct * 32 + (rg & 3) + 8 * (rg >> 2);          // wave-uniform part of the channel
+            const float bv = SPLIT ? 0.0f : a.bias[cos + 4 * half];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.0f;
+            for (int pt = 0; pt < PXT; ++pt) acc[ct][pt][rg] = bv;
+        }
+    if (!SPLIT && a.res) {
+        if (full_tile) {
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const float* rb = a.res + (long)(co0 + ct * 32 + (rg & 3) + 8 * (rg >> 2)) * HW;
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt) {
+                        const float r = rb[roff[pt]];
+                        acc[ct][pt][rg] += pvalid[pt] ? r : 0.0f;
+                    }
+                }
+        } else {      // ragged cout tile (never on the UNet's residual convs): predicated loads
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int cos = co0 + ct * 32 + (rg & 3) + 8 * (rg >> 2);
+                    const float* rb = a.res + (long)cos * HW;
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt)
+                        if (cos + 4 * half < a.Cout && pvalid[pt]) acc[ct][pt][rg] += rb[voff[pt]];
+                }
+        }
+    }
 
     const int nchunks = a.CinP / CK;
     MCVD_LOAD_CHUNK(0);
@@ -219,13 +273,31 @@ __global__ __launch_bounds__(256, (COT * PXT >= 6) ? 1 : 2) void conv_mfma_kerne
     }
 
     // ---------------- split-K reduction across the 4 waves (through LDS) ----------------
+    // Wave 0 is the reducer; it also adds bias + residual here, one 32x32 tile per round, so only 16 (unconditional)
+    // residual loads are in flight at a time and they overlap the other waves' LDS writes.
     if (SPLIT) {
         float* red = smem;      // 3 * 1024 floats, LDS is free now (last barrier above passed)
 #pragma unroll
         for (int ct = 0; ct < COT; ++ct)
 #pragma unroll
             for (int pt = 0; pt < PXT; ++pt) {
-                if (wave > 0) {
+                float rr[16];
+                if (wave == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cos = co0 + ct * 32 + (r & 3) + 8 * (r >> 2);
+                        float v = a.bias[cos + 4 * half];                         // zero-padded to CoutP
+                        if (a.res) {
+                            if (full_tile) {
+                                const float x = a.res[(long)cos * HW + roff[pt]];
+                                v += pvalid[pt] ? x : 0.0f;
+                            } else if (cos + 4 * half < a.Cout && pvalid[pt]) {
+                                v += a.res[(long)cos * HW + voff[pt]];
+                            }
+                        }
+                        rr[r] = v;
+                    }
+                } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) red[(wave - 1) * 1024 + r * 64 + lane] = acc[ct][pt][r];
                 }
@@ -233,41 +305,24 @@ __global__ __launch_bounds__(256, (COT * PXT >= 6) ? 1 : 2) void conv_mfma_kerne
                 if (wave == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        acc[ct][pt][r] += red[r * 64 + lane] + red[1024 + r * 64 + lane] + red[2048 + r * 64 + lane];
+                        acc[ct][pt][r] += (red[r * 64 + lane] + red[1024 + r * 64 + lane]) + (red[2048 + r * 64 + lane] + rr[r]);
                 }
                 __syncthreads();
             }
         if (wave != 0) return;
     }
 
-    // ---------------- epilogue: bias, residual, scale, coalesced NCHW stores ----------------
-    long pbase[PXT];
-#pragma unroll
-    for (int pt = 0; pt < PXT; ++pt) {
-        const int m = wpx0 + pt * 32 + l31;
-        const int rowt = m / W;
-        const int c = m - rowt * W;
-        const int img = rowt / g.rpi;
-        const int r = rowt - img * g.rpi;
-        const int b = b0 + img;
-        pbase[pt] = (b < a.B) ? (long)b * a.Cout * HW + (long)(y0 + r) * W + c : -1;
-    }
+    // ---------------- epilogue: scale, coalesced NCHW stores (bias/residual are already in the accumulators)
 #pragma unroll
     for (int ct = 0; ct < COT; ++ct) {
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
-            const int co = co0 + ct * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
-            if (co < a.Cout) {
-                const float bv = a.bias[co];
+            const int cos = co0 + ct * 32 + (rg & 3) + 8 * (rg >> 2);
+            float* yb = a.y + (long)cos * HW;
+            if (cos + 4 * half < a.Cout) {
 #pragma unroll
-                for (int pt = 0; pt < PXT; ++pt) {
-                    if (pbase[pt] >= 0) {
-                        const long idx = pbase[pt] + (long)co * HW;
-                        float v = acc[ct][pt][rg] + bv;
-                        if (a.res) v += a.res[idx];
-                        a.y[idx] = v * a.out_scale;
-                    }
-                }
+                for (int pt = 0; pt < PXT; ++pt)
+                    if (pvalid[pt]) yb[voff[pt]] = acc[ct][pt][rg] * a.out_scale;
             }
         }
     }
@@ -296,6 +351,7 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     g.n_ptiles = (int)((rows + g.RT - 1) / g.RT);
     const int countA = CK * g.nimg * (g.rpi + 2 * Cfg::HALO) * (a.W / 4);
     MCVD_REQUIRE(countA <= Cfg::MAXA * 256, "conv: staging slots exceeded (%d > %d)", countA, Cfg::MAXA * 256);
+    MCVD_REQUIRE((double)a.B * a.Cout * a.H * a.W < 4.0e9, "conv: output tensor exceeds 32-bit element offsets");
     MCVD_REQUIRE(a.CinP % CK == 0 && a.CoutP % Cfg::BCO == 0, "conv: packed dims (%d,%d) vs chunk %d tile %d",
                  a.CinP, a.CoutP, CK, Cfg::BCO);
     size_t lds = (size_t)(CK * g.PS + CK * Cfg::KK * Cfg::BCO) * sizeof(float);

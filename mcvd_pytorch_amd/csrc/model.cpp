@@ -282,10 +282,10 @@ int mcvd_model::build_plan() {
     add_param("unet.all_modules.1.weight", {T, T});
     add_param("unet.all_modules.1.bias", {T});
     Op temb{};
-    temb.kind = OP_TEMB; temb.module = 0;
+    temb.kind = OP_TEMB; temb.module = 1;      // output = SiLU(module 1's output), what every Dense_0 consumes
     ops.push_back(temb);
     Op dense_op{};
-    dense_op.kind = OP_DENSE; dense_op.module = 1;
+    dense_op.kind = OP_DENSE; dense_op.module = -1;
     ops.push_back(dense_op);
 
     auto in_attn = [&](int res) {

@@ -386,7 +386,7 @@ def unet_forward(sd, config, x, t, cond=None, taps=None):
 
     if cond is not None and not c.spade:
         x = torch.cat([x, cond], dim=1)                           # :257
-    temb = timestep_embedding(t, c.ngf)                           # :273
+    temb = timestep_embedding(t, c.ngf).to(x.dtype)               # :273 (fp32 there; cast only matters for fp64 noise-floor runs)
     temb = tap(0, temb @ sd[P + "0.weight"].t() + sd[P + "0.bias"])
     temb = tap(1, silu(temb) @ sd[P + "1.weight"].t() + sd[P + "1.bias"])   # :278-280
     temb_act = silu(temb)                                         # act_emb(emb), layerspp.py:521
@@ -429,11 +429,12 @@ class OracleScoreNet:
 
     type = None
 
-    def __init__(self, config, sd):
+    def __init__(self, config, sd, dtype=torch.float32):
         self.config = config
         self.c = hot_cfg(config)
-        self.sd = sd
-        self.betas, self.alphas, self.alphas_prev = make_schedule(self.c)
+        self.sd = {k: v.to(dtype) for k, v in sd.items()}
+        # dtype=float64: same fp32-rounded tables and weights, all arithmetic in double (noise-floor measurements)
+        self.betas, self.alphas, self.alphas_prev = (t.to(dtype) for t in make_schedule(self.c))
 
     @torch.no_grad()
     def __call__(self, x, y, cond=None, cond_mask=None):

@@ -53,6 +53,27 @@ def conv_emulate(x0, x1, wp, bias, coef, act, res, scale, Cout, CoutP, CinP, ks,
             countA = CK * per_cin
             assert countA <= MAXA * 256
             acc = np.zeros((4, COT, PXT, 16, 64))
+            for wave in range(4):            # accumulators start at bias (+ residual); SPLIT adds them in the epilogue
+                if SPLIT:
+                    continue
+                wpx0 = 0 if SPLIT else wave * PXT * 32
+                for lane in range(64):
+                    l31, half = lane & 31, lane >> 5
+                    for pt in range(PXT):
+                        m = wpx0 + pt * 32 + l31
+                        rowt = m // W
+                        c = m - rowt * W
+                        img = rowt // rpi
+                        r = rowt - img * rpi
+                        b = b0 + img
+                        for ct in range(COT):
+                            for rg in range(16):
+                                co = co0 + ct * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half
+                                if co < Cout:
+                                    v = bias[co]
+                                    if res is not None and b < B:
+                                        v += res[b, co, y0 + r, c]
+                                    acc[wave, ct, pt, rg, lane] = v
             for ch in range(CinP // CK):
                 cbase = ch * CK
                 for tid in range(256):
@@ -129,9 +150,9 @@ def conv_emulate(x0, x1, wp, bias, coef, act, res, scale, Cout, CoutP, CinP, ks,
                             for rg in range(16):
                                 co = co0 + ct * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half
                                 if co < Cout:
-                                    v = acc[wave, ct, pt, rg, lane] + bias[co]
-                                    if res is not None:
-                                        v += res[b, co, y0 + r, c]
+                                    v = acc[wave, ct, pt, rg, lane]
+                                    if SPLIT:
+                                        v += bias[co] + (res[b, co, y0 + r, c] if res is not None else 0.0)
                                     y[b, co, y0 + r, c] = v * scale
     return y
 

@@ -8,20 +8,20 @@ rocm-smi --showproductname > gpurun_out/rocm_smi.log 2>&1
 nproc > gpurun_out/nproc.log; lscpu | head -20 >> gpurun_out/nproc.log
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
 echo "build rc=$?" >> gpurun_out/build.log
-timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
-echo "smoke rc=$?" >> gpurun_out/smoke.log
-tail -3 gpurun_out/smoke.log
 if [ "$MODE" != "prof" ]; then
+  timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
+  echo "smoke rc=$?" >> gpurun_out/smoke.log
+  tail -3 gpurun_out/smoke.log
   timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
   tail -40 gpurun_out/pytest_gpu.log
 fi
-if [ "$MODE" != "quick" ]; then
+if [ "$MODE" != "quick" ] && [ "$MODE" != "prof" ]; then
   timeout 900 python bench.py --steps 1 --warmup 1 > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench rc=$?" >> gpurun_out/bench.err
   cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
 fi
 if [ "$MODE" = "prof" ]; then
-  cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof_bench.err
+  cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof_bench.err
   cd $GRAFT_REPO_ROOT; ls -R gpurun_out/prof | head -20
 fi

@@ -1,0 +1,155 @@
+"""GPU diagnostics (writes gpurun_out/diag_*.txt): precision vs fp32/fp64 oracle, per-op timings, conv tile sweep.
+    python tools/gpu_diag.py [precision] [ops] [sweep]
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+torch.set_num_threads(min(os.cpu_count() or 1, 16))
+
+from mcvd_pytorch_amd import HipScoreNet, _lib, ddim_sampler, ddpm_sampler, synthetic  # noqa: E402
+from oracle import sampler_ref, synth, unet_ref  # noqa: E402
+
+OUT = os.path.join(ROOT, "gpurun_out")
+os.makedirs(OUT, exist_ok=True)
+
+
+def mk(name):
+    config = synth.make_config(name)
+    config.device = "cuda:0"
+    sd = synth.make_state_dict(config, seed=123)
+    net = HipScoreNet(config)
+    net.load_state_dict(sd, strict=True)
+    return config, sd, net
+
+
+def precision(f):
+    from tests.hiputil import module_output
+    for name, B, sub in (("tiny", 3, 10), ("smmnist_big5", 2, 100)):
+        config, sd, net = mk(name)
+        x, cond = synth.make_inputs(config, B, seed=0)
+        t = torch.tensor([(37 * (b + 1)) % 1000 for b in range(B)]).long()
+        taps32, taps64 = {}, {}
+        with torch.no_grad():
+            r32 = unet_ref.unet_forward(sd, config, x, t, cond, taps=taps32)
+            sd64 = {k: v.double() for k, v in sd.items()}
+            r64 = unet_ref.unet_forward(sd64, config, x.double(), t, cond.double(), taps=taps64)
+        for naive in (0, 1):
+            net.set_option("naive_conv", naive)
+            net.set_option("naive_attn", naive)
+            eps = net(x.cuda(), t.cuda(), cond=cond.cuda()).cpu()
+            f.write(f"[{name} B={B} naive={naive}] forward: |eps|max {r64.abs().max():.3f}  hip-ref32 {(eps - r32).abs().max():.3e}  "
+                    f"hip-ref64 {(eps.double() - r64).abs().max():.3e}  ref32-ref64 {(r32.double() - r64).abs().max():.3e}\n")
+            rows = []
+            for i in sorted(taps64):
+                if i in (0,):
+                    continue
+                try:
+                    got = eps if i == len(taps64) - 1 else module_output(net, i, B).cpu()
+                except RuntimeError:
+                    continue
+                w64 = unet_ref.silu(taps64[1]) if i == 1 else taps64[i]
+                w32 = unet_ref.silu(taps32[1]) if i == 1 else taps32[i]
+                sc = w64.abs().max().item()
+                rows.append((i, (got.double() - w64).abs().max().item() / sc, (w32.double() - w64).abs().max().item() / sc))
+            f.write("   per-module relative max err (module: hip-vs-64 | ref32-vs-64): " +
+                    "  ".join(f"{i}:{a:.1e}|{b:.1e}" for i, a, b in rows) + "\n")
+        net.set_option("naive_conv", 0)
+        net.set_option("naive_attn", 0)
+        noise = synth.make_noise(config, B, sub + 1, seed=2)
+        for kind, smp in (("ddpm", ddpm_sampler), ("ddim", ddim_sampler)):
+            if name != "tiny" and kind == "ddim":
+                continue
+            outs = {}
+            for dt in (torch.float32, torch.float64):
+                k = [0]
+
+                def fn(i, like):
+                    k[0] += 1
+                    return noise[k[0] - 1].to(like.dtype)
+                o = sampler_ref.sample(x.to(dt), unet_ref.OracleScoreNet(config, sd, dtype=dt), cond=cond.to(dt), kind=kind,
+                                       final_only=True, denoise=True, subsample_steps=sub, noise_fn=fn)
+                outs[dt] = o
+            got = smp(x.cuda(), net, cond=cond.cuda(), final_only=True, denoise=True, subsample_steps=sub, noise=noise.cuda(),
+                      verbose=False, log=False).cpu()
+            f.write(f"[{name} B={B}] {kind}-{sub}: hip-ref32 {(got - outs[torch.float32]).abs().max():.3e}  "
+                    f"hip-ref64 {(got.double() - outs[torch.float64]).abs().max():.3e}  "
+                    f"ref32-ref64 {(outs[torch.float32].double() - outs[torch.float64]).abs().max():.3e}\n")
+        f.flush()
+
+
+def ops(f, cfgname="smmnist_big5_ngf96", B=64):
+    import bench
+    config = bench.make_config(cfgname)
+    config.device = "cuda:0"
+    net = HipScoreNet(config)
+    net.load_state_dict(synthetic.random_state_dict(net), strict=True)
+    net.set_option("profile", 1)
+    x, cond = synthetic.random_inputs(config, 0, B)
+    x, cond = x.cuda(), cond.cuda()
+    for _ in range(2):
+        ddpm_sampler(x, net, cond=cond, final_only=True, subsample_steps=2, seed=1)
+    n = _lib.lib.mcvd_model_profile_read(net._model, None, None, None, None, None, 0)
+    kinds, kss = (C.c_int * n)(), (C.c_int * n)()
+    ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    assert _lib.lib.mcvd_model_profile_read(net._model, kinds, kss, ms, fl, by, n) == n
+    names = {0: "temb", 1: "dense", 2: "gn", 3: "conv", 4: "fir", 5: "attn"}
+    info = (C.c_int * 8)()
+    f.write(f"# {cfgname} B={B}: op, module, kind, ks, H, Cin, Cout, res, pro, us, TFLOP/s, GB/s(alg)\n")
+    tot = 0.0
+    for i in range(n):
+        _lib.lib.mcvd_model_op_info(net._model, i, info)
+        tot += ms[i]
+        f.write(f"{i:4d} m{info[1]:3d} {names[info[0]]:5s} k{info[2]} H{info[3]:4d} ci{info[4]:5d} co{info[5]:5d} r{info[6]} p{info[7]} "
+                f"{ms[i] * 1e3:9.1f} us {fl[i] / max(ms[i], 1e-9) / 1e9:8.2f} TF {by[i] / max(ms[i], 1e-9) / 1e6:9.1f} GB/s\n")
+    f.write(f"# total {tot:.3f} ms\n")
+    f.flush()
+
+
+def sweep(f):
+    from tests.hiputil import Ctx
+    ctx = Ctx()
+    B = 64
+    shapes = [(96, 96, 64, 3), (192, 96, 64, 3), (288, 96, 64, 3), (192, 192, 32, 3), (480, 192, 32, 3), (288, 288, 16, 3),
+              (672, 288, 16, 3), (384, 384, 8, 3), (768, 384, 8, 3), (192, 576, 32, 1), (288, 864, 16, 1), (384, 1152, 8, 1),
+              (96, 192, 32, 1), (768, 384, 8, 1)]
+    f.write("# conv tile sweep at B=64: Cin Cout H ks | shape0(256px) shape1(128px) shape2(64px split-K): us, TFLOP/s\n")
+    for cin, cout, H, ks in shapes:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, ks, ks, device="cuda") / (cin * ks * ks) ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda")
+        flops = 2.0 * B * H * H * cout * cin * ks * ks
+        line = f"{cin:4d} {cout:4d} {H:3d} k{ks} |"
+        for shape in (0, 1, 2):
+            ctx.opt("conv_shape", shape)
+            try:
+                for _ in range(2):
+                    ctx.conv2d(x, w, b, coef=coef, act=1)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    ctx.conv2d(x, w, b, coef=coef, act=1)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 5
+                line += f"  {us:8.1f} us {flops / us / 1e6:6.1f} TF |"
+            except RuntimeError as e:
+                line += f"  n/a ({str(e)[-40:]}) |"
+        f.write(line + "\n")
+        f.flush()
+    ctx.opt("conv_shape", -1)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["precision", "ops", "sweep"]
+    for w in what:
+        with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
+            t0 = time.time()
+            {"precision": precision, "ops": ops, "sweep": sweep}[w](f)
+            f.write(f"# done in {time.time() - t0:.1f}s\n")
