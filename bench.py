@@ -178,9 +178,17 @@ def main():
                  for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     c3 = agg["conv3x3"]
     achieved = c3["flops"] / c3["ms"] / 1e9
+    traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/, tools/gpu_check.sh prof)
+    try:
+        tr = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("conv3x3_traffic.json"))
+        if tr:
+            traffic = round(json.load(open(os.path.join(ROOT, "profiles", tr[-1])))["traffic_bytes_per_launch"])
+    except Exception:
+        traffic = None
     roofline = dict(bound="mfma", kernel="conv_mfma_kernel<3x3> (implicit-GEMM, v_mfma_f32_32x32x2_f32)",
                     achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                    frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                    algorithmic_bytes_per_launch=round(c3["bytes"] / c3["launches"]),
                     launches=c3["launches"], avg_launch_us=round(1e3 * c3["ms"] / c3["launches"], 1),
                     flops_per_launch_avg=c3["flops"] / c3["launches"], forward_ms_events=round(fwd_ms, 3),
                     breakdown=breakdown)

@@ -41,6 +41,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     mcvd_ctx* c = new mcvd_ctx();
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
+    if (const char* t = getenv("MCVD_AUTOTUNE")) c->autotune = atoi(t);
     const char* e = getenv("MCVD_NAIVE");
     if (e) {
         const int v = atoi(e);
@@ -71,6 +72,8 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "graph")) ctx->graph = value;
     else if (!strcmp(key, "conv_shape")) ctx->conv_shape = value;
     else if (!strcmp(key, "profile")) ctx->profile = value;
+    else if (!strcmp(key, "conv_wdma")) ctx->conv_wdma = value;
+    else if (!strcmp(key, "autotune")) ctx->autotune = value;
     else {
         set_error("unknown option '%s'", key);
         return MCVD_EINVAL;
@@ -324,13 +327,14 @@ int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, doub
     return n;
 }
 
-// info: kind, module, ks, H, Cin, Cout, has_res, has_coef
+// info: kind, module, ks, H, Cin, Cout, has_res | tuned_shape<<4 | tuned_cot<<8, has_coef
 int mcvd_model_op_info(mcvd_model* m, int i, int info[8]) {
     MCVD_REQUIRE(m && info && i >= 0 && i < (int)m->ops.size(), "op_info: index %d", i);
     const Op& op = m->ops[i];
     info[0] = (int)op.kind; info[1] = op.module; info[2] = op.ks; info[3] = op.H;
     info[4] = op.src0.C + (op.src1.kind == REF_NONE ? 0 : op.src1.C); info[5] = op.Cout;
     info[6] = op.res.kind != REF_NONE; info[7] = op.coef.kind != REF_NONE;
+    if ((size_t)i < m->tuned_shape.size() && m->tuned_shape[i] >= 0) info[6] |= (m->tuned_shape[i] << 4) | (m->tuned_cot[i] << 8) | (1 << 12);
     return 0;
 }
 
@@ -472,6 +476,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.wp = ctx->scratch;
     a.bias = ctx->scratch + wfloats;
     a.shape_hint = ctx->conv_shape;
+    a.wdma = ctx->conv_wdma;
     return ctx->naive_conv ? launch_conv_naive(a, ctx->stream) : launch_conv_mfma(a, ctx->stream);
     API_CATCH
 }

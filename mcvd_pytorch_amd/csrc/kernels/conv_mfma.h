@@ -41,7 +41,7 @@ struct ConvGeom {
 };
 
 template <int KS, int CK, int COT, int PXT, bool SPLIT>
-struct ConvCfg {
+struct ConvCfg {   // tile geometry (independent of how the weights are staged)
     static constexpr int KK = KS * KS;
     static constexpr int HALO = (KS == 3) ? 1 : 0;
     static constexpr int BPX = SPLIT ? PXT * 32 : 4 * PXT * 32;
@@ -51,8 +51,11 @@ struct ConvCfg {
     static constexpr int MAXW = (WCOUNT + 255) / 256;
 };
 
-template <int KS, int CK, int COT, int PXT, bool SPLIT>
-__global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT)) ? 1 : 2) void conv_mfma_kernel(ConvArgs a, ConvGeom g) {
+// WDMA: weight chunks go global -> LDS by LDS-DMA (global_load_lds_dwordx4: the packed weight slab of a chunk is one
+// linear LDS image, wave-uniform base + lane*16) instead of through 28-36 staging VGPRs; that is what lets the 256-pixel
+// x 96-cout tile fit two workgroups per CU, so one block's barrier/staging/epilogue phases hide under the other's MFMAs.
+template <int KS, int CK, int COT, int PXT, bool SPLIT, bool WDMA>
+__global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT && !WDMA)) ? 1 : 2) void conv_mfma_kernel(ConvArgs a, ConvGeom g) {
     using Cfg = ConvCfg<KS, CK, COT, PXT, SPLIT>;
     constexpr int KK = Cfg::KK, HALO = Cfg::HALO, BCO = Cfg::BCO, MAXA = Cfg::MAXA, MAXW = Cfg::MAXW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -133,13 +136,24 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT))
             ra[s] = *reinterpret_cast<const f32x4*>(src);                                                            \
             rc[s] = *reinterpret_cast<const f32x2*>(csrc);                                                           \
         }                                                                                                            \
-        const float* wsrc = a.wp + (long)cbase * KK * a.CoutP;                                                       \
-        _Pragma("unroll") for (int s = 0; s < MAXW; ++s)                                                             \
-            rw[s] = *reinterpret_cast<const f32x4*>(wsrc + (w_goff[s] >= 0 ? w_goff[s] : 0));                        \
+        if (!WDMA) {                                                                                                 \
+            const float* wsrc = a.wp + (long)cbase * KK * a.CoutP;                                                   \
+            _Pragma("unroll") for (int s = 0; s < MAXW; ++s)                                                         \
+                rw[s] = *reinterpret_cast<const f32x4*>(wsrc + (w_goff[s] >= 0 ? w_goff[s] : 0));                    \
+        }                                                                                                            \
     }
 #define MCVD_WRITE_CHUNK(ch)                                                                                         \
     {                                                                                                                \
         const int cbase = (ch) * CK;                                                                                 \
+        if (WDMA) { /* issue the weight DMA first: it flies while the activation patch is transformed and written */ \
+            const float* wsrc = a.wp + (long)cbase * KK * a.CoutP;                                                   \
+            _Pragma("unroll") for (int s = 0; s < MAXW; ++s) {                                                       \
+                if (w_goff[s] >= 0)                                                                                  \
+                    __builtin_amdgcn_global_load_lds(                                                                \
+                        (const __attribute__((address_space(1))) void*)(wsrc + w_goff[s]),                           \
+                        (__attribute__((address_space(3))) void*)(sW + (s * 256 + wave * 64) * 4), 16, 0, 0);        \
+            }                                                                                                        \
+        }                                                                                                            \
         _Pragma("unroll") for (int s = 0; s < MAXA; ++s) {                                                           \
             if (a_cb[s] >= 0) {                                                                                      \
                 f32x4 v = ra[s];                                                                                     \
@@ -156,8 +170,10 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT))
                 *reinterpret_cast<f32x4*>(sA + a_lds[s]) = v;                                                        \
             }                                                                                                        \
         }                                                                                                            \
-        _Pragma("unroll") for (int s = 0; s < MAXW; ++s) {                                                           \
-            if (w_goff[s] >= 0) *reinterpret_cast<f32x4*>(sW + (s * 256 + tid) * 4) = rw[s];                         \
+        if (!WDMA) {                                                                                                 \
+            _Pragma("unroll") for (int s = 0; s < MAXW; ++s) {                                                       \
+                if (w_goff[s] >= 0) *reinterpret_cast<f32x4*>(sW + (s * 256 + tid) * 4) = rw[s];                     \
+            }                                                                                                        \
         }                                                                                                            \
     }
 
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT))
 }
 
 // Host-side geometry + launch for one instantiation.
-template <int KS, int CK, int COT, int PXT, bool SPLIT>
+template <int KS, int CK, int COT, int PXT, bool SPLIT, bool WDMA>
 int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     using Cfg = ConvCfg<KS, CK, COT, PXT, SPLIT>;
     ConvGeom g;
@@ -358,7 +374,7 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     if (SPLIT && lds < 3 * 1024 * sizeof(float)) lds = 3 * 1024 * sizeof(float);
     MCVD_REQUIRE(lds <= 64 * 1024, "conv: LDS %zu > 64KiB", lds);
     dim3 grid(g.n_ptiles, a.CoutP / Cfg::BCO);
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, CK, COT, PXT, SPLIT>), grid, dim3(256), lds, s, a, g);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, CK, COT, PXT, SPLIT, WDMA>), grid, dim3(256), lds, s, a, g);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -366,10 +382,11 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
 // one translation unit per (KS, COT) instantiates the three tile shapes
 template <int KS, int CK, int COT>
 int conv_mfma_dispatch_shape(const ConvArgs& a, int shape, hipStream_t s) {
+    const bool dma = a.wdma != 0;
     switch (shape) {
-        case 0: return conv_mfma_launch<KS, CK, COT, 2, false>(a, s);   // 256-pixel tile
-        case 1: return conv_mfma_launch<KS, CK, COT, 1, false>(a, s);   // 128-pixel tile
-        case 2: return conv_mfma_launch<KS, CK, COT, 2, true>(a, s);    // 64-pixel tile, waves split K
+        case 0: return dma ? conv_mfma_launch<KS, CK, COT, 2, false, true>(a, s) : conv_mfma_launch<KS, CK, COT, 2, false, false>(a, s);   // 256-pixel tile
+        case 1: return dma ? conv_mfma_launch<KS, CK, COT, 1, false, true>(a, s) : conv_mfma_launch<KS, CK, COT, 1, false, false>(a, s);   // 128-pixel tile
+        case 2: return dma ? conv_mfma_launch<KS, CK, COT, 2, true, true>(a, s) : conv_mfma_launch<KS, CK, COT, 2, true, false>(a, s);     // 64-pixel tile, waves split K
     }
     set_error("conv: bad shape id %d", shape);
     return -1;

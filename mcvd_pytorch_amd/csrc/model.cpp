@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <tuple>
 
 namespace mcvd {
 
@@ -487,6 +488,12 @@ int mcvd_model::launch_op(const Op& op, const float* x, const int64_t* lab, cons
             a.ks = op.ks;
             a.cot = op.cot;
             a.shape_hint = ctx->conv_shape;
+            a.wdma = ctx->conv_wdma;
+            const size_t oi = (size_t)(&op - ops.data());
+            if (ctx->conv_shape < 0 && tuned_B == B && oi < tuned_shape.size() && tuned_shape[oi] >= 0) {
+                a.shape_hint = tuned_shape[oi];
+                a.cot = tuned_cot[oi];
+            }
             return ctx->naive_conv ? launch_conv_naive(a, s) : launch_conv_mfma(a, s);
         }
         case OP_FIR:
@@ -502,10 +509,80 @@ int mcvd_model::launch_op(const Op& op, const float* x, const int64_t* lab, cons
     }
 }
 
+// Measurement-driven tile selection: for every distinct conv layer shape, time the candidate (pixel tile, cout tile)
+// pairs with HIP events on the real workspace buffers and keep the fastest.  ~0.2 s once per batch size.
+int mcvd_model::autotune(int B) {
+    hipStream_t s = ctx->stream;
+    tuned_shape.assign(ops.size(), -1);
+    tuned_cot.assign(ops.size(), 0);
+    hipEvent_t e0, e1;
+    MCVD_HIP_CHECK(hipEventCreate(&e0));
+    MCVD_HIP_CHECK(hipEventCreate(&e1));
+    // benign, finite workspace contents for the timing runs
+    MCVD_HIP_CHECK(hipMemsetAsync(arena, 0x3c, (size_t)arena_per_sample * B * sizeof(float), s));
+    struct Key { int ks, H, cin, cout, coef, res; bool operator<(const Key& o) const {
+        return std::tie(ks, H, cin, cout, coef, res) < std::tie(o.ks, o.H, o.cin, o.cout, o.coef, o.res); } };
+    std::map<Key, std::pair<int, int>> best;
+    float* scratch_io = arena;      // stands in for the caller's x / cond / out during tuning
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const Op& op = ops[i];
+        if (op.kind != OP_CONV) continue;
+        const int cin = op.src0.C + (op.src1.kind == REF_NONE ? 0 : op.src1.C);
+        Key k{op.ks, op.H, cin, op.Cout, op.coef.kind != REF_NONE, op.res.kind != REF_NONE};
+        auto it = best.find(k);
+        if (it == best.end()) {
+            ConvArgs a{};
+            a.x0 = resolve(op.src0, scratch_io, scratch_io, scratch_io, B);
+            a.x1 = resolve(op.src1, scratch_io, scratch_io, scratch_io, B);
+            a.C0 = op.src0.C;
+            a.C1 = op.src1.kind == REF_NONE ? 0 : op.src1.C;
+            a.coef = op.coef.kind == REF_NONE ? nullptr : resolve(op.coef, scratch_io, scratch_io, scratch_io, B);
+            a.act = op.act;
+            a.wp = packed + op.wp;
+            a.bias = packed + op.bias;
+            a.res = op.res.kind == REF_NONE ? nullptr : resolve(op.res, scratch_io, scratch_io, scratch_io, B);
+            a.out_scale = op.out_scale;
+            a.y = resolve(op.dst, scratch_io, scratch_io, scratch_io, B);
+            a.B = B; a.Cin = cin; a.CinP = op.CinP; a.Cout = op.Cout; a.CoutP = op.CoutP; a.H = op.H; a.W = op.W; a.ks = op.ks;
+            a.wdma = ctx->conv_wdma;
+            float best_ms = 1e30f;
+            std::pair<int, int> choice{-1, op.cot};
+            const int cots[2] = {op.cot, 1};
+            for (int ci = 0; ci < (op.cot == 1 ? 1 : 2); ++ci) {
+                for (int shape = 0; shape < 3; ++shape) {
+                    a.cot = cots[ci];
+                    a.shape_hint = shape;
+                    const int bpx = shape == 0 ? 256 : shape == 1 ? 128 : 64;
+                    const bool fits = bpx % op.W == 0 && (bpx / op.W <= op.H ? op.H % (bpx / op.W) == 0 : (bpx / op.W) % op.H == 0);
+                    if (!fits) continue;
+                    if (launch_conv_mfma(a, s)) continue;                 // warm-up (and validity check)
+                    MCVD_HIP_CHECK(hipEventRecord(e0, s));
+                    for (int r = 0; r < 3; ++r)
+                        if (int rc = launch_conv_mfma(a, s)) return rc;
+                    MCVD_HIP_CHECK(hipEventRecord(e1, s));
+                    MCVD_HIP_CHECK(hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    MCVD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best_ms) { best_ms = ms; choice = {shape, cots[ci]}; }
+                }
+            }
+            it = best.emplace(k, choice).first;
+        }
+        tuned_shape[i] = it->second.first;
+        tuned_cot[i] = it->second.second;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    tuned_B = B;
+    return 0;
+}
+
 int mcvd_model::forward(const float* x, const int64_t* lab, const float* cond, float* out, int B) {
     MCVD_REQUIRE(finalized, "forward before mcvd_model_finalize");
     MCVD_REQUIRE(B > 0 && x && lab && out, "forward: bad arguments");
     if (int rc = ensure_workspace(B)) return rc;
+    if (ctx->autotune && !ctx->naive_conv && tuned_B != B)
+        if (int rc = autotune(B)) return rc;
     if (ctx->profile && profile_armed) {
         profile_armed = false;
         if (ev.size() != 2 * ops.size()) {

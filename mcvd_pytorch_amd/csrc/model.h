@@ -14,6 +14,8 @@ struct mcvd_ctx {
     int naive_attn = 0;
     int graph = 0;
     int conv_shape = -1;           // -1 auto, 0/1/2 force a conv tile shape (tests)
+    int conv_wdma = 1;             // weight chunks by LDS-DMA (1) or register staging (0)
+    int autotune = 1;              // time the conv tile candidates per distinct layer shape on first use of a batch size
     int profile = 0;               // record HIP events around every op of the first forward of each sampler call
     float* scratch = nullptr;      // small device scratch for stand-alone ops (kernel taps, packed weights)
     size_t scratch_bytes = 0;
@@ -108,6 +110,11 @@ struct mcvd_model {
     float* eps_buf = nullptr;         // [arena_B * C*nf*S*S] (sampler-owned eps)
 
     std::vector<float> betas, alphas, alphas_prev, freqs;
+
+    // conv tile choice per op for the batch size it was tuned at: (shape, cot); filled by autotune()
+    std::vector<int> tuned_shape, tuned_cot;
+    int tuned_B = 0;
+    int autotune(int B);
 
     // per-op HIP event timing (bench.py roofline): events are recorded on the ctx stream around each op of ONE forward
     std::vector<hipEvent_t> ev;

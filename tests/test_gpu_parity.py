@@ -280,9 +280,14 @@ def test_config2_shapes_mfma_vs_naive_and_properties():
     perm = torch.tensor([3, 0, 5, 1, 4, 2]).cuda()
     eps_p = net(xc[perm].contiguous(), tc[perm].contiguous(), cond=cc[perm].contiguous())
     assert (eps_p - eps[perm]).abs().max().item() <= 1e-5 * eps.abs().max().item()
-    # sharded == unsharded with the Philox stream keyed by global sample index
+    # sharded == unsharded with the Philox stream keyed by global sample index.  The tile shape (hence the fp32 summation
+    # order) is normally tuned per batch size; pin it so the shard computes bit-comparable rows.
+    net.set_option("autotune", 0)
+    net.set_option("conv_shape", 1)
     full = ddpm_sampler(xc, net, cond=cc, final_only=True, subsample_steps=5, seed=77)
     part = ddpm_sampler(xc[4:].contiguous(), net, cond=cc[4:].contiguous(), final_only=True, subsample_steps=5, seed=77,
                         sample_offset=4)
+    net.set_option("conv_shape", -1)
+    net.set_option("autotune", 1)
     assert (full[0, 4:] - part[0]).abs().max().item() <= 2e-5
     assert full.abs().max().item() < 4.0

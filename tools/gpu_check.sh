@@ -22,6 +22,14 @@ if [ "$MODE" != "quick" ] && [ "$MODE" != "prof" ]; then
   cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
 fi
 if [ "$MODE" = "prof" ]; then
-  cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof_bench.err
-  cd $GRAFT_REPO_ROOT; ls -R gpurun_out/prof | head -20
+  R=$GRAFT_REPO_ROOT
+  cd /tmp
+  # pass 1: kernel trace + stats of the default bench command (same workload as the bench line)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_bench.err
+  # passes 2,3: HBM-side PMC counters, each in its own run (kernel-trace only), on a shortened sampler (6 forwards)
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.json 2> $R/gpurun_out/pmc_fetch.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline > $R/gpurun_out/pmc_write.json 2> $R/gpurun_out/pmc_write.err
+  cd $R; python tools/summarize_prof.py > gpurun_out/prof_summary.txt 2>&1; head -40 gpurun_out/prof_summary.txt
+  # keep the merged payload small: raw per-dispatch CSVs can be large
+  find gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -size +20M -delete
 fi

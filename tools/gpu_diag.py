@@ -105,7 +105,8 @@ def ops(f, cfgname="smmnist_big5_ngf96", B=64):
     for i in range(n):
         _lib.lib.mcvd_model_op_info(net._model, i, info)
         tot += ms[i]
-        f.write(f"{i:4d} m{info[1]:3d} {names[info[0]]:5s} k{info[2]} H{info[3]:4d} ci{info[4]:5d} co{info[5]:5d} r{info[6]} p{info[7]} "
+        tune = f"s{(info[6] >> 4) & 15}c{(info[6] >> 8) & 15}" if info[6] >> 12 else "    "
+        f.write(f"{i:4d} m{info[1]:3d} {names[info[0]]:5s} k{info[2]} H{info[3]:4d} ci{info[4]:5d} co{info[5]:5d} r{info[6] & 1} p{info[7]} {tune} "
                 f"{ms[i] * 1e3:9.1f} us {fl[i] / max(ms[i], 1e-9) / 1e9:8.2f} TF {by[i] / max(ms[i], 1e-9) / 1e6:9.1f} GB/s\n")
     f.write(f"# total {tot:.3f} ms\n")
     f.flush()
@@ -118,32 +119,38 @@ def sweep(f):
     shapes = [(96, 96, 64, 3), (192, 96, 64, 3), (288, 96, 64, 3), (192, 192, 32, 3), (480, 192, 32, 3), (288, 288, 16, 3),
               (672, 288, 16, 3), (384, 384, 8, 3), (768, 384, 8, 3), (192, 576, 32, 1), (288, 864, 16, 1), (384, 1152, 8, 1),
               (96, 192, 32, 1), (768, 384, 8, 1)]
-    f.write("# conv tile sweep at B=64: Cin Cout H ks | shape0(256px) shape1(128px) shape2(64px split-K): us, TFLOP/s\n")
-    for cin, cout, H, ks in shapes:
+    f.write("# conv tile sweep at B=64: Cin Cout H ks res | shape0(256px) shape1(128px) shape2(64px split-K): us, TFLOP/s ; wdma=0 then wdma=1\n")
+    shapes = [(c, o, h, k, r) for (c, o, h, k) in shapes for r in ((0, 1) if k == 3 and c == o else (0,))]
+    for cin, cout, H, ks, use_res in shapes:
         x = torch.randn(B, cin, H, H, device="cuda")
         w = torch.randn(cout, cin, ks, ks, device="cuda") / (cin * ks * ks) ** 0.5
         b = torch.zeros(cout, device="cuda")
         coef = torch.ones(B, cin, 2, device="cuda")
         flops = 2.0 * B * H * H * cout * cin * ks * ks
-        line = f"{cin:4d} {cout:4d} {H:3d} k{ks} |"
-        for shape in (0, 1, 2):
-            ctx.opt("conv_shape", shape)
-            try:
-                for _ in range(2):
-                    ctx.conv2d(x, w, b, coef=coef, act=1)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(5):
-                    ctx.conv2d(x, w, b, coef=coef, act=1)
-                e1.record()
-                torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / 5
-                line += f"  {us:8.1f} us {flops / us / 1e6:6.1f} TF |"
-            except RuntimeError as e:
-                line += f"  n/a ({str(e)[-40:]}) |"
+        res = torch.randn(B, cout, H, H, device="cuda") if use_res else None
+        line = f"{cin:4d} {cout:4d} {H:3d} k{ks} r{use_res} |"
+        for wdma in (0, 1):
+            ctx.opt("conv_wdma", wdma)
+            for shape in (0, 1, 2):
+                ctx.opt("conv_shape", shape)
+                try:
+                    for _ in range(2):
+                        ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    us = e0.elapsed_time(e1) * 1e3 / 5
+                    line += f" {us:7.1f} us {flops / us / 1e6:6.1f} TF |"
+                except RuntimeError as e:
+                    line += f"  n/a ({str(e)[-40:]}) |"
+            line += "|"
         f.write(line + "\n")
         f.flush()
     ctx.opt("conv_shape", -1)
+    ctx.opt("conv_wdma", 1)
 
 
 if __name__ == "__main__":

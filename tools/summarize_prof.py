@@ -1,0 +1,59 @@
+"""Condense rocprofv3 CSV output (kernel stats + per-dispatch PMC counters) into profiles-ready text."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def short(name):
+    m = re.match(r".*conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>.*", name)
+    if m:
+        ks, ck, cot, pxt, split, dma = m.groups()
+        return f"conv_mfma<{ks}x{ks},CK{ck},co{32 * int(cot)},px{(1 if split == 'true' else 4) * 32 * int(pxt)}{',splitK' if split == 'true' else ''}{',dma' if dma == 'true' else ''}>"
+    m = re.match(r".*mcvd::(\w+)(<[^>]*>)?\(.*", name)
+    if m:
+        return m.group(1) + (m.group(2) or "")
+    return name[:70]
+
+
+def stats():
+    for f in glob.glob(os.path.join(OUT, "prof", "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        print(f"== kernel stats ({os.path.relpath(f, ROOT)}): name, calls, total ms, avg us, % of GPU time")
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        agg = defaultdict(lambda: [0, 0.0])
+        for r in rows:
+            k = short(r["Name"])
+            agg[k][0] += int(r["Calls"])
+            agg[k][1] += float(r["TotalDurationNs"])
+        for k, (c, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            print(f"{k:58s} {c:7d} {ns / 1e6:10.2f} ms {ns / c / 1e3:9.1f} us {100 * ns / tot:6.2f}%")
+        conv3 = [(c, ns) for k, (c, ns) in agg.items() if k.startswith("conv_mfma<3x3")]
+        if conv3:
+            c = sum(x[0] for x in conv3); ns = sum(x[1] for x in conv3)
+            print(f"-- all conv_mfma<3x3,...> instantiations: {c} launches, avg {ns / c / 1e3:.1f} us")
+
+
+def pmc(dirname, counter):
+    for f in glob.glob(os.path.join(OUT, dirname, "**", "*counter_collection.csv"), recursive=True):
+        agg = defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            k = short(r["Kernel_Name"])
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+        print(f"== {counter} per launch ({os.path.relpath(f, ROOT)}; rocprofv3 units: KiB as reported)")
+        for k, (c, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+            print(f"{k:58s} {c:6d} launches  avg {v / c:14.1f}  total {v:16.1f}")
+
+
+if __name__ == "__main__":
+    stats()
+    pmc("pmc_fetch", "FETCH_SIZE")
+    pmc("pmc_write", "WRITE_SIZE")
