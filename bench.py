@@ -43,6 +43,9 @@ def make_config(name):
     elif name == "kth64_big_ngf128":
         data.update(num_frames_cond=10)
         model.update(ngf=128, n_head_channels=128)
+    elif name == "bair_big_spade":
+        data.update(channels=3, num_frames_cond=2)
+        model.update(spade=True, spade_dim=128)
     elif name == "cityscapes_big":
         data.update(image_size=128, channels=3, num_frames_cond=2)
         model.update(ngf=128, n_head_channels=128, ch_mult=[1, 1, 2, 3, 4])
@@ -166,9 +169,11 @@ def main():
     kinds, kss = (C.c_int * n)(), (C.c_int * n)()
     ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
     _lib.check(0 if _lib.lib.mcvd_model_profile_read(net._model, kinds, kss, ms, fl, by, n) == n else -1, "profile_read")
-    names = {0: "temb_mlp", 1: "dense_all", 2: "gn_coef", 3: "conv", 4: "fir2", 5: "attention"}
+    names = {0: "temb_mlp", 1: "dense_all", 2: "gn_coef", 3: "conv", 4: "fir2", 5: "attention", 6: "nearest", 7: "coef2", 8: "spade_apply"}
     agg = {}
     for i in range(n):
+        if ms[i] == 0.0 and fl[i] == 0.0 and by[i] == 0.0:
+            continue
         key = names[kinds[i]] + (f"{kss[i]}x{kss[i]}" if kinds[i] == 3 else "")
         a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
         a["launches"] += 1; a["ms"] += ms[i]; a["flops"] += fl[i]; a["bytes"] += by[i]

@@ -118,6 +118,12 @@ int mcvd_model_set_temb_freqs(mcvd_model* m, const float* freqs_host, int n);
 
 /* eps = UNet(x, labels, cond).  x:[B, C*nf, S, S]  labels:[B] int64  cond:[B, C*nc, S, S] (NULL iff nc==0)  eps like x. */
 int mcvd_unet_forward(mcvd_model* m, const float* x, const int64_t* labels, const float* cond, float* eps_out, int B);
+/* SPADE models (model.spade): the gamma/beta modulation maps depend only on the conditioning frames (layerspp.py:164-168), so
+ * they are computed by mcvd_model_prepare_cond and cached; later forwards that pass the SAME cond pointer and batch size reuse
+ * them until mcvd_model_invalidate_cond / another prepare (the caller promises not to modify cond in between).  A forward whose
+ * (cond, B) was not prepared computes the maps itself, every call.  mcvd_sampler_run prepares once per call.  No-ops for concat models. */
+int mcvd_model_prepare_cond(mcvd_model* m, const float* cond, int B);
+int mcvd_model_invalidate_cond(mcvd_model* m);
 /* Number of kernels one forward enqueues at this batch size (for tests / DESIGN.md). */
 int mcvd_model_num_launches(mcvd_model* m, int B);
 

@@ -48,6 +48,8 @@ _PROTOS = {
     "mcvd_model_set_schedule": (_i, [_vp, _vp, _vp, _vp, _i]),
     "mcvd_model_set_temb_freqs": (_i, [_vp, _vp, _i]),
     "mcvd_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
+    "mcvd_model_prepare_cond": (_i, [_vp, _vp, _i]),
+    "mcvd_model_invalidate_cond": (_i, [_vp]),
     "mcvd_model_num_launches": (_i, [_vp, _i]),
     "mcvd_model_profile_read": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "mcvd_model_op_info": (_i, [_vp, _i, C.POINTER(_i)]),

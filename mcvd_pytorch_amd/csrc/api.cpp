@@ -279,7 +279,25 @@ int mcvd_unet_forward(mcvd_model* m, const float* x, const int64_t* labels, cons
     API_CATCH
 }
 
-int mcvd_model_num_launches(mcvd_model* m, int) { return m ? (int)m->ops.size() : MCVD_EINVAL; }
+int mcvd_model_num_launches(mcvd_model* m, int) {
+    if (!m) return MCVD_EINVAL;
+    int n = 0;
+    for (const Op& op : m->ops) n += op.prep ? 0 : 1;
+    return n;
+}
+
+int mcvd_model_prepare_cond(mcvd_model* m, const float* cond, int B) {
+    API_TRY
+    MCVD_REQUIRE(m && m->ctx, "prepare_cond: NULL model");
+    return m->prepare_cond(cond, B);
+    API_CATCH
+}
+
+int mcvd_model_invalidate_cond(mcvd_model* m) {
+    MCVD_REQUIRE(m, "invalidate_cond: NULL model");
+    m->cond_cache_valid = false;
+    return 0;
+}
 
 // Per-op timings of the last event-instrumented forward (option "profile").  Arrays of length >= n_ops:
 // kind (OpKind), ks (conv kernel size or 0), ms, algorithmic flops, algorithmic bytes (inputs + outputs + weights once).
@@ -294,7 +312,7 @@ int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, doub
     for (int i = 0; i < n; ++i) {
         const Op& op = m->ops[i];
         float t = 0.f;
-        MCVD_HIP_CHECK(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
+        if (!op.prep) MCVD_HIP_CHECK(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
         kinds[i] = (int)op.kind;
         ks[i] = op.kind == OP_CONV ? op.ks : 0;
         ms[i] = t;
@@ -317,6 +335,7 @@ int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, doub
                 f = 4.0 * B * HW * HW * op.Cout;                                     // QK^T + PV
                 by = 4.0 * B * HW * op.Cout * 4.0;                                    // q,k,v in + o out
                 break;
+            case OP_APPLY: by = 4.0 * B * HW * cin * 4.0; f = 12.0 * B * HW * cin; break;   // x, gamma, beta in; y out
             case OP_TEMB: f = 2.0 * B * (m->d.ngf * m->T + (double)m->T * m->T); by = 4.0 * (m->d.ngf * m->T + (double)m->T * m->T); break;
             case OP_DENSE: f = 2.0 * B * m->T * m->NE; by = 4.0 * ((double)m->T * m->NE + B * m->NE); break;
             default: break;
@@ -383,7 +402,9 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
     const int L = (int)steps.size();
     const int64_t per = (int64_t)m->d.channels * m->d.num_frames * m->d.image_size * m->d.image_size;
     const int64_t n = per * B;
-    if (int rc = m->ensure_workspace(B)) return rc;
+    if (int rc = m->prepare_B(B)) return rc;
+    if (int rc = m->prepare_cond(cond, B)) return rc;      // SPADE: gamma/beta once per sampler call (cond is constant)
+    struct CacheGuard { mcvd_model* m; ~CacheGuard() { m->cond_cache_valid = false; } } guard{m};
     hipStream_t s = m->ctx->stream;
     m->profile_armed = true;          // with option "profile": the first forward of this call is event-instrumented
     const int use_philox = noise ? 0 : 1;

@@ -82,6 +82,9 @@ int launch_fir2(const float* x, const float* coef, int act, int up, float* y, in
                 const float* gamma, const float* beta, const float* coef2, hipStream_t s);
 int launch_upfirdn2d(const float* in, const float* kernel_dev, int kh, int kw, int up, int down, int pad0, int pad1,
                      float* out, int NC, int H, int W, int oh, int ow, hipStream_t s);
+int launch_spade_apply(const float* x0, int C0, const float* x1, int C1, const float* coef, const float* gb,
+                       const float* coef2, float* y, int B, int HW, hipStream_t s);
+int launch_coef2(const float* emb, int emb_stride, int emb_off, float* coef2, int B, int C, hipStream_t s);
 int launch_nearest_resize(const float* in, float* out, int BC, int H, int W, int oh, int ow, hipStream_t s);
 
 // ------------------------------------------------------------------ time embedding

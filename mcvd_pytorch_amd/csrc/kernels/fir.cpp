@@ -9,7 +9,7 @@ __device__ __forceinline__ float silu1(float v) { return v * __builtin_amdgcn_rc
 
 struct FirArgs {
     const float* x; const float* coef; int act; int up; float* y; int B, C, H, W;
-    const float* gamma; const float* beta; const float* coef2;
+    const float* gamma; const float* beta; const float* coef2;   // SPADE maps live in a [B][2C][H][W] tensor (gamma | beta)
 };
 
 // value of the (activated) input plane at (yy, xx); zero outside (padding applies after the activation)
@@ -19,7 +19,9 @@ __device__ __forceinline__ float fir_src(const FirArgs& a, const float* plane, l
     float v = plane[yy * a.W + xx];
     if (a.coef) v = v * cA + cB;
     if (a.gamma) {
-        const long gi = pidx + (long)yy * a.W + xx;
+        const long bc = pidx / ((long)a.H * a.W);
+        const long b = bc / a.C, c = bc - b * a.C;
+        const long gi = ((b * 2 * a.C + c) * a.H + yy) * a.W + xx;
         v = v * (1.0f + a.gamma[gi]) + a.beta[gi];
         v = v * sA + sB;
     }
@@ -117,6 +119,63 @@ int launch_upfirdn2d(const float* in, const float* kernel_dev, int kh, int kw, i
     const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
     hipLaunchKernelGGL(upfirdn2d_kernel, dim3(blocks), dim3(256), 0, s, in, kernel_dev, kh, kw, up, down, pad0, out, NC, H,
                        W, oh, ow);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// SPADE modulation + temb scale/shift + SiLU (layerspp.py:171, :535, :548) on a (virtual concat) tensor:
+//   y = silu( ((A x + B) (1 + gamma) + beta) * sA + sB ),  gamma|beta in gb:[B][2C][HW], (A,B) = plain GroupNorm coefficients
+struct SpadeArgs {
+    const float* x0; const float* x1; int C0, C1; const float* coef; const float* gb; const float* coef2; float* y; int B, HW;
+};
+__global__ __launch_bounds__(256) void spade_apply_kernel(SpadeArgs a) {
+    const int C = a.C0 + a.C1;
+    const int HW4 = a.HW >> 2;
+    const long n4 = (long)a.B * C * HW4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int p4 = (int)(i % HW4);
+        const long bc = i / HW4;
+        const int c = (int)(bc % C);
+        const long b = bc / C;
+        const float* src = (c < a.C0) ? a.x0 + (b * a.C0 + c) * a.HW : a.x1 + (b * a.C1 + (c - a.C0)) * a.HW;
+        const float4 v = reinterpret_cast<const float4*>(src)[p4];
+        const float4 g = reinterpret_cast<const float4*>(a.gb + (b * 2 * C + c) * a.HW)[p4];
+        const float4 be = reinterpret_cast<const float4*>(a.gb + (b * 2 * C + C + c) * a.HW)[p4];
+        const float cA = a.coef[bc * 2], cB = a.coef[bc * 2 + 1];
+        float sA = 1.f, sB = 0.f;
+        if (a.coef2) { sA = a.coef2[bc * 2]; sB = a.coef2[bc * 2 + 1]; }
+        float4 o;
+        o.x = silu1(((v.x * cA + cB) * (1.0f + g.x) + be.x) * sA + sB);
+        o.y = silu1(((v.y * cA + cB) * (1.0f + g.y) + be.y) * sA + sB);
+        o.z = silu1(((v.z * cA + cB) * (1.0f + g.z) + be.z) * sA + sB);
+        o.w = silu1(((v.w * cA + cB) * (1.0f + g.w) + be.w) * sA + sB);
+        reinterpret_cast<float4*>(a.y + bc * a.HW)[p4] = o;
+    }
+}
+
+int launch_spade_apply(const float* x0, int C0, const float* x1, int C1, const float* coef, const float* gb,
+                       const float* coef2, float* y, int B, int HW, hipStream_t s) {
+    MCVD_REQUIRE(HW % 4 == 0, "spade_apply: HW=%d", HW);
+    SpadeArgs a{x0, x1, C0, x1 ? C1 : 0, coef, gb, coef2, y, B, HW};
+    const long n4 = (long)B * (a.C0 + a.C1) * (HW / 4);
+    const int blocks = (int)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(spade_apply_kernel, dim3(blocks), dim3(256), 0, s, a);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// coef2[b][c] = (1 + scale, shift) from the fused Dense_0 output (layerspp.py:523,535)
+__global__ void coef2_kernel(const float* emb, int emb_stride, int emb_off, float* coef2, int B, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const float* e = emb + (long)b * emb_stride + emb_off;
+    coef2[2 * i] = 1.0f + e[c];
+    coef2[2 * i + 1] = e[C + c];
+}
+
+int launch_coef2(const float* emb, int emb_stride, int emb_off, float* coef2, int B, int C, hipStream_t s) {
+    hipLaunchKernelGGL(coef2_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, emb, emb_stride, emb_off, coef2, B, C);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -108,6 +108,50 @@ struct Builder {
         return e.emb_off;
     }
 
+    // ---- SPADE (layerspp.py:101-173): gamma/beta depend only on the conditioning frames -> "prep" ops, cached
+    std::map<int, TRef> seg_by_res;
+    TRef seg_for(int R) {
+        auto it = seg_by_res.find(R);
+        if (it != seg_by_res.end()) return it->second;
+        const int cond_ch = m.d.channels * m.d.num_frames_cond;
+        TRef seg = alloc(cond_ch, R);
+        Op op{};
+        op.kind = OP_NEAREST; op.module = -1; op.prep = true; op.src0 = TRef{REF_COND, 0, cond_ch}; op.dst = seg;
+        op.H = op.W = R;
+        m.ops.push_back(op);
+        seg_by_res[R] = seg;
+        return seg;
+    }
+    // registers the MySPADE parameters of `prefix`.Norm_0 and emits the two cond-only convs; returns gb:[2ch, R, R]
+    TRef spade_prep(int module, const std::string& prefix, int ch, int R) {
+        const int cond_ch = m.d.channels * m.d.num_frames_cond, sd = m.d.spade_dim;
+        const std::string N = prefix + ".Norm_0";
+        m.add_param(N + ".mlp_shared.0.weight", {sd, cond_ch, 3, 3});
+        m.add_param(N + ".mlp_shared.0.bias", {sd});
+        m.add_param(N + ".mlp_gamma.weight", {ch, sd, 3, 3});
+        m.add_param(N + ".mlp_gamma.bias", {ch});
+        m.add_param(N + ".mlp_beta.weight", {ch, sd, 3, 3});
+        m.add_param(N + ".mlp_beta.bias", {ch});
+        TRef seg = seg_for(R);
+        TRef sh = alloc(sd, R);
+        Op c1{};
+        c1.kind = OP_CONV; c1.module = module; c1.prep = true; c1.src0 = seg; c1.H = c1.W = R; c1.dst = sh;
+        conv_pack(c1, {N + ".mlp_shared.0.weight"}, {N + ".mlp_shared.0.bias"}, sd, cond_ch, 3, 0);
+        m.ops.push_back(c1);
+        TRef gb = alloc(2 * ch, R);
+        Op c2{};
+        c2.kind = OP_CONV; c2.module = module; c2.prep = true; c2.src0 = sh; c2.H = c2.W = R; c2.act = 1; c2.dst = gb;   // silu(mlp_shared) :148
+        conv_pack(c2, {N + ".mlp_gamma.weight", N + ".mlp_beta.weight"}, {N + ".mlp_gamma.bias", N + ".mlp_beta.bias"}, ch, sd, 3, 0);
+        m.ops.push_back(c2);
+        m.has_prep = true;
+        return gb;
+    }
+    Op coef2_op(int module, int emb_off, int ch, const TRef& dst) {
+        Op op{};
+        op.kind = OP_COEF2; op.module = module; op.emb_off = emb_off; op.Cout = ch; op.dst = dst;
+        return op;
+    }
+
     // registers weights (possibly several fused along Cout) and fills the conv fields of `op`
     void conv_pack(Op& op, const std::vector<std::string>& wnames, const std::vector<std::string>& bnames, int Cout_each,
                    int Cin, int ks, int nin) {
@@ -151,27 +195,39 @@ struct Builder {
         return op;
     }
 
-    // layerspp.py:553-624 ResnetBlockBigGANppGN
+    // layerspp.py:553-624 ResnetBlockBigGANppGN / :628-705 ResnetBlockBigGANppSPADE
     int res_block(int idx, const Act& x, int cin, int cout, bool up, bool down, Act* out) {
         const std::string P = "unet.all_modules." + std::to_string(idx);
         MCVD_REQUIRE(x.C() == cin, "plan: module %d expects %d channels, got %d", idx, cin, x.C());
         MCVD_REQUIRE(!(up || down) || x.b.kind == REF_NONE, "plan: resample block %d fed by a concat", idx);
         const bool conv2 = (cin != cout) || up || down;
+        const bool spade = m.d.spade != 0;
+        const int H = x.H, Ho = up ? 2 * H : (down ? H / 2 : H);
+        // parameter registration in state_dict order (actnorm0, Conv_0, actnorm1, Conv_1, Conv_2)
         const int e0 = dense_entry(P + ".actnorm0", cin);
+        TRef gb0, gb1;
+        if (spade) gb0 = spade_prep(idx, P + ".actnorm0", cin, H);          // norm runs at the PRE-resample resolution
         m.add_param(P + ".Conv_0.weight", {cout, cin, 3, 3});
         m.add_param(P + ".Conv_0.bias", {cout});
         const int e1 = dense_entry(P + ".actnorm1", cout);
+        if (spade) gb1 = spade_prep(idx, P + ".actnorm1", cout, Ho);
         m.add_param(P + ".Conv_1.weight", {cout, cout, 3, 3});
         m.add_param(P + ".Conv_1.bias", {cout});
         if (conv2) {
             m.add_param(P + ".Conv_2.weight", {cout, cin, 1, 1});
             m.add_param(P + ".Conv_2.bias", {cout});
         }
-        const int H = x.H, Ho = up ? 2 * H : (down ? H / 2 : H);
         const float rs2 = 1.0f / (float)sqrt(2.0);
 
-        TRef coef0 = alloc_floats(2 * cin, cin);
-        m.ops.push_back(gn_op(idx, x, 1e-5f, 1, e0, -1, -1, coef0));
+        // ---- actnorm0
+        TRef coef0 = alloc_floats(2 * cin, cin), c2_0;
+        if (spade) {
+            m.ops.push_back(gn_op(idx, x, 1e-6f, 0, 0, -1, -1, coef0));                 // layerspp.py:131 (eps 1e-6, no affine)
+            c2_0 = alloc_floats(2 * cin, cin);
+            m.ops.push_back(coef2_op(idx, e0, cin, c2_0));
+        } else {
+            m.ops.push_back(gn_op(idx, x, 1e-5f, 1, e0, -1, -1, coef0));
+        }
 
         Act h1;
         h1.H = Ho;
@@ -181,9 +237,10 @@ struct Builder {
             TRef hA = alloc(cin, Ho), xr = alloc(cin, Ho);
             Op f{};
             f.kind = OP_FIR; f.module = idx; f.src0 = x.a; f.H = f.W = H; f.coef = coef0; f.act = 1; f.up = up ? 1 : 0; f.dst = hA;
+            if (spade) { f.gb = gb0; f.coef2 = c2_0; }
             m.ops.push_back(f);
-            Op f2 = f;
-            f2.coef = TRef{}; f2.act = 0; f2.dst = xr;
+            Op f2{};
+            f2.kind = OP_FIR; f2.module = idx; f2.src0 = x.a; f2.H = f2.W = H; f2.up = up ? 1 : 0; f2.dst = xr;
             m.ops.push_back(f2);
             Op c{};
             c.kind = OP_CONV; c.module = idx; c.src0 = hA; c.H = c.W = Ho; c.dst = h1.a;
@@ -193,12 +250,35 @@ struct Builder {
             shortcut_src1 = TRef{};
         } else {
             Op c{};
-            c.kind = OP_CONV; c.module = idx; c.src0 = x.a; c.src1 = x.b; c.H = c.W = H; c.coef = coef0; c.act = 1; c.dst = h1.a;
+            c.kind = OP_CONV; c.module = idx; c.H = c.W = H; c.dst = h1.a;
+            if (spade) {                         // modulated + activated tensor is materialised, conv reads it plainly
+                TRef t = alloc(cin, H);
+                Op ap{};
+                ap.kind = OP_APPLY; ap.module = idx; ap.src0 = x.a; ap.src1 = x.b; ap.H = ap.W = H; ap.coef = coef0; ap.gb = gb0;
+                ap.coef2 = c2_0; ap.dst = t;
+                m.ops.push_back(ap);
+                c.src0 = t;
+            } else {
+                c.src0 = x.a; c.src1 = x.b; c.coef = coef0; c.act = 1;
+            }
             conv_pack(c, {P + ".Conv_0.weight"}, {P + ".Conv_0.bias"}, cout, cin, 3, 0);
             m.ops.push_back(c);
         }
+        // ---- actnorm1
         TRef coef1 = alloc_floats(2 * cout, cout);
-        m.ops.push_back(gn_op(idx, h1, 1e-5f, 1, e1, -1, -1, coef1));
+        TRef conv1_src = h1.a;
+        if (spade) {
+            m.ops.push_back(gn_op(idx, h1, 1e-6f, 0, 0, -1, -1, coef1));
+            TRef c2_1 = alloc_floats(2 * cout, cout);
+            m.ops.push_back(coef2_op(idx, e1, cout, c2_1));
+            TRef t = alloc(cout, Ho);
+            Op ap{};
+            ap.kind = OP_APPLY; ap.module = idx; ap.src0 = h1.a; ap.H = ap.W = Ho; ap.coef = coef1; ap.gb = gb1; ap.coef2 = c2_1; ap.dst = t;
+            m.ops.push_back(ap);
+            conv1_src = t;
+        } else {
+            m.ops.push_back(gn_op(idx, h1, 1e-5f, 1, e1, -1, -1, coef1));
+        }
 
         TRef res;
         if (conv2) {
@@ -214,8 +294,8 @@ struct Builder {
         out->a = alloc(cout, Ho);
         out->b = TRef{};
         Op c{};
-        c.kind = OP_CONV; c.module = idx; c.src0 = h1.a; c.H = c.W = Ho; c.coef = coef1; c.act = 1; c.res = res;
-        c.out_scale = rs2; c.dst = out->a;
+        c.kind = OP_CONV; c.module = idx; c.src0 = conv1_src; c.H = c.W = Ho; c.res = res; c.out_scale = rs2; c.dst = out->a;
+        if (!spade) { c.coef = coef1; c.act = 1; }
         conv_pack(c, {P + ".Conv_1.weight"}, {P + ".Conv_1.bias"}, cout, cout, 3, 0);
         m.ops.push_back(c);
         return 0;
@@ -270,7 +350,7 @@ int mcvd_model::build_plan() {
     MCVD_REQUIRE((c.image_size >> (c.n_levels - 1)) >= 8, "desc: lowest resolution %d < 8", c.image_size >> (c.n_levels - 1));
     MCVD_REQUIRE(c.ngf >= 8 && c.ngf % 4 == 0 && c.ngf <= 256, "desc: ngf=%d", c.ngf);
     MCVD_REQUIRE(c.channels > 0 && c.num_frames > 0 && c.num_frames_cond >= 0, "desc: frames/channels");
-    MCVD_REQUIRE(!c.spade, "model.spade=true is not implemented yet in this build");
+    MCVD_REQUIRE(!c.spade || (c.num_frames_cond > 0 && c.spade_dim > 0), "desc: spade needs conditioning frames and spade_dim");
     MCVD_REQUIRE(c.num_classes >= 2, "desc: num_classes=%d", c.num_classes);
     const int nf = c.ngf, C = c.channels, L = c.n_levels, S = c.image_size;
     T = 4 * nf;
@@ -373,19 +453,31 @@ int mcvd_model::build_plan() {
         }
     }
     MCVD_REQUIRE(hs.empty(), "plan: skip stack not empty");
-    // final GroupNorm(affine)+SiLU, conv3x3 (ncsnpp_more.py:246-247)
+    // final norm + SiLU, conv3x3 (ncsnpp_more.py:246-247 GroupNorm affine / :584-586 SPADE without temb)
     {
         const std::string P = "unet.all_modules." + std::to_string(idx);
-        const int gw = add_param(P + ".Norm_0.weight", {in_ch});
-        const int gb = add_param(P + ".Norm_0.bias", {in_ch});
         TRef coef = bld.alloc_floats(2 * in_ch, in_ch);
-        ops.push_back(bld.gn_op(idx, h, 1e-5f, 2, 0, params[gw].off, params[gb].off, coef));
+        Op cv{};
+        cv.kind = OP_CONV; cv.H = cv.W = h.H;
+        if (c.spade) {
+            TRef gb = bld.spade_prep(idx, P, in_ch, h.H);
+            ops.push_back(bld.gn_op(idx, h, 1e-6f, 0, 0, -1, -1, coef));
+            TRef t = bld.alloc(in_ch, h.H);
+            Op ap{};
+            ap.kind = OP_APPLY; ap.module = idx; ap.src0 = h.a; ap.H = ap.W = h.H; ap.coef = coef; ap.gb = gb; ap.dst = t;
+            ops.push_back(ap);
+            cv.src0 = t;
+        } else {
+            const int gw = add_param(P + ".Norm_0.weight", {in_ch});
+            const int gb = add_param(P + ".Norm_0.bias", {in_ch});
+            ops.push_back(bld.gn_op(idx, h, 1e-5f, 2, 0, params[gw].off, params[gb].off, coef));
+            cv.src0 = h.a; cv.coef = coef; cv.act = 1;
+        }
         ++idx;
         const std::string Q = "unet.all_modules." + std::to_string(idx);
         add_param(Q + ".weight", {cx, in_ch, 3, 3});
         add_param(Q + ".bias", {cx});
-        Op cv{};
-        cv.kind = OP_CONV; cv.module = idx; cv.src0 = h.a; cv.H = cv.W = h.H; cv.coef = coef; cv.act = 1;
+        cv.module = idx;
         cv.dst = TRef{REF_OUT, 0, cx};
         bld.conv_pack(cv, {Q + ".weight"}, {Q + ".bias"}, cx, in_ch, 3, 0);
         ops.push_back(cv);
@@ -416,6 +508,8 @@ int mcvd_model::ensure_workspace(int B) {
     MCVD_HIP_CHECK(hipMalloc((void**)&labels, (size_t)B * sizeof(int64_t)));
     MCVD_HIP_CHECK(hipMalloc((void**)&eps_buf, per * B * sizeof(float)));
     arena_B = B;
+    cond_cache_valid = false;
+    tuned_B = 0;
     return 0;
 }
 
@@ -496,10 +590,27 @@ int mcvd_model::launch_op(const Op& op, const float* x, const int64_t* lab, cons
             }
             return ctx->naive_conv ? launch_conv_naive(a, s) : launch_conv_mfma(a, s);
         }
-        case OP_FIR:
+        case OP_FIR: {
+            const float* gb = op.gb.kind == REF_NONE ? nullptr : resolve(op.gb, x, cond, out, B);
             return launch_fir2(resolve(op.src0, x, cond, out, B),
                                op.coef.kind == REF_NONE ? nullptr : resolve(op.coef, x, cond, out, B), op.act, op.up,
-                               resolve(op.dst, x, cond, out, B), B, op.src0.C, op.H, op.W, nullptr, nullptr, nullptr, s);
+                               resolve(op.dst, x, cond, out, B), B, op.src0.C, op.H, op.W, gb,
+                               gb ? gb + (size_t)op.src0.C * op.H * op.W : nullptr,
+                               op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B), s);
+        }
+        case OP_NEAREST:
+            MCVD_REQUIRE(cond, "forward: SPADE model needs the conditioning tensor");
+            return launch_nearest_resize(cond, resolve(op.dst, x, cond, out, B), B * op.src0.C, d.image_size, d.image_size,
+                                         op.H, op.W, s);
+        case OP_COEF2:
+            return launch_coef2(resolve(ops[1].dst, x, cond, out, B), NE, op.emb_off, resolve(op.dst, x, cond, out, B), B,
+                                op.Cout, s);
+        case OP_APPLY:
+            return launch_spade_apply(resolve(op.src0, x, cond, out, B), op.src0.C, resolve(op.src1, x, cond, out, B),
+                                      op.src1.kind == REF_NONE ? 0 : op.src1.C, resolve(op.coef, x, cond, out, B),
+                                      resolve(op.gb, x, cond, out, B),
+                                      op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B),
+                                      resolve(op.dst, x, cond, out, B), B, op.H * op.W, s);
         case OP_ATTN:
             return (ctx->naive_attn ? launch_attention_naive : launch_attention_mfma)(
                 resolve(op.src0, x, cond, out, B), resolve(op.dst, x, cond, out, B), B, op.Cout, op.heads, op.H * op.W, s);
@@ -577,12 +688,41 @@ int mcvd_model::autotune(int B) {
     return 0;
 }
 
+int mcvd_model::prepare_B(int B) {
+    if (int rc = ensure_workspace(B)) return rc;
+    if (ctx->autotune && !ctx->naive_conv && tuned_B != B) {
+        if (int rc = autotune(B)) return rc;
+        cond_cache_valid = false;                 // the tuner scribbles over the workspace
+    }
+    return 0;
+}
+
+int mcvd_model::run_prep(const float* cond, int B) {
+    for (const Op& op : ops)
+        if (op.prep)
+            if (int rc = launch_op(op, nullptr, nullptr, cond, nullptr, B)) return rc;
+    return 0;
+}
+
+int mcvd_model::prepare_cond(const float* cond, int B) {
+    MCVD_REQUIRE(finalized, "prepare_cond before mcvd_model_finalize");
+    if (!has_prep) return 0;
+    MCVD_REQUIRE(cond && B > 0, "prepare_cond: bad arguments");
+    if (int rc = prepare_B(B)) return rc;
+    if (int rc = run_prep(cond, B)) return rc;
+    prepared_cond = cond;
+    prepared_B = B;
+    cond_cache_valid = true;
+    return 0;
+}
+
 int mcvd_model::forward(const float* x, const int64_t* lab, const float* cond, float* out, int B) {
     MCVD_REQUIRE(finalized, "forward before mcvd_model_finalize");
     MCVD_REQUIRE(B > 0 && x && lab && out, "forward: bad arguments");
-    if (int rc = ensure_workspace(B)) return rc;
-    if (ctx->autotune && !ctx->naive_conv && tuned_B != B)
-        if (int rc = autotune(B)) return rc;
+    if (int rc = prepare_B(B)) return rc;
+    // SPADE gamma/beta: reuse the cache only for the exact (cond pointer, batch) it was prepared for
+    if (has_prep && !(cond_cache_valid && prepared_cond == cond && prepared_B == B))
+        if (int rc = run_prep(cond, B)) return rc;
     if (ctx->profile && profile_armed) {
         profile_armed = false;
         if (ev.size() != 2 * ops.size()) {
@@ -592,6 +732,7 @@ int mcvd_model::forward(const float* x, const int64_t* lab, const float* cond, f
         }
         profile_B = B;
         for (size_t i = 0; i < ops.size(); ++i) {
+            if (ops[i].prep) continue;
             MCVD_HIP_CHECK(hipEventRecord(ev[2 * i], ctx->stream));
             if (int rc = launch_op(ops[i], x, lab, cond, out, B)) return rc;
             MCVD_HIP_CHECK(hipEventRecord(ev[2 * i + 1], ctx->stream));
@@ -599,6 +740,7 @@ int mcvd_model::forward(const float* x, const int64_t* lab, const float* cond, f
         return 0;
     }
     for (const Op& op : ops)
-        if (int rc = launch_op(op, x, lab, cond, out, B)) return rc;
+        if (!op.prep)
+            if (int rc = launch_op(op, x, lab, cond, out, B)) return rc;
     return 0;
 }

@@ -41,7 +41,7 @@ struct TRef {
     int C = 0;
 };
 
-enum OpKind { OP_TEMB, OP_DENSE, OP_GN, OP_CONV, OP_FIR, OP_ATTN, OP_NEAREST, OP_COEF2 };
+enum OpKind { OP_TEMB, OP_DENSE, OP_GN, OP_CONV, OP_FIR, OP_ATTN, OP_NEAREST, OP_COEF2, OP_APPLY };
 
 struct Op {
     OpKind kind;
@@ -65,8 +65,9 @@ struct Op {
     int up = 0;
     // attention
     int heads = 0;
-    // SPADE
-    TRef gamma, beta, coef2;
+    // SPADE: gb = cached [2C] (gamma | beta) maps, coef2 = (1 + scale, shift) per (sample, channel)
+    TRef gb, coef2;
+    bool prep = false;             // depends on the conditioning frames only: runs once per cond, not per step
 };
 
 struct DenseEntry {
@@ -120,6 +121,15 @@ struct mcvd_model {
     std::vector<hipEvent_t> ev;
     bool profile_armed = false;
     int profile_B = 0;
+
+    // SPADE modulation cache: valid for (cond pointer, batch) after prepare_cond()
+    const float* prepared_cond = nullptr;
+    int prepared_B = 0;
+    bool cond_cache_valid = false;
+    bool has_prep = false;
+    int prepare_B(int B);                                   // workspace + autotune for a batch size
+    int run_prep(const float* cond, int B);                 // the cond-only ops
+    int prepare_cond(const float* cond, int B);             // run_prep + mark the cache valid
 
     int build_plan();
     int add_param(const std::string& name, std::initializer_list<int64_t> shape);

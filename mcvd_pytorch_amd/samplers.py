@@ -87,6 +87,7 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
                 C.c_void_p(noise.data_ptr()) if noise is not None else None, C.c_uint64(seed or 0),
                 C.c_uint64(sample_offset), int(subsample_steps) if subsample_steps is not None else 0, flags,
                 float(t_min), B), "sampler_run")
+        net._cond_key = None          # the device loop prepared (and then dropped) its own SPADE cache
         return x.unsqueeze(0)
 
     # ------------------------------------------------------------------ host loop (reference :262-340 / :138-203)

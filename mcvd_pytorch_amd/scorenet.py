@@ -84,6 +84,7 @@ class HipScoreNet:
                 torch.zeros(shp, dtype=torch.float32, device=self.device), requires_grad=False)
         self._loaded = False
         self._dirty = True
+        self._cond_key = None          # (data_ptr, _version, B) of the cond whose SPADE maps are cached in the library
         # schedule buffers + sinusoid table, computed exactly like the reference and handed to the library
         betas, alphas, alphas_prev = _schedule(config)
         self._set_schedule(betas, alphas, alphas_prev)
@@ -159,6 +160,8 @@ class HipScoreNet:
                 _lib.check(_lib.lib.mcvd_model_set_param(self._model, k.encode(), _fptr(p.data), shape, p.dim(), 1),
                            f"set_param({k})")
             _lib.check(_lib.lib.mcvd_model_finalize(self._model), "finalize")
+            _lib.check(_lib.lib.mcvd_model_invalidate_cond(self._model))
+        self._cond_key = None
         self._dirty = False
 
     def eval(self):
@@ -236,6 +239,13 @@ class HipScoreNet:
         out = torch.empty_like(x)
         with torch.cuda.device(self.device):
             self._bind_stream()
+            if self._desc.spade:
+                # SPADE gamma/beta depend only on cond: recompute only when the tensor (or its content version) changes
+                key = (cond.data_ptr(), cond._version, B)
+                if key != self._cond_key:
+                    _lib.check(_lib.lib.mcvd_model_prepare_cond(self._model, _fptr(cond), B), "prepare_cond")
+                    self._cond_key = key
+                    self._cond_keepalive = cond
             _lib.check(_lib.lib.mcvd_unet_forward(self._model, _fptr(x), C.c_void_p(y.data_ptr()),
                                                   _fptr(cond) if cond is not None else None, _fptr(out), B), "unet_forward")
         return out

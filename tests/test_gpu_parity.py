@@ -186,7 +186,7 @@ def _net(name):
     return config, sd, net.eval()
 
 
-@pytest.mark.parametrize("fx", ["tiny_b3.pt", "smmnist_big5_b2.pt"])
+@pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt"])
 @pytest.mark.parametrize("naive", [0, 3], ids=["mfma", "naive"])
 def test_forward_vs_reference_golden(golden_dir, fx, naive):
     """One UNet forward vs the REAL reference's output (fixture) and, module by module, vs the oracle."""
@@ -228,6 +228,7 @@ def test_forward_vs_reference_golden(golden_dir, fx, naive):
     ("tiny_b3.pt", "ddpm_10", "ddpm", 10, {}),
     ("tiny_b3.pt", "ddim_10", "ddim", 10, {}),
     ("tiny_b3.pt", "ddpm_10_t_min0.35", "ddpm", 10, dict(t_min=0.35)),
+    ("tiny_spade_b2.pt", "ddpm_10", "ddpm", 10, {}),              # SPADE conditioning, gamma/beta cached per call
     ("smmnist_big5_b2.pt", "ddpm_100", "ddpm", 100, {}),          # BASELINE config 1: 100 steps + denoise
 ])
 @pytest.mark.parametrize("path", ["device_loop", "host_loop"])
@@ -255,6 +256,38 @@ def test_sampler_vs_reference_golden(golden_dir, fx, key, kind, sub, extra, path
     # tools/gpu_diag.py, profiles/r01_precision.txt), so the bar is 3e-4 there.
     tol = 3e-4 if kind == "ddim" else 1e-4
     assert err <= tol, f"final frames max-abs err {err:.3e}"
+
+
+def test_spade_cache_follows_cond_content():
+    """SPADE gamma/beta are cached per cond tensor: changing cond in place (torch bumps ._version) must recompute."""
+    config, sd, net = _net("tiny_spade")
+    B = 2
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = torch.tensor([700, 20])
+    xc, cc = x.cuda(), cond.cuda()
+    e1 = net(xc, t.cuda(), cond=cc)
+    e1b = net(xc, t.cuda(), cond=cc)                 # cached path
+    assert torch.equal(e1, e1b)
+    cc.mul_(0.5)                                     # in-place edit -> new version -> cache miss
+    e2 = net(xc, t.cuda(), cond=cc)
+    with torch.no_grad():
+        ref2 = unet_ref.unet_forward(sd, config, x, t, cond * 0.5)
+    assert (e2.cpu() - ref2).abs().max().item() <= 1e-4 * ref2.abs().max().item()
+    assert (e2 - e1).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize("name,B", [("kth64_big_ngf128", 2), ("bair_big_spade", 2), ("cityscapes_big", 1)])
+def test_other_baseline_configs_forward(name, B):
+    """BASELINE configs 3-5 (ngf=128 / SPADE at full width / 128x128 five-level): one forward vs the CPU oracle."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    config, sd, net = _net(name)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = torch.tensor([(311 * (b + 1)) % 1000 for b in range(B)])
+    eps = net(x.cuda(), t.cuda(), cond=cond.cuda()).cpu()
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t, cond)
+    err = (eps - ref).abs().max().item()
+    assert err <= 1e-4 * ref.abs().max().item(), f"{name}: {err:.3e} vs scale {ref.abs().max().item():.3e}"
 
 
 def test_config2_shapes_mfma_vs_naive_and_properties():

@@ -52,8 +52,8 @@ def _plan(name):
     return _lib, config, m
 
 
-@pytest.mark.parametrize("name", ["tiny", "smmnist_big5", "smmnist_big5_ngf96", "kth64_big_ngf128", "cityscapes_big",
-                                  "cityscapes_big_variant"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_spade", "smmnist_big5", "smmnist_big5_ngf96", "kth64_big_ngf128",
+                                  "bair_big_spade", "cityscapes_big", "cityscapes_big_variant"])
 def test_plan_parameter_table_matches_reference_names(name):
     """Names, shapes and ORDER equal the reference state_dict (oracle.param_shapes is pinned to it by gen_golden)."""
     _lib, config, m = _plan(name)

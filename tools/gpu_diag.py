@@ -98,7 +98,7 @@ def ops(f, cfgname="smmnist_big5_ngf96", B=64):
     kinds, kss = (C.c_int * n)(), (C.c_int * n)()
     ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
     assert _lib.lib.mcvd_model_profile_read(net._model, kinds, kss, ms, fl, by, n) == n
-    names = {0: "temb", 1: "dense", 2: "gn", 3: "conv", 4: "fir", 5: "attn"}
+    names = {0: "temb", 1: "dense", 2: "gn", 3: "conv", 4: "fir", 5: "attn", 6: "near", 7: "coef2", 8: "apply"}
     info = (C.c_int * 8)()
     f.write(f"# {cfgname} B={B}: op, module, kind, ks, H, Cin, Cout, res, pro, us, TFLOP/s, GB/s(alg)\n")
     tot = 0.0
