@@ -327,7 +327,7 @@ int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, doub
             case OP_GN: by = 4.0 * B * HW * cin; f = 4.0 * B * HW * cin; break;       // one algorithmic read (2nd pass hits L2)
             case OP_FIR: {
                 const double o = op.up ? 4.0 : 0.25;
-                by = 4.0 * B * HW * op.src0.C * (1.0 + o);
+                by = 4.0 * B * HW * op.src0.C * (1.0 + o * (op.dst2.kind != REF_NONE ? 2.0 : 1.0));
                 f = B * HW * op.src0.C * o * (op.up ? 8.0 : 32.0);
                 break;
             }
@@ -518,7 +518,7 @@ int mcvd_op_attention(mcvd_ctx* ctx, const float* qkv, float* out, int B, int C,
 
 int mcvd_op_fir2(mcvd_ctx* ctx, const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W) {
     MCVD_REQUIRE(ctx && x && y, "op_fir2: NULL argument");
-    return launch_fir2(x, coef, act, up, y, B, C, H, W, nullptr, nullptr, nullptr, ctx->stream);
+    return launch_fir2(x, coef, act, up, y, B, C, H, W, nullptr, nullptr, nullptr, nullptr, ctx->stream);
 }
 
 }  // extern "C"

@@ -79,7 +79,7 @@ int launch_attention_naive(const float* qkv, float* out, int B, int C, int heads
 
 // ------------------------------------------------------------------ FIR resampling
 int launch_fir2(const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W,
-                const float* gamma, const float* beta, const float* coef2, hipStream_t s);
+                const float* gamma, const float* beta, const float* coef2, float* y_raw, hipStream_t s);
 int launch_upfirdn2d(const float* in, const float* kernel_dev, int kh, int kw, int up, int down, int pad0, int pad1,
                      float* out, int NC, int H, int W, int oh, int ow, hipStream_t s);
 int launch_spade_apply(const float* x0, int C0, const float* x1, int C1, const float* coef, const float* gb,

@@ -13,7 +13,7 @@ int conv_cout_tile(int Cout) {
     return 1;
 }
 
-int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
+int conv_chunk(int ks) { return ks == 3 ? 16 : 32; }   // packing granule of Cin (the largest chunk any tile shape uses)
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);

@@ -1,5 +1,5 @@
 // instantiation unit: 1x1 conv, 32-channel cout tile (split out for parallel compilation)
 #include "conv_mfma.h"
 namespace mcvd {
-int conv1_cot1(const ConvArgs& a, int shape, hipStream_t s) { return conv_mfma_dispatch_shape<1, 16, 1>(a, shape, s); }
+int conv1_cot1(const ConvArgs& a, int shape, hipStream_t s) { return conv_mfma_dispatch_shape<1, 32, 1>(a, shape, s); }
 }  // namespace mcvd

@@ -49,6 +49,7 @@ struct ConvCfg {   // tile geometry (independent of how the weights are staged)
     static constexpr int MAXA = (KS == 3) ? 4 : (CK * BPX / 4 + 255) / 256;
     static constexpr int WCOUNT = CK * KK * BCO / 4;          // float4 per weight chunk
     static constexpr int MAXW = (WCOUNT + 255) / 256;
+    static_assert(WCOUNT % 64 == 0, "weight chunk must be wave-granular for the LDS-DMA path");
 };
 
 // WDMA: weight chunks go global -> LDS by LDS-DMA (global_load_lds_dwordx4: the packed weight slab of a chunk is one
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
 
     f32x4 ra[MAXA];      // native vector types: plain load/store, no struct memcpy (keeps them in VGPRs)
     f32x2 rc[MAXA];
-    f32x4 rw[MAXW];
+    f32x4 rw[WDMA ? 1 : MAXW];
 
     // Loads are unconditional (invalid slots read a safe in-bounds address and are discarded at write time) so the
     // staging registers are always defined; plain macros (not lambdas) keep them out of scratch.
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
         if (WDMA) { /* issue the weight DMA first: it flies while the activation patch is transformed and written */ \
             const float* wsrc = a.wp + (long)cbase * KK * a.CoutP;                                                   \
             _Pragma("unroll") for (int s = 0; s < MAXW; ++s) {                                                       \
-                if (w_goff[s] >= 0)                                                                                  \
+                if (w_goff[s] >= 0) /* wave-granular: WCOUNT is a multiple of 64 */                                  \
                     __builtin_amdgcn_global_load_lds(                                                                \
                         (const __attribute__((address_space(1))) void*)(wsrc + w_goff[s]),                           \
                         (__attribute__((address_space(3))) void*)(sW + (s * 256 + wave * 64) * 4), 16, 0, 0);        \
@@ -372,7 +373,15 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
                  a.CinP, a.CoutP, CK, Cfg::BCO);
     size_t lds = (size_t)(CK * g.PS + CK * Cfg::KK * Cfg::BCO) * sizeof(float);
     if (SPLIT && lds < 3 * 1024 * sizeof(float)) lds = 3 * 1024 * sizeof(float);
-    MCVD_REQUIRE(lds <= 64 * 1024, "conv: LDS %zu > 64KiB", lds);
+    MCVD_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu > 160KiB", lds);
+    if (lds > 64 * 1024) {      // above the default dynamic-LDS limit: opt in once per instantiation
+        static bool raised = false;
+        if (!raised) {
+            MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, CK, COT, PXT, SPLIT, WDMA>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+    }
     dim3 grid(g.n_ptiles, a.CoutP / Cfg::BCO);
     hipLaunchKernelGGL((conv_mfma_kernel<KS, CK, COT, PXT, SPLIT, WDMA>), grid, dim3(256), lds, s, a, g);
     MCVD_HIP_CHECK(hipGetLastError());
@@ -383,10 +392,12 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
 template <int KS, int CK, int COT>
 int conv_mfma_dispatch_shape(const ConvArgs& a, int shape, hipStream_t s) {
     const bool dma = a.wdma != 0;
+    constexpr int CK2 = (KS == 3 && COT <= 3) ? 2 * CK : CK;
     switch (shape) {
         case 0: return dma ? conv_mfma_launch<KS, CK, COT, 2, false, true>(a, s) : conv_mfma_launch<KS, CK, COT, 2, false, false>(a, s);   // 256-pixel tile
         case 1: return dma ? conv_mfma_launch<KS, CK, COT, 1, false, true>(a, s) : conv_mfma_launch<KS, CK, COT, 1, false, false>(a, s);   // 128-pixel tile
-        case 2: return dma ? conv_mfma_launch<KS, CK, COT, 2, true, true>(a, s) : conv_mfma_launch<KS, CK, COT, 2, true, false>(a, s);     // 64-pixel tile, waves split K
+        // 64-pixel tile, the 4 waves split K; 3x3 uses a 16-channel chunk there (more MFMAs per barrier; CinP is packed to 16)
+        case 2: return dma ? conv_mfma_launch<KS, CK2, COT, 2, true, true>(a, s) : conv_mfma_launch<KS, CK2, COT, 2, true, false>(a, s);
     }
     set_error("conv: bad shape id %d", shape);
     return -1;

@@ -9,14 +9,19 @@ __device__ __forceinline__ float silu1(float v) { return v * __builtin_amdgcn_rc
 
 struct FirArgs {
     const float* x; const float* coef; int act; int up; float* y; int B, C, H, W;
+    float* y_raw;      // optional second output: the same resampling of the RAW input (ResBlock shortcut path), one read
     const float* gamma; const float* beta; const float* coef2;   // SPADE maps live in a [B][2C][H][W] tensor (gamma | beta)
 };
 
-// value of the (activated) input plane at (yy, xx); zero outside (padding applies after the activation)
-__device__ __forceinline__ float fir_src(const FirArgs& a, const float* plane, long pidx, int yy, int xx, float cA,
-                                         float cB, float sA, float sB) {
-    if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) return 0.0f;
+struct V2 { float h, r; };    // (prologue-transformed, raw)
+
+// (transformed, raw) value of the input plane at (yy, xx); zero outside (padding applies after the activation)
+__device__ __forceinline__ V2 fir_src(const FirArgs& a, const float* plane, long pidx, int yy, int xx, float cA,
+                                      float cB, float sA, float sB) {
+    V2 o{0.0f, 0.0f};
+    if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) return o;
     float v = plane[yy * a.W + xx];
+    o.r = v;
     if (a.coef) v = v * cA + cB;
     if (a.gamma) {
         const long bc = pidx / ((long)a.H * a.W);
@@ -26,7 +31,8 @@ __device__ __forceinline__ float fir_src(const FirArgs& a, const float* plane, l
         v = v * sA + sB;
     }
     if (a.act) v = silu1(v);
-    return v;
+    o.h = v;
+    return o;
 }
 
 __global__ __launch_bounds__(256) void fir2_kernel(FirArgs a) {
@@ -42,47 +48,57 @@ __global__ __launch_bounds__(256) void fir2_kernel(FirArgs a) {
         float cA = 1.f, cB = 0.f, sA = 1.f, sB = 0.f;
         if (a.coef) { cA = a.coef[bc * 2]; cB = a.coef[bc * 2 + 1]; }
         if (a.coef2) { sA = a.coef2[bc * 2]; sB = a.coef2[bc * 2 + 1]; }
-        float o[4];
+        float o[4], r[4];
         if (a.up) {
             // per axis: y[2n] = x[n-1]/4 + 3x[n]/4 ; y[2n+1] = 3x[n]/4 + x[n+1]/4     
             const int ny = oy >> 1;
             const int ya = (oy & 1) ? ny : ny - 1, yb = (oy & 1) ? ny + 1 : ny;      // rows with weights (wa, wb)
             const float wya = (oy & 1) ? 0.75f : 0.25f, wyb = (oy & 1) ? 0.25f : 0.75f;
             const int nx0 = ox0 >> 1;
-            float col[4];                                                           // vertical blend of cols nx0-1..nx0+2
+            float col[4], colr[4];                                                  // vertical blend of cols nx0-1..nx0+2
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int xx = nx0 - 1 + j;
-                col[j] = wya * fir_src(a, plane, pidx, ya, xx, cA, cB, sA, sB) + wyb * fir_src(a, plane, pidx, yb, xx, cA, cB, sA, sB);
+                const V2 p = fir_src(a, plane, pidx, ya, xx, cA, cB, sA, sB), q = fir_src(a, plane, pidx, yb, xx, cA, cB, sA, sB);
+                col[j] = wya * p.h + wyb * q.h;
+                colr[j] = wya * p.r + wyb * q.r;
             }
             o[0] = 0.25f * col[0] + 0.75f * col[1];
             o[1] = 0.75f * col[1] + 0.25f * col[2];
             o[2] = 0.25f * col[1] + 0.75f * col[2];
             o[3] = 0.75f * col[2] + 0.25f * col[3];
+            r[0] = 0.25f * colr[0] + 0.75f * colr[1];
+            r[1] = 0.75f * colr[1] + 0.25f * colr[2];
+            r[2] = 0.25f * colr[1] + 0.75f * colr[2];
+            r[3] = 0.75f * colr[2] + 0.25f * colr[3];
         } else {
             // per axis: y[m] = (x[2m-1] + 3x[2m] + 3x[2m+1] + x[2m+2]) / 8
-            float col[10];
+            float col[10], colr[10];
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
                 const int xx = 2 * ox0 - 1 + j;
-                const float v0 = fir_src(a, plane, pidx, 2 * oy - 1, xx, cA, cB, sA, sB);
-                const float v1 = fir_src(a, plane, pidx, 2 * oy, xx, cA, cB, sA, sB);
-                const float v2 = fir_src(a, plane, pidx, 2 * oy + 1, xx, cA, cB, sA, sB);
-                const float v3 = fir_src(a, plane, pidx, 2 * oy + 2, xx, cA, cB, sA, sB);
-                col[j] = (v0 + 3.0f * v1 + 3.0f * v2 + v3) * 0.125f;
+                const V2 v0 = fir_src(a, plane, pidx, 2 * oy - 1, xx, cA, cB, sA, sB);
+                const V2 v1 = fir_src(a, plane, pidx, 2 * oy, xx, cA, cB, sA, sB);
+                const V2 v2 = fir_src(a, plane, pidx, 2 * oy + 1, xx, cA, cB, sA, sB);
+                const V2 v3 = fir_src(a, plane, pidx, 2 * oy + 2, xx, cA, cB, sA, sB);
+                col[j] = (v0.h + 3.0f * v1.h + 3.0f * v2.h + v3.h) * 0.125f;
+                colr[j] = (v0.r + 3.0f * v1.r + 3.0f * v2.r + v3.r) * 0.125f;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k) {
                 o[k] = (col[2 * k] + 3.0f * col[2 * k + 1] + 3.0f * col[2 * k + 2] + col[2 * k + 3]) * 0.125f;
+                r[k] = (colr[2 * k] + 3.0f * colr[2 * k + 1] + 3.0f * colr[2 * k + 2] + colr[2 * k + 3]) * 0.125f;
+            }
         }
         *reinterpret_cast<float4*>(a.y + (bc * OH + oy) * OW + ox0) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.y_raw) *reinterpret_cast<float4*>(a.y_raw + (bc * OH + oy) * OW + ox0) = make_float4(r[0], r[1], r[2], r[3]);
     }
 }
 
 int launch_fir2(const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W,
-                const float* gamma, const float* beta, const float* coef2, hipStream_t s) {
+                const float* gamma, const float* beta, const float* coef2, float* y_raw, hipStream_t s) {
     MCVD_REQUIRE((up ? W * 2 : W / 2) % 4 == 0 && H % 2 == 0, "fir2: H=%d W=%d unsupported", H, W);
-    FirArgs a{x, coef, act, up, y, B, C, H, W, gamma, beta, coef2};
+    FirArgs a{x, coef, act, up, y, B, C, H, W, y_raw, gamma, beta, coef2};
     const long n4 = (long)B * C * (up ? H * 2 : H / 2) * ((up ? W * 2 : W / 2) / 4);
     const int blocks = (int)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
     hipLaunchKernelGGL(fir2_kernel, dim3(blocks), dim3(256), 0, s, a);

@@ -1,7 +1,6 @@
 // GroupNorm statistics -> per-(sample, channel) affine coefficients (A, B) with y = A*x + B, so the consumer
 // conv applies normalisation + temb scale/shift (+ SiLU) while it stages its input tile: the normalised tensor is
-// never written to HBM.  One workgroup per (sample, group); two passes over the group's data (the second pass
-// hits L2): mean first, then the centred sum of squares, which keeps the fp32 variance accurate.
+// never written to HBM.  One workgroup per (sample, group), ONE pass over the group's data (pilot-shifted moments).
 // Input may be a virtual channel concat of two tensors (UNet up path: cat([h, skip])).
 #include "../common.h"
 
@@ -32,25 +31,34 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(GnArgs a) {
         return (c < a.C0) ? a.x0 + ((long)b * a.C0 + c) * HW : a.x1 + ((long)b * a.C1 + (c - a.C0)) * HW;
     };
 
-    float s = 0.0f;
-    for (int i = threadIdx.x; i < n4; i += 256) {
+    // Single pass over the group: sums of (x - p) and (x - p)^2 around a pilot value p (the group's first element), which
+    // keeps the fp32 variance free of the E[x^2] - mean^2 cancellation while reading the tensor from HBM exactly once.
+    const float pilot = chan_ptr(c0)[0];
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 256 < n4; i += 512) {                      // two independent float4 streams per thread
+        const int cla = i / HW4, clb = (i + 256) / HW4;
+        const float4 va = *reinterpret_cast<const float4*>(chan_ptr(c0 + cla) + (i - cla * HW4) * 4);
+        const float4 vb = *reinterpret_cast<const float4*>(chan_ptr(c0 + clb) + (i + 256 - clb * HW4) * 4);
+        const float ax = va.x - pilot, ay = va.y - pilot, az = va.z - pilot, aw = va.w - pilot;
+        const float bx = vb.x - pilot, by = vb.y - pilot, bz = vb.z - pilot, bw = vb.w - pilot;
+        s0 += (ax + ay) + (az + aw);
+        s1 += (bx + by) + (bz + bw);
+        q0 += (ax * ax + ay * ay) + (az * az + aw * aw);
+        q1 += (bx * bx + by * by) + (bz * bz + bw * bw);
+    }
+    if (i < n4) {
         const int cl = i / HW4;
-        const int p4 = i - cl * HW4;
-        const float4 v = *reinterpret_cast<const float4*>(chan_ptr(c0 + cl) + p4 * 4);
-        s += (v.x + v.y) + (v.z + v.w);
+        const float4 v = *reinterpret_cast<const float4*>(chan_ptr(c0 + cl) + (i - cl * HW4) * 4);
+        const float ax = v.x - pilot, ay = v.y - pilot, az = v.z - pilot, aw = v.w - pilot;
+        s0 += (ax + ay) + (az + aw);
+        q0 += (ax * ax + ay * ay) + (az * az + aw * aw);
     }
     const float inv_n = 1.0f / (float)(gs * HW);
-    const float mean = block_sum_256(s, red) * inv_n;
-
-    float q = 0.0f;
-    for (int i = threadIdx.x; i < n4; i += 256) {
-        const int cl = i / HW4;
-        const int p4 = i - cl * HW4;
-        const float4 v = *reinterpret_cast<const float4*>(chan_ptr(c0 + cl) + p4 * 4);
-        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    }
-    const float var = block_sum_256(q, red) * inv_n;
+    const float ds = block_sum_256(s0 + s1, red) * inv_n;            // E[x - p]
+    const float dq = block_sum_256(q0 + q1, red) * inv_n;            // E[(x - p)^2]
+    const float mean = pilot + ds;
+    const float var = fmaxf(dq - ds * ds, 0.0f);
     const float rstd = 1.0f / sqrtf(var + a.eps);
 
     for (int cl = threadIdx.x; cl < gs; cl += 256) {

@@ -238,10 +238,8 @@ struct Builder {
             Op f{};
             f.kind = OP_FIR; f.module = idx; f.src0 = x.a; f.H = f.W = H; f.coef = coef0; f.act = 1; f.up = up ? 1 : 0; f.dst = hA;
             if (spade) { f.gb = gb0; f.coef2 = c2_0; }
+            f.dst2 = xr;                 // one read of x produces both FIR(act(norm(x))) and FIR(x) (layerspp.py:600-601)
             m.ops.push_back(f);
-            Op f2{};
-            f2.kind = OP_FIR; f2.module = idx; f2.src0 = x.a; f2.H = f2.W = H; f2.up = up ? 1 : 0; f2.dst = xr;
-            m.ops.push_back(f2);
             Op c{};
             c.kind = OP_CONV; c.module = idx; c.src0 = hA; c.H = c.W = Ho; c.dst = h1.a;
             conv_pack(c, {P + ".Conv_0.weight"}, {P + ".Conv_0.bias"}, cout, cin, 3, 0);
@@ -596,7 +594,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const int64_t* lab, cons
                                op.coef.kind == REF_NONE ? nullptr : resolve(op.coef, x, cond, out, B), op.act, op.up,
                                resolve(op.dst, x, cond, out, B), B, op.src0.C, op.H, op.W, gb,
                                gb ? gb + (size_t)op.src0.C * op.H * op.W : nullptr,
-                               op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B), s);
+                               op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B),
+                               op.dst2.kind == REF_NONE ? nullptr : resolve(op.dst2, x, cond, out, B), s);
         }
         case OP_NEAREST:
             MCVD_REQUIRE(cond, "forward: SPADE model needs the conditioning tensor");

@@ -67,6 +67,7 @@ struct Op {
     int heads = 0;
     // SPADE: gb = cached [2C] (gamma | beta) maps, coef2 = (1 + scale, shift) per (sample, channel)
     TRef gb, coef2;
+    TRef dst2;                     // FIR: second output (raw-input resampling for the shortcut path)
     bool prep = false;             // depends on the conditioning frames only: runs once per cond, not per step
 };
 
