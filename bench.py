@@ -172,7 +172,7 @@ def main():
     names = {0: "temb_mlp", 1: "dense_all", 2: "gn_coef", 3: "conv", 4: "fir2", 5: "attention", 6: "nearest", 7: "coef2", 8: "spade_apply"}
     agg = {}
     for i in range(n):
-        if ms[i] == 0.0 and fl[i] == 0.0 and by[i] == 0.0:
+        if ms[i] == 0.0:          # cond-only (SPADE prep) ops are not part of the per-step forward
             continue
         key = names[kinds[i]] + (f"{kss[i]}x{kss[i]}" if kinds[i] == 3 else "")
         a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))

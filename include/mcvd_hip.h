@@ -82,7 +82,7 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
 /* options: "naive_conv", "naive_attn" (0/1: route through the simple one-thread-per-output HIP kernels, used by the
  * tests to triangulate), "conv_shape" (-1 auto; 0/1/2 force the 256/128/64-pixel conv tile), "conv_wdma" (1: weight
  * chunks by LDS-DMA, 0: register staging), "autotune" (1: time the conv tile candidates per layer shape on first use of a batch
- * size and keep the fastest), "profile" (0/1, see
+ * size and keep the fastest), "side_stream" (1: ResBlock shortcut convs run on a second HIP stream concurrently with Conv_0; default 0, it measured slower), "profile" (0/1, see
  * mcvd_model_profile_read), "graph" (0/1: hipGraph replay of the forward). */
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value);
 const char* mcvd_last_error(mcvd_ctx* ctx); /* ctx may be NULL: last error of this thread */

@@ -42,6 +42,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
     if (const char* t = getenv("MCVD_AUTOTUNE")) c->autotune = atoi(t);
+    if (const char* t = getenv("MCVD_SIDE_STREAM")) c->side_stream = atoi(t);
     const char* e = getenv("MCVD_NAIVE");
     if (e) {
         const int v = atoi(e);
@@ -56,6 +57,9 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
 void mcvd_ctx_destroy(mcvd_ctx* ctx) {
     if (!ctx) return;
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
 }
 
@@ -74,6 +78,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "profile")) ctx->profile = value;
     else if (!strcmp(key, "conv_wdma")) ctx->conv_wdma = value;
     else if (!strcmp(key, "autotune")) ctx->autotune = value;
+    else if (!strcmp(key, "side_stream")) ctx->side_stream = value;
     else {
         set_error("unknown option '%s'", key);
         return MCVD_EINVAL;

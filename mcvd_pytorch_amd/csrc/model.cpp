@@ -233,6 +233,16 @@ struct Builder {
         h1.H = Ho;
         h1.a = alloc(cout, Ho);
         TRef shortcut_src0 = x.a, shortcut_src1 = x.b;
+        TRef res = x.a;             // identity shortcut unless Conv_2 exists (in == out, no resample => single source)
+        auto emit_shortcut = [&]() {
+            if (!conv2) return;
+            res = alloc(cout, Ho);
+            Op c{};
+            c.kind = OP_CONV; c.module = idx; c.src0 = shortcut_src0; c.src1 = shortcut_src1; c.H = c.W = Ho; c.dst = res;
+            c.side = true;          // depends only on x: runs on the side stream, concurrently with Conv_0 / actnorm1
+            conv_pack(c, {P + ".Conv_2.weight"}, {P + ".Conv_2.bias"}, cout, cin, 1, 0);
+            m.ops.push_back(c);
+        };
         if (up || down) {
             TRef hA = alloc(cin, Ho), xr = alloc(cin, Ho);
             Op f{};
@@ -240,13 +250,15 @@ struct Builder {
             if (spade) { f.gb = gb0; f.coef2 = c2_0; }
             f.dst2 = xr;                 // one read of x produces both FIR(act(norm(x))) and FIR(x) (layerspp.py:600-601)
             m.ops.push_back(f);
+            shortcut_src0 = xr;
+            shortcut_src1 = TRef{};
+            emit_shortcut();
             Op c{};
             c.kind = OP_CONV; c.module = idx; c.src0 = hA; c.H = c.W = Ho; c.dst = h1.a;
             conv_pack(c, {P + ".Conv_0.weight"}, {P + ".Conv_0.bias"}, cout, cin, 3, 0);
             m.ops.push_back(c);
-            shortcut_src0 = xr;
-            shortcut_src1 = TRef{};
         } else {
+            emit_shortcut();
             Op c{};
             c.kind = OP_CONV; c.module = idx; c.H = c.W = H; c.dst = h1.a;
             if (spade) {                         // modulated + activated tensor is materialised, conv reads it plainly
@@ -278,21 +290,12 @@ struct Builder {
             m.ops.push_back(gn_op(idx, h1, 1e-5f, 1, e1, -1, -1, coef1));
         }
 
-        TRef res;
-        if (conv2) {
-            res = alloc(cout, Ho);
-            Op c{};
-            c.kind = OP_CONV; c.module = idx; c.src0 = shortcut_src0; c.src1 = shortcut_src1; c.H = c.W = Ho; c.dst = res;
-            conv_pack(c, {P + ".Conv_2.weight"}, {P + ".Conv_2.bias"}, cout, cin, 1, 0);
-            m.ops.push_back(c);
-        } else {
-            res = x.a;      // identity shortcut (in == out, no resample => single source)
-        }
         out->H = Ho;
         out->a = alloc(cout, Ho);
         out->b = TRef{};
         Op c{};
         c.kind = OP_CONV; c.module = idx; c.src0 = conv1_src; c.H = c.W = Ho; c.res = res; c.out_scale = rs2; c.dst = out->a;
+        c.join = conv2;
         if (!spade) { c.coef = coef1; c.act = 1; }
         conv_pack(c, {P + ".Conv_1.weight"}, {P + ".Conv_1.bias"}, cout, cout, 3, 0);
         m.ops.push_back(c);
@@ -522,7 +525,7 @@ float* mcvd_model::resolve(const TRef& r, const float* x, const float* cond, flo
 }
 
 int mcvd_model::launch_op(const Op& op, const float* x, const int64_t* lab, const float* cond, float* out, int B) {
-    hipStream_t s = ctx->stream;
+    hipStream_t s = op_stream ? op_stream : ctx->stream;
     switch (op.kind) {
         case OP_TEMB: {
             const float* w0 = blob + params[find_param("unet.all_modules.0.weight")].off;
@@ -730,7 +733,7 @@ int mcvd_model::forward(const float* x, const int64_t* lab, const float* cond, f
             for (auto& e : ev) MCVD_HIP_CHECK(hipEventCreate(&e));
         }
         profile_B = B;
-        for (size_t i = 0; i < ops.size(); ++i) {
+        for (size_t i = 0; i < ops.size(); ++i) {      // instrumented forward: everything on the main stream
             if (ops[i].prep) continue;
             MCVD_HIP_CHECK(hipEventRecord(ev[2 * i], ctx->stream));
             if (int rc = launch_op(ops[i], x, lab, cond, out, B)) return rc;
@@ -738,8 +741,26 @@ int mcvd_model::forward(const float* x, const int64_t* lab, const float* cond, f
         }
         return 0;
     }
-    for (const Op& op : ops)
-        if (!op.prep)
-            if (int rc = launch_op(op, x, lab, cond, out, B)) return rc;
+    const bool use_side = ctx->side_stream && !ctx->naive_conv;
+    if (use_side && !ctx->side) {
+        MCVD_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        MCVD_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        MCVD_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    for (const Op& op : ops) {
+        if (op.prep) continue;
+        if (use_side && op.side) {                       // fork: the shortcut conv overlaps the main chain
+            MCVD_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            MCVD_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+            op_stream = ctx->side;
+            const int rc = launch_op(op, x, lab, cond, out, B);
+            op_stream = nullptr;
+            if (rc) return rc;
+            MCVD_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->side));
+            continue;
+        }
+        if (use_side && op.join) MCVD_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        if (int rc = launch_op(op, x, lab, cond, out, B)) return rc;
+    }
     return 0;
 }

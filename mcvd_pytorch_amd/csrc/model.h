@@ -15,6 +15,9 @@ struct mcvd_ctx {
     int graph = 0;
     int conv_shape = -1;           // -1 auto, 0/1/2 force a conv tile shape (tests)
     int conv_wdma = 1;             // weight chunks by LDS-DMA (1) or register staging (0)
+    int side_stream = 0;           // 1: run the ResBlock shortcut 1x1 convs on a second stream (measured -2 %: off by default)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int autotune = 1;              // time the conv tile candidates per distinct layer shape on first use of a batch size
     int profile = 0;               // record HIP events around every op of the first forward of each sampler call
     float* scratch = nullptr;      // small device scratch for stand-alone ops (kernel taps, packed weights)
@@ -68,6 +71,8 @@ struct Op {
     // SPADE: gb = cached [2C] (gamma | beta) maps, coef2 = (1 + scale, shift) per (sample, channel)
     TRef gb, coef2;
     TRef dst2;                     // FIR: second output (raw-input resampling for the shortcut path)
+    bool side = false;             // independent of the main chain until `join`: may run on the side stream
+    bool join = false;             // must wait for the preceding side op
     bool prep = false;             // depends on the conditioning frames only: runs once per cond, not per step
 };
 
@@ -132,6 +137,7 @@ struct mcvd_model {
     int run_prep(const float* cond, int B);                 // the cond-only ops
     int prepare_cond(const float* cond, int B);             // run_prep + mark the cache valid
 
+    hipStream_t op_stream = nullptr;                        // overrides ctx->stream for the op being launched (side stream)
     int build_plan();
     int add_param(const std::string& name, std::initializer_list<int64_t> shape);
     int find_param(const char* name) const;

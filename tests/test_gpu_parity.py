@@ -290,6 +290,51 @@ def test_other_baseline_configs_forward(name, B):
     assert err <= 1e-4 * ref.abs().max().item(), f"{name}: {err:.3e} vs scale {ref.abs().max().item():.3e}"
 
 
+def test_video_gen_autoregressive_and_checkpoint_format(tmp_path):
+    """The autoregressive block driver (runners/ncsn_runner.py:1504-1569) on device vs the same loop over the CPU
+    oracle, with the weights arriving through the reference's checkpoint.pt list format + EMA overwrite."""
+    from mcvd_pytorch_amd import load_model, video_gen
+    config = synth.make_config("tiny")           # nf = nc = 2 -> 3 blocks for 5 predicted frames, cropped to 5
+    sd = synth.make_state_dict(config, seed=123)
+    stale = {"module." + k: torch.zeros_like(v) for k, v in sd.items()}     # states[0] is overwritten by the EMA shadow
+    torch.save([stale, {}, 7, 1234, dict(sd)], tmp_path / "checkpoint.pt")
+    config.model.ema = True
+    net = load_model(str(tmp_path / "checkpoint.pt"), config, device="cuda:0")
+    B, nfp = 2, 5
+    c = unet_ref.hot_cfg(config)
+    _, cond = synth.make_inputs(config, B, seed=0)
+    n_blocks = 3
+    inits = [torch.randn(B, c.channels * c.num_frames, c.image_size, c.image_size, generator=_g(50 + i)) for i in range(n_blocks)]
+    noises = [synth.make_noise(config, B, 11, seed=60 + i) for i in range(n_blocks)]
+    blk = [0]
+
+    def sampler(x, scorenet, cond=None, **kw):
+        from mcvd_pytorch_amd.samplers import ddpm_sampler
+        i = blk[0]
+        blk[0] += 1
+        kw.pop("subsample_steps", None)
+        return ddpm_sampler(x, scorenet, cond=cond, subsample_steps=10, noise=noises[i].cuda(), **kw)
+    got = video_gen(config, net, cond.cuda(), num_frames_pred=nfp, sampler=sampler,
+                    init_noise_fn=lambda i, shp, dev: inits[i].to(dev)).cpu()
+    # oracle loop
+    onet = unet_ref.OracleScoreNet(config, sd)
+    oc, preds = cond.clone(), []
+    C, nf, nc = c.channels, c.num_frames, config.data.num_frames_cond
+    for i in range(n_blocks):
+        k = [0]
+
+        def fn(j, like, i=i):
+            k[0] += 1
+            return noises[i][k[0] - 1]
+        gen = sampler_ref.sample(inits[i].clone(), onet, cond=oc, kind="ddpm", final_only=True, denoise=True,
+                                 subsample_steps=10, noise_fn=fn)[0]
+        preds.append(gen)
+        oc = torch.cat([oc[:, C * nf:], gen[:, C * max(0, nf - nc):]], dim=1)
+    want = torch.cat(preds, dim=1)[:, :C * nfp]
+    assert got.shape == want.shape == (B, C * nfp, c.image_size, c.image_size)
+    assert (got - want).abs().max().item() <= 2e-4        # three chained 10-step blocks
+
+
 def test_config2_shapes_mfma_vs_naive_and_properties():
     """BASELINE config 2 width (ngf=96) at a batch the oracle would take minutes for: MFMA path vs the simple HIP
     kernels (same inputs), plus size-independent properties: per-sample independence (row permutation equivariance)
