@@ -111,10 +111,15 @@ def main():
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     import torch.distributed as dist
+    backend = os.environ.get("MCVD_DIST_BACKEND", "nccl")     # "gloo": N>1 plumbing check on a box with fewer GPUs than ranks
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
 
     from mcvd_pytorch_amd import HipScoreNet, ddpm_sampler, synthetic
     from mcvd_pytorch_amd.dist import broadcast_weights, gather_rows, shard_rows
@@ -156,7 +161,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     assert torch.isfinite(frames).all() and frames.shape[0] == total

@@ -49,6 +49,10 @@ struct ConvCfg {   // tile geometry (independent of how the weights are staged)
     static constexpr int MAXA = (KS == 3) ? 4 : (CK * BPX / 4 + 255) / 256;
     static constexpr int WCOUNT = CK * KK * BCO / 4;          // float4 per weight chunk
     static constexpr int MAXW = (WCOUNT + 255) / 256;
+    static constexpr int WSZ = CK * KK * BCO;                 // floats per weight chunk
+    // Double-buffer the weight chunk when it is small enough to keep two workgroups per CU: the DMA for chunk i+1 is
+    // then issued BEFORE the MFMAs of chunk i and its latency disappears behind them.
+    static constexpr bool WDB = WSZ * 4 <= 30 * 1024;
     static_assert(WCOUNT % 64 == 0, "weight chunk must be wave-granular for the LDS-DMA path");
 };
 
@@ -59,6 +63,7 @@ template <int KS, int CK, int COT, int PXT, bool SPLIT, bool WDMA>
 __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT && !WDMA)) ? 1 : 2) void conv_mfma_kernel(ConvArgs a, ConvGeom g) {
     using Cfg = ConvCfg<KS, CK, COT, PXT, SPLIT>;
     constexpr int KK = Cfg::KK, HALO = Cfg::HALO, BCO = Cfg::BCO, MAXA = Cfg::MAXA, MAXW = Cfg::MAXW;
+    constexpr bool WDB = WDMA && Cfg::WDB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sW = smem + CK * g.PS;
@@ -142,11 +147,21 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
             _Pragma("unroll") for (int s = 0; s < MAXW; ++s)                                                         \
                 rw[s] = *reinterpret_cast<const f32x4*>(wsrc + (w_goff[s] >= 0 ? w_goff[s] : 0));                    \
         }                                                                                                            \
+        if (WDB) { /* double-buffered: this chunk's weights fly into the idle buffer during the previous chunk's MFMAs */ \
+            const float* wsrc = a.wp + (long)cbase * KK * a.CoutP;                                                   \
+            float* wdst = sW + (((ch) & 1) ? Cfg::WSZ : 0);                                                          \
+            _Pragma("unroll") for (int s = 0; s < MAXW; ++s) {                                                       \
+                if (w_goff[s] >= 0)                                                                                  \
+                    __builtin_amdgcn_global_load_lds(                                                                \
+                        (const __attribute__((address_space(1))) void*)(wsrc + w_goff[s]),                           \
+                        (__attribute__((address_space(3))) void*)(wdst + (s * 256 + wave * 64) * 4), 16, 0, 0);      \
+            }                                                                                                        \
+        }                                                                                                            \
     }
 #define MCVD_WRITE_CHUNK(ch)                                                                                         \
     {                                                                                                                \
         const int cbase = (ch) * CK;                                                                                 \
-        if (WDMA) { /* issue the weight DMA first: it flies while the activation patch is transformed and written */ \
+        if (WDMA && !WDB) { /* single buffer: issue the DMA first, it flies while the activation patch is written */ \
             const float* wsrc = a.wp + (long)cbase * KK * a.CoutP;                                                   \
             _Pragma("unroll") for (int s = 0; s < MAXW; ++s) {                                                       \
                 if (w_goff[s] >= 0) /* wave-granular: WCOUNT is a multiple of 64 */                                  \
@@ -229,17 +244,24 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
         }
     if (!SPLIT && a.res) {
         if (full_tile) {
+            // one 32-channel sub-tile at a time: 16*PXT independent loads in flight, then the adds.  The scheduling
+            // barriers keep hipcc from serialising them into load-wait-add pairs under register pressure (48 round trips).
 #pragma unroll
-            for (int ct = 0; ct < COT; ++ct)
+            for (int ct = 0; ct < COT; ++ct) {
+                float tmp[16][PXT];
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) {
                     const float* rb = a.res + (long)(co0 + ct * 32 + (rg & 3) + 8 * (rg >> 2)) * HW;
 #pragma unroll
-                    for (int pt = 0; pt < PXT; ++pt) {
-                        const float r = rb[roff[pt]];
-                        acc[ct][pt][rg] += pvalid[pt] ? r : 0.0f;
-                    }
+                    for (int pt = 0; pt < PXT; ++pt) tmp[rg][pt] = rb[roff[pt]];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg)
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt) acc[ct][pt][rg] += pvalid[pt] ? tmp[rg][pt] : 0.0f;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {      // ragged cout tile (never on the UNet's residual convs): predicated loads
 #pragma unroll
             for (int ct = 0; ct < COT; ++ct)
@@ -262,6 +284,7 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
 
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch + 1 < nchunks) MCVD_LOAD_CHUNK(ch + 1);
+        const float* sWc = sW + ((WDB && (ch & 1)) ? Cfg::WSZ : 0);
         // ---- MFMA over this chunk
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
@@ -272,7 +295,7 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
                 const int kp = SPLIT ? (wave + 4 * kq) : kq;
                 float aw[COT], bx[PXT];
 #pragma unroll
-                for (int ct = 0; ct < COT; ++ct) aw[ct] = sW[(2 * kp * KK + tap) * BCO + ct * 32 + woff];
+                for (int ct = 0; ct < COT; ++ct) aw[ct] = sWc[(2 * kp * KK + tap) * BCO + ct * 32 + woff];
 #pragma unroll
                 for (int pt = 0; pt < PXT; ++pt) bx[pt] = sA[2 * kp * g.PS + pixoff[pt] + tapoff];
 #pragma unroll
@@ -371,7 +394,7 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     MCVD_REQUIRE((double)a.B * a.Cout * a.H * a.W < 4.0e9, "conv: output tensor exceeds 32-bit element offsets");
     MCVD_REQUIRE(a.CinP % CK == 0 && a.CoutP % Cfg::BCO == 0, "conv: packed dims (%d,%d) vs chunk %d tile %d",
                  a.CinP, a.CoutP, CK, Cfg::BCO);
-    size_t lds = (size_t)(CK * g.PS + CK * Cfg::KK * Cfg::BCO) * sizeof(float);
+    size_t lds = (size_t)(CK * g.PS + ((WDMA && Cfg::WDB) ? 2 : 1) * Cfg::WSZ) * sizeof(float);
     if (SPLIT && lds < 3 * 1024 * sizeof(float)) lds = 3 * 1024 * sizeof(float);
     MCVD_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu > 160KiB", lds);
     if (lds > 64 * 1024) {      // above the default dynamic-LDS limit: opt in once per instantiation

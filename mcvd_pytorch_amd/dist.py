@@ -16,6 +16,11 @@ def shard_rows(total_rows, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def _host_staged():
+    """gloo moves GPU tensors through the host (it has no device all_gather); RCCL ("nccl") works on device memory."""
+    return dist.get_backend() == "gloo"
+
+
 def broadcast_weights(net, src=0):
     """ONE collective: rank `src` exports its parameter blob, everyone imports it."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -25,7 +30,12 @@ def broadcast_weights(net, src=0):
         blob = net.export_blob()
     else:
         blob = torch.empty(net.blob_numel(), dtype=torch.float32, device=net.device)
-    dist.broadcast(blob, src=src)
+    if _host_staged() and blob.is_cuda:
+        host = blob.cpu()
+        dist.broadcast(host, src=src)
+        blob = host.to(net.device)
+    else:
+        dist.broadcast(blob, src=src)
     if dist.get_rank() != src:
         net.import_blob(blob)
 
@@ -37,11 +47,14 @@ def gather_rows(local, total_rows):
     world = dist.get_world_size()
     sizes = [shard_rows(total_rows, r, world) for r in range(world)]
     mx = max(e - b for b, e in sizes)
-    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dev = local.device
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
     pad[:local.shape[0]] = local
+    if _host_staged() and pad.is_cuda:
+        pad = pad.cpu()
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
-    return torch.cat([o[:e - b] for o, (b, e) in zip(out, sizes)], dim=0)
+    return torch.cat([o[:e - b] for o, (b, e) in zip(out, sizes)], dim=0).to(dev)
 
 
 def sample_sharded(sampler, scorenet, x_full_fn, cond_full_fn, total_rows, **sampler_kwargs):

@@ -21,6 +21,12 @@ if [ "$MODE" != "quick" ] && [ "$MODE" != "prof" ]; then
   echo "bench rc=$?" >> gpurun_out/bench.err
   cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
 fi
+if [ "$MODE" = "pmc2" ]; then
+  R=$GRAFT_REPO_ROOT
+  cd /tmp
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_mfma -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline > $R/gpurun_out/pmc_mfma.json 2> $R/gpurun_out/pmc_mfma.err
+  cd $R; python tools/summarize_prof.py mfma > gpurun_out/pmc_mfma_summary.txt 2>&1; head -30 gpurun_out/pmc_mfma_summary.txt
+fi
 if [ "$MODE" = "prof" ]; then
   R=$GRAFT_REPO_ROOT
   cd /tmp

@@ -53,7 +53,32 @@ def pmc(dirname, counter):
             print(f"{k:58s} {c:6d} launches  avg {v / c:14.1f}  total {v:16.1f}")
 
 
+def mfma():
+    """MFMA-busy and effective clock per kernel from GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES + kernel durations."""
+    for f in glob.glob(os.path.join(OUT, "pmc_mfma", "**", "*counter_collection.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        cols = rows[0].keys() if rows else []
+        print("columns:", list(cols))
+        agg = defaultdict(lambda: defaultdict(float))
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if "Start_Timestamp" in r and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                agg[k]["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                agg[k]["n"] += 1
+        print("== per kernel: launches, total ms, GUI_ACTIVE cycles, eff. clock GHz, MFMA_BUSY/(GUI_ACTIVE*1024 SIMDs)")
+        for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("ns", 0))[:20]:
+            ns, gui, mf = d.get("ns", 0), d.get("GRBM_GUI_ACTIVE", 0), d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
+            if ns <= 0 or gui <= 0:
+                continue
+            print(f"{k:58s} {int(d['n']):5d} {ns / 1e6:9.2f} ms  gui {gui:.3e}  clk {gui / ns:5.2f} GHz  mfma_busy/gui {mf / gui:9.2f}  "
+                  f"(/1024 SIMDs = {mf / gui / 1024:5.3f}, /256 CUs = {mf / gui / 256:5.3f})  sq_busy/gui {d.get('SQ_BUSY_CYCLES', 0) / gui:8.2f}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "mfma":
+        mfma()
+        sys.exit(0)
     stats()
     pmc("pmc_fetch", "FETCH_SIZE")
     pmc("pmc_write", "WRITE_SIZE")
