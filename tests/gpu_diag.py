@@ -1,5 +1,6 @@
-"""GPU diagnostics (writes gpurun_out/diag_*.txt): precision vs fp32/fp64 oracle, per-op timings, conv tile sweep.
-    python tools/gpu_diag.py [precision] [ops] [sweep]
+"""GPU diagnostics -- test infrastructure (uses the oracle as checker; writes gpurun_out/diag_*.txt): precision vs the
+fp32/fp64 oracle, per-op timings, conv tile sweep.
+    python tests/gpu_diag.py [precision] [ops] [sweep]
 """
 import ctypes as C
 import os

@@ -253,7 +253,7 @@ def test_sampler_vs_reference_golden(golden_dir, fx, key, kind, sub, extra, path
     err = (out.cpu() - ref).abs().max().item()
     # DDPM: 1e-4.  DDIM has no per-step noise to damp rounding differences and this random-weight net is
     # chaotic under it: the REFERENCE's own fp32-vs-fp64 drift on this fixture is 4.6e-5 (HIP-vs-fp64: 7.4e-5, measured by
-    # tools/gpu_diag.py, profiles/r01_precision.txt), so the bar is 3e-4 there.
+    # tests/gpu_diag.py, profiles/r01_precision.txt), so the bar is 3e-4 there.
     tol = 3e-4 if kind == "ddim" else 1e-4
     assert err <= tol, f"final frames max-abs err {err:.3e}"
 
