@@ -85,6 +85,10 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  * size and keep the fastest), "side_stream" (1: ResBlock shortcut convs run on a second HIP stream concurrently with Conv_0; default 0, it measured slower), "profile" (0/1, see
  * mcvd_model_profile_read), "graph" (0/1: hipGraph replay of the forward). */
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value);
+/* Diagnostics: when set (device pointer to [n_blocks][8] uint64, or NULL to disable), mcvd_op_conv2d's MFMA kernel records per
+ * block the shader cycles wave 0 spent in {prologue, MFMA phases, barrier after MFMA, staging writes, second barrier, split-K
+ * reduction, epilogue, total}. */
+int mcvd_ctx_set_debug_buffer(mcvd_ctx* ctx, void* device_u64);
 const char* mcvd_last_error(mcvd_ctx* ctx); /* ctx may be NULL: last error of this thread */
 const char* mcvd_version(void);
 

@@ -69,6 +69,12 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream) {
     return 0;
 }
 
+int mcvd_ctx_set_debug_buffer(mcvd_ctx* ctx, void* device_u64) {
+    MCVD_REQUIRE(ctx, "ctx is NULL");
+    ctx->dbg = (unsigned long long*)device_u64;
+    return 0;
+}
+
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     MCVD_REQUIRE(ctx && key, "ctx/key is NULL");
     if (!strcmp(key, "naive_conv")) ctx->naive_conv = value;
@@ -503,6 +509,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.bias = ctx->scratch + wfloats;
     a.shape_hint = ctx->conv_shape;
     a.wdma = ctx->conv_wdma;
+    a.dbg = ctx->dbg;
     return ctx->naive_conv ? launch_conv_naive(a, ctx->stream) : launch_conv_mfma(a, ctx->stream);
     API_CATCH
 }

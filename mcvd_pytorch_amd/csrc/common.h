@@ -48,6 +48,7 @@ struct ConvArgs {
     int cot;              // cout tile in units of 32 channels (1..4); CoutP % (32*cot) == 0
     int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile (tests)
     int wdma;             // 1: stage weight chunks by LDS-DMA (default), 0: through registers
+    unsigned long long* dbg;   // optional: per-block phase cycle counters [n_blocks][8] (diagnostics), else null
 };
 int conv_cout_tile(int Cout);                 // 32-channel units per block along Cout
 int conv_chunk(int ks);                       // input-channel chunk the MFMA kernel consumes per stage

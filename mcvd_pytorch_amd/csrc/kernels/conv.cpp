@@ -31,8 +31,8 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     auto blocks = [&](int bpx) { return ((px + bpx - 1) / bpx) * ntc; };
     auto fits = [&](int bpx) { return bpx % a.W == 0 && (bpx / a.W <= a.H ? a.H % (bpx / a.W) == 0 : (bpx / a.W) % a.H == 0); };
     int shape;
-    const int want = (a.shape_hint >= 0 && a.shape_hint <= 2) ? a.shape_hint : forced;
-    if (want >= 0 && want <= 2 && fits(want == 0 ? 256 : want == 1 ? 128 : 64)) shape = want;
+    const int want = (a.shape_hint >= 0 && a.shape_hint <= 3) ? a.shape_hint : forced;
+    if (want >= 0 && want <= 3 && fits(want == 0 ? 256 : want == 1 ? 128 : 64)) shape = want;
     else if (fits(256) && blocks(256) >= min_blocks) shape = 0;
     else if (fits(128) && blocks(128) >= min_blocks) shape = 1;
     else if (fits(64)) shape = 2;

@@ -20,6 +20,10 @@
 #pragma once
 #include "../common.h"
 
+#ifndef MCVD_CONV_PIPE2
+#define MCVD_CONV_PIPE2 0
+#endif
+
 namespace mcvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -59,14 +63,20 @@ struct ConvCfg {   // tile geometry (independent of how the weights are staged)
 // WDMA: weight chunks go global -> LDS by LDS-DMA (global_load_lds_dwordx4: the packed weight slab of a chunk is one
 // linear LDS image, wave-uniform base + lane*16) instead of through 28-36 staging VGPRs; that is what lets the 256-pixel
 // x 96-cout tile fit two workgroups per CU, so one block's barrier/staging/epilogue phases hide under the other's MFMAs.
-template <int KS, int CK, int COT, int PXT, bool SPLIT, bool WDMA>
+template <int KS, int CK, int COT, int PXT, bool SPLIT, bool WDMA, bool WDBF = false>
 __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT && !WDMA)) ? 1 : 2) void conv_mfma_kernel(ConvArgs a, ConvGeom g) {
     using Cfg = ConvCfg<KS, CK, COT, PXT, SPLIT>;
     constexpr int KK = Cfg::KK, HALO = Cfg::HALO, BCO = Cfg::BCO, MAXA = Cfg::MAXA, MAXW = Cfg::MAXW;
-    constexpr bool WDB = WDMA && Cfg::WDB;
+    constexpr bool WDB = WDMA && (Cfg::WDB || WDBF);      // WDBF: double-buffer even a large weight chunk (one block per CU)
+    // PIPE2 (3x3, pixel-split tiles, double-buffered DMA weights): the activation patch is double-buffered too, so the
+    // prologue transform + LDS write of chunk i+1 is interleaved with the MFMAs of chunk i (separate pipes) and each chunk
+    // needs ONE barrier.  The serialised staging phase is 10-13 % of a block's time in isolation, but with two
+    // workgroups per CU the partner block already fills it: measured on MI355X this variant is 0-5 % SLOWER (profiles/
+    // r01_conv_phase_breakdown.txt), so it is compiled out (MCVD_CONV_PIPE2=1 re-enables it).
+    constexpr bool PIPE2 = MCVD_CONV_PIPE2 && (KS == 3) && !SPLIT && WDB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
-    float* sW = smem + CK * g.PS;
+    float* sW = smem + (PIPE2 ? 2 : 1) * CK * g.PS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
     }
 
     // zero the activation patch once: halo columns (and unused pad) stay zero for the whole kernel
-    for (int i = tid; i < CK * g.PS; i += 256) sA[i] = 0.0f;
+    for (int i = tid; i < (PIPE2 ? 2 : 1) * CK * g.PS; i += 256) sA[i] = 0.0f;
 
     f32x4 ra[MAXA];      // native vector types: plain load/store, no struct memcpy (keeps them in VGPRs)
     f32x2 rc[MAXA];
@@ -125,6 +135,61 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
 
     // Loads are unconditional (invalid slots read a safe in-bounds address and are discarded at write time) so the
     // staging registers are always defined; plain macros (not lambdas) keep them out of scratch.
+#define MCVD_LOAD_A(ch)                                                                                              \
+    {                                                                                                                \
+        const int cbase = (ch) * CK;                                                                                 \
+        _Pragma("unroll") for (int s = 0; s < MAXA; ++s) {                                                           \
+            const int c = cbase + (a_cb[s] >> 16);                                                                   \
+            const int b = b0 + ((a_cb[s] >> 1) & 0x7fff);                                                            \
+            const bool ok = (a_cb[s] >= 0) && (a_cb[s] & 1) && (c < Cin);                                            \
+            const float* src = a.x0;                                                                                 \
+            const float* csrc = a.coef ? a.coef : a.bias;                                                            \
+            if (ok) {                                                                                                \
+                src = ((c < a.C0) ? a.x0 + ((long)b * a.C0 + c) * HW                                                 \
+                                  : a.x1 + ((long)b * a.C1 + (c - a.C0)) * HW) + a_goff[s];                          \
+                if (a.coef) csrc = a.coef + ((long)b * Cin + c) * 2;                                                 \
+            }                                                                                                        \
+            ra[s] = *reinterpret_cast<const f32x4*>(src);                                                            \
+            rc[s] = *reinterpret_cast<const f32x2*>(csrc);                                                           \
+        }                                                                                                            \
+    }
+#define MCVD_DMA_W(ch)                                                                                               \
+    {                                                                                                                \
+        const float* wsrc = a.wp + (long)(ch) * CK * KK * a.CoutP;                                                   \
+        float* wdst = sW + (((ch) & 1) ? Cfg::WSZ : 0);                                                              \
+        _Pragma("unroll") for (int s = 0; s < MAXW; ++s) {                                                           \
+            if (w_goff[s] >= 0)                                                                                      \
+                __builtin_amdgcn_global_load_lds(                                                                    \
+                    (const __attribute__((address_space(1))) void*)(wsrc + w_goff[s]),                               \
+                    (__attribute__((address_space(3))) void*)(wdst + (s * 256 + wave * 64) * 4), 16, 0, 0);          \
+        }                                                                                                            \
+    }
+// (issuing the DMA pieces one by one between MFMA groups instead of in a burst measured neutral: it costs registers)
+#define MCVD_DMA_W_SLOT(ch, s)                                                                                       \
+    {                                                                                                                \
+        if (w_goff[s] >= 0)                                                                                          \
+            __builtin_amdgcn_global_load_lds(                                                                        \
+                (const __attribute__((address_space(1))) void*)(a.wp + (long)(ch) * CK * KK * a.CoutP + w_goff[s]),  \
+                (__attribute__((address_space(3))) void*)(sW + (((ch) & 1) ? Cfg::WSZ : 0) + (s * 256 + wave * 64) * 4), \
+                16, 0, 0);                                                                                           \
+    }
+#define MCVD_WRITE_A_SLOT(ch, s, dstbase)                                                                            \
+    {                                                                                                                \
+        if (a_cb[s] >= 0) {                                                                                          \
+            f32x4 v = ra[s];                                                                                         \
+            const bool live = (a_cb[s] & 1) && ((ch) * CK + (a_cb[s] >> 16) < Cin);                                  \
+            if (live) {                                                                                              \
+                if (a.coef) {                                                                                        \
+                    v.x = v.x * rc[s].x + rc[s].y; v.y = v.y * rc[s].x + rc[s].y;                                    \
+                    v.z = v.z * rc[s].x + rc[s].y; v.w = v.w * rc[s].x + rc[s].y;                                    \
+                }                                                                                                    \
+                if (a.act) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }           \
+            } else {                                                                                                 \
+                v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                       \
+            }                                                                                                        \
+            *reinterpret_cast<f32x4*>((dstbase) + a_lds[s]) = v;                                                     \
+        }                                                                                                            \
+    }
 #define MCVD_LOAD_CHUNK(ch)                                                                                          \
     {                                                                                                                \
         const int cbase = (ch) * CK;                                                                                 \
@@ -276,11 +341,64 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
         }
     }
 
+    // optional phase timing (wave 0 of every block; shader cycles): 0 prologue, 1 MFMA phases, 2 barrier after MFMA (incl.
+    // vmcnt drain), 3 staging writes, 4 second barrier, 5 split-K reduction, 6 epilogue, 7 total
+    unsigned long long tk0 = 0, tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    if (a.dbg) tk0 = tprev = __builtin_amdgcn_s_memtime();
+#define MCVD_STAMP(i)                                                   \
+    if (a.dbg) {                                                        \
+        const unsigned long long tn = __builtin_amdgcn_s_memtime();     \
+        tacc[i] += tn - tprev;                                          \
+        tprev = tn;                                                     \
+    }
+
     const int nchunks = a.CinP / CK;
+    if (PIPE2) {
+        // ---- software pipeline over channel chunks: one barrier per chunk
+        MCVD_LOAD_A(0);
+        MCVD_DMA_W(0);
+        __syncthreads();              // zero fill done (and chunk-0 loads landed)
+#pragma unroll
+        for (int s = 0; s < MAXA; ++s) MCVD_WRITE_A_SLOT(0, s, sA);
+        if (nchunks > 1) MCVD_LOAD_A(1);
+        __syncthreads();
+        MCVD_STAMP(0)
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const bool more = ch + 1 < nchunks;
+            if (more) MCVD_DMA_W(ch + 1);                       // into the weight buffer chunk ch-1 just released
+            const float* sAc = sA + ((ch & 1) ? CK * g.PS : 0);
+            float* sAn = sA + ((ch & 1) ? 0 : CK * g.PS);
+            const float* sWc = sW + ((ch & 1) ? Cfg::WSZ : 0);
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                const int tapoff = ((tap / 3) - 1) * g.P + ((tap % 3) - 1);
+#pragma unroll
+                for (int kp = 0; kp < CK / 2; ++kp) {
+                    float aw[COT], bx[PXT];
+#pragma unroll
+                    for (int ct = 0; ct < COT; ++ct) aw[ct] = sWc[(2 * kp * KK + tap) * BCO + ct * 32 + woff];
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt) bx[pt] = sAc[2 * kp * g.PS + pixoff[pt] + tapoff];
+#pragma unroll
+                    for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < PXT; ++pt)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ct], bx[pt], acc[ct][pt], 0, 0, 0);
+                }
+                // staging work for the NEXT chunk rides between the MFMAs of this one (VALU/LDS-write vs matrix pipe)
+                if (more && tap >= 1 && tap <= MAXA) MCVD_WRITE_A_SLOT(ch + 1, tap - 1, sAn);
+                if (tap == MAXA + 1 && ch + 2 < nchunks) MCVD_LOAD_A(ch + 2);
+            }
+            MCVD_STAMP(1)
+            __syncthreads();          // chunk ch consumed by all waves; chunk ch+1 patch visible; its weight DMA landed
+            MCVD_STAMP(2)
+        }
+    } else {
     MCVD_LOAD_CHUNK(0);
     __syncthreads();              // zero fill done
     MCVD_WRITE_CHUNK(0);
     __syncthreads();
+    MCVD_STAMP(0)
 
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch + 1 < nchunks) MCVD_LOAD_CHUNK(ch + 1);
@@ -305,12 +423,18 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
                         acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ct], bx[pt], acc[ct][pt], 0, 0, 0);
             }
         }
+        MCVD_STAMP(1)
         __syncthreads();
+        MCVD_STAMP(2)
         if (ch + 1 < nchunks) {
             MCVD_WRITE_CHUNK(ch + 1);
+            MCVD_STAMP(3)
             __syncthreads();
+            MCVD_STAMP(4)
         }
     }
+    }
+    unsigned long long t_loop_end = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---------------- split-K reduction across the 4 waves (through LDS) ----------------
     // Wave 0 is the reducer; it also adds bias + residual here, one 32x32 tile per round, so only 16 (unconditional)
@@ -351,6 +475,7 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
             }
         if (wave != 0) return;
     }
+    const unsigned long long t_red_end = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---------------- epilogue: scale, coalesced NCHW stores (bias/residual are already in the accumulators)
 #pragma unroll
@@ -366,10 +491,17 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
             }
         }
     }
+    if (a.dbg && tid == 0) {
+        const unsigned long long te = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = a.dbg + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        d[0] = tacc[0]; d[1] = tacc[1]; d[2] = tacc[2]; d[3] = tacc[3]; d[4] = tacc[4];
+        d[5] = t_red_end - t_loop_end; d[6] = te - t_red_end; d[7] = te - tk0;
+    }
+#undef MCVD_STAMP
 }
 
 // Host-side geometry + launch for one instantiation.
-template <int KS, int CK, int COT, int PXT, bool SPLIT, bool WDMA>
+template <int KS, int CK, int COT, int PXT, bool SPLIT, bool WDMA, bool WDBF = false>
 int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     using Cfg = ConvCfg<KS, CK, COT, PXT, SPLIT>;
     ConvGeom g;
@@ -380,13 +512,14 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     MCVD_REQUIRE(g.RT % g.rpi == 0 && a.H % g.rpi == 0, "conv: tile rows %d vs H=%d", g.RT, a.H);
     g.nimg = g.RT / g.rpi;
     if (Cfg::HALO) {
-        g.P = (a.W == 8) ? 20 : a.W + 8;
+        // row = [3 pad | left halo | W pixels]; the right halo of a row is the (always zero) first pad slot of the next row
+        g.P = (a.W == 8) ? 20 : a.W + 4;
         g.IS = (g.rpi + 2) * g.P;
     } else {
         g.P = a.W;
         g.IS = g.rpi * g.P;
     }
-    g.PS = round_up(g.nimg * g.IS, 4);
+    g.PS = round_up(g.nimg * g.IS + (Cfg::HALO ? 4 : 0), 4);    // +4: the last row's right halo spills one slot past IS
     const long rows = (long)a.B * a.H;
     g.n_ptiles = (int)((rows + g.RT - 1) / g.RT);
     const int countA = CK * g.nimg * (g.rpi + 2 * Cfg::HALO) * (a.W / 4);
@@ -394,19 +527,21 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     MCVD_REQUIRE((double)a.B * a.Cout * a.H * a.W < 4.0e9, "conv: output tensor exceeds 32-bit element offsets");
     MCVD_REQUIRE(a.CinP % CK == 0 && a.CoutP % Cfg::BCO == 0, "conv: packed dims (%d,%d) vs chunk %d tile %d",
                  a.CinP, a.CoutP, CK, Cfg::BCO);
-    size_t lds = (size_t)(CK * g.PS + ((WDMA && Cfg::WDB) ? 2 : 1) * Cfg::WSZ) * sizeof(float);
+    constexpr bool WDB = WDMA && (Cfg::WDB || WDBF);
+    constexpr bool PIPE2 = MCVD_CONV_PIPE2 && (KS == 3) && !SPLIT && WDB;
+    size_t lds = (size_t)((PIPE2 ? 2 : 1) * CK * g.PS + (WDB ? 2 : 1) * Cfg::WSZ) * sizeof(float);
     if (SPLIT && lds < 3 * 1024 * sizeof(float)) lds = 3 * 1024 * sizeof(float);
     MCVD_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu > 160KiB", lds);
     if (lds > 64 * 1024) {      // above the default dynamic-LDS limit: opt in once per instantiation
         static bool raised = false;
         if (!raised) {
-            MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, CK, COT, PXT, SPLIT, WDMA>),
+            MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, CK, COT, PXT, SPLIT, WDMA, WDBF>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             raised = true;
         }
     }
     dim3 grid(g.n_ptiles, a.CoutP / Cfg::BCO);
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, CK, COT, PXT, SPLIT, WDMA>), grid, dim3(256), lds, s, a, g);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, CK, COT, PXT, SPLIT, WDMA, WDBF>), grid, dim3(256), lds, s, a, g);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -421,6 +556,9 @@ int conv_mfma_dispatch_shape(const ConvArgs& a, int shape, hipStream_t s) {
         case 1: return dma ? conv_mfma_launch<KS, CK, COT, 1, false, true>(a, s) : conv_mfma_launch<KS, CK, COT, 1, false, false>(a, s);   // 128-pixel tile
         // 64-pixel tile, the 4 waves split K; 3x3 uses a 16-channel chunk there (more MFMAs per barrier; CinP is packed to 16)
         case 2: return dma ? conv_mfma_launch<KS, CK2, COT, 2, true, true>(a, s) : conv_mfma_launch<KS, CK2, COT, 2, true, false>(a, s);
+        // same split-K tile with the (large) weight chunk double-buffered: one block per CU, but the ~100-cycle-per-KiB DMA issue
+        // and its latency ride under the MFMAs -- for layers that have <= 256 tiles anyway (8x8 at B=64)
+        case 3: return conv_mfma_launch<KS, CK2, COT, 2, true, true, true>(a, s);
     }
     set_error("conv: bad shape id %d", shape);
     return -1;

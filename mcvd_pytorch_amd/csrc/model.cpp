@@ -662,9 +662,10 @@ int mcvd_model::autotune(int B) {
             std::pair<int, int> choice{-1, op.cot};
             const int cots[2] = {op.cot, 1};
             for (int ci = 0; ci < (op.cot == 1 ? 1 : 2); ++ci) {
-                for (int shape = 0; shape < 3; ++shape) {
+                for (int shape = 0; shape < 4; ++shape) {
                     a.cot = cots[ci];
                     a.shape_hint = shape;
+                    if (shape == 3 && (op.ks != 3 || !ctx->conv_wdma)) continue;      // 3 = split-K with double-buffered weights
                     const int bpx = shape == 0 ? 256 : shape == 1 ? 128 : 64;
                     const bool fits = bpx % op.W == 0 && (bpx / op.W <= op.H ? op.H % (bpx / op.W) == 0 : (bpx / op.W) % op.H == 0);
                     if (!fits) continue;

@@ -20,6 +20,7 @@ struct mcvd_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int autotune = 1;              // time the conv tile candidates per distinct layer shape on first use of a batch size
     int profile = 0;               // record HIP events around every op of the first forward of each sampler call
+    unsigned long long* dbg = nullptr;   // conv phase-timing buffer for mcvd_op_conv2d (diagnostics)
     float* scratch = nullptr;      // small device scratch for stand-alone ops (kernel taps, packed weights)
     size_t scratch_bytes = 0;
     int ensure_scratch(size_t bytes);

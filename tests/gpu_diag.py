@@ -154,10 +154,49 @@ def sweep(f):
     ctx.opt("conv_wdma", 1)
 
 
+
+
+def phases(f):
+    """Where a conv block's time goes: per-phase shader-cycle counters of wave 0 (mcvd_ctx_set_debug_buffer)."""
+    from tests.hiputil import Ctx, P
+    ctx = Ctx()
+    B = 64
+    names = ["prologue", "mfma", "barrier1(+vmcnt)", "stage-write", "barrier2", "splitK-reduce", "epilogue", "total"]
+    cases = [(96, 96, 64, 3, 0, 0), (96, 96, 64, 3, 1, 0), (192, 192, 32, 3, 0, 0), (480, 192, 32, 3, 0, 0), (288, 288, 16, 3, 0, 1),
+             (288, 288, 16, 3, 0, 2), (384, 384, 8, 3, 0, 2), (384, 384, 8, 3, 0, 3), (768, 384, 8, 3, 0, 2), (768, 384, 8, 3, 0, 3), (192, 576, 32, 1, 0, 1), (192, 192, 32, 1, 1, 1)]
+    f.write("# conv phase breakdown, B=64 (cycles of wave 0, mean over blocks; % of the block's total)\n")
+    for cin, cout, H, ks, use_res, shape in cases:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, ks, ks, device="cuda") / (cin * ks * ks) ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda")
+        res = torch.randn(B, cout, H, H, device="cuda") if use_res else None
+        dbg = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
+        ctx.opt("conv_shape", shape)
+        for _ in range(2):
+            ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
+        _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
+        e1.record()
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
+        d = dbg.view(-1, 8).cpu().double()
+        d = d[d[:, 7] > 0]
+        m = d.mean(0)
+        f.write(f"cin{cin} cout{cout} H{H} k{ks} res{use_res} shape{shape}: {d.shape[0]} blocks, kernel {e0.elapsed_time(e1) * 1e3:.0f} us, "
+                f"block total {m[7]:.0f} cyc ({m[7] / 2400:.1f} us @2.4GHz) | " +
+                " ".join(f"{n} {100 * m[i] / m[7]:.1f}%" for i, n in enumerate(names[:7])) + "\n")
+        f.flush()
+    ctx.opt("conv_shape", -1)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["precision", "ops", "sweep"]
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
+

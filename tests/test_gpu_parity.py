@@ -48,6 +48,8 @@ CONV_CASES = [
     (5, 40, 24, 96, 8, 3, True, 1, True, 0),        # 8x8: several images per tile, B not a multiple of the tile
     (5, 40, 24, 96, 8, 3, True, 1, True, 1),
     (5, 40, 24, 96, 8, 3, True, 1, True, 2),
+    (5, 40, 24, 96, 8, 3, True, 1, True, 3),        # split-K with the double-buffered weight chunk
+    (3, 192, 0, 192, 16, 3, True, 1, True, 3),
     (2, 96, 0, 5, 64, 3, True, 1, False, -1),       # final conv, Cout=5
     (1, 32, 0, 32, 128, 3, True, 1, True, 0),       # 128x128 rows
     (1, 32, 0, 32, 128, 3, True, 1, True, 1),

@@ -29,9 +29,9 @@ def conv_emulate(x0, x1, wp, bias, coef, act, res, scale, Cout, CoutP, CinP, ks,
     RT = BPX // W
     rpi = min(RT, H)
     nimg = RT // rpi
-    P = ((20 if W == 8 else W + 8) if HALO else W)
+    P = ((20 if W == 8 else W + 4) if HALO else W)
     IS = (rpi + 2 * HALO) * P
-    PS = (nimg * IS + 3) // 4 * 4
+    PS = (nimg * IS + (4 if HALO else 0) + 3) // 4 * 4
     HW = H * W
     MAXA = 4 if ks == 3 else (CK * BPX // 4 + 255) // 256
     WCOUNT = CK * KK * BCO // 4
