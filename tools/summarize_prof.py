@@ -11,10 +11,11 @@ OUT = os.path.join(ROOT, "gpurun_out")
 
 
 def short(name):
-    m = re.match(r".*conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>.*", name)
+    m = re.match(r".*conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+)(?:, (\w+))?>.*", name)
     if m:
-        ks, ck, cot, pxt, split, dma = m.groups()
-        return f"conv_mfma<{ks}x{ks},CK{ck},co{32 * int(cot)},px{(1 if split == 'true' else 4) * 32 * int(pxt)}{',splitK' if split == 'true' else ''}{',dma' if dma == 'true' else ''}>"
+        ks, ck, cot, pxt, split, dma, wdbf = m.groups()
+        return (f"conv_mfma<{ks}x{ks},CK{ck},co{32 * int(cot)},px{(1 if split == 'true' else 4) * 32 * int(pxt)}"
+                f"{',splitK' if split == 'true' else ''}{',dma' if dma == 'true' else ''}{',wdb' if wdbf == 'true' else ''}>")
     m = re.match(r".*mcvd::(\w+)(<[^>]*>)?\(.*", name)
     if m:
         return m.group(1) + (m.group(2) or "")
