@@ -43,6 +43,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     c->stream = (hipStream_t)hip_stream;
     if (const char* t = getenv("MCVD_AUTOTUNE")) c->autotune = atoi(t);
     if (const char* t = getenv("MCVD_SIDE_STREAM")) c->side_stream = atoi(t);
+    if (const char* t = getenv("MCVD_WINOGRAD")) c->winograd = atoi(t);
     const char* e = getenv("MCVD_NAIVE");
     if (e) {
         const int v = atoi(e);
@@ -85,6 +86,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "conv_wdma")) ctx->conv_wdma = value;
     else if (!strcmp(key, "autotune")) ctx->autotune = value;
     else if (!strcmp(key, "side_stream")) ctx->side_stream = value;
+    else if (!strcmp(key, "winograd")) ctx->winograd = value;
     else {
         set_error("unknown option '%s'", key);
         return MCVD_EINVAL;
@@ -239,6 +241,8 @@ int mcvd_model_finalize(mcvd_model* m) {
                 return rc;
             MCVD_HIP_CHECK(hipMemcpyAsync(m->packed + p.bias + j * p.Cout_each, m->blob + b.off,
                                           (size_t)p.Cout_each * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (p.wpw >= 0)
+                if (int rc = launch_pack_wino_weight(m->blob + w.off, m->packed + p.wpw, p.Cout_each, p.Cin, p.CoutP, s)) return rc;
         }
     }
     for (const DenseEntry& e : m->dense) {
@@ -501,8 +505,14 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.CinP = round_up(a.Cin, conv_chunk(ks));
     a.CoutP = round_up(Cout, 32 * a.cot);
     const size_t wfloats = (size_t)a.CinP * ks * ks * a.CoutP;
-    if (int rc = ctx->ensure_scratch((wfloats + a.CoutP) * sizeof(float))) return rc;
-    MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP) * sizeof(float), ctx->stream));
+    const bool wino = ctx->conv_shape == 4 && conv_wino_supported(ks, H, W);
+    const size_t ufloats = wino ? (size_t)a.CinP * 16 * a.CoutP : 0;
+    if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats) * sizeof(float))) return rc;
+    MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP + ufloats) * sizeof(float), ctx->stream));
+    if (wino) {
+        if (int rc = launch_pack_wino_weight(w, ctx->scratch + wfloats + a.CoutP, Cout, a.Cin, a.CoutP, ctx->stream)) return rc;
+        a.wpw = ctx->scratch + wfloats + a.CoutP;
+    }
     if (int rc = launch_pack_conv_weight(w, ctx->scratch, Cout, a.Cin, ks, a.CinP, a.CoutP, 0, 0, ctx->stream)) return rc;
     MCVD_HIP_CHECK(hipMemcpyAsync(ctx->scratch + wfloats, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     a.wp = ctx->scratch;

@@ -39,6 +39,7 @@ struct ConvArgs {
     const float* coef;    // [B][Cin][2] per-(sample,channel) affine (A,B), or null
     int act;              // SiLU after the affine
     const float* wp;      // packed weights
+    const float* wpw;     // Winograd-transformed packed weights Up[(cin*16 + xi)*CoutP + cout] (3x3 only), or null
     const float* bias;    // [Cout]
     const float* res;     // residual [B][Cout][H][W] or null
     float out_scale;
@@ -54,6 +55,10 @@ int conv_cout_tile(int Cout);                 // 32-channel units per block alon
 int conv_chunk(int ks);                       // input-channel chunk the MFMA kernel consumes per stage
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 int launch_conv_naive(const ConvArgs& a, hipStream_t s);
+// Winograd F(2x2,3x3) variant (conv_wino.cpp): tile shape id 4 of the dispatcher
+bool conv_wino_supported(int ks, int H, int W);
+int launch_conv_wino(const ConvArgs& a, hipStream_t s);
+int launch_pack_wino_weight(const float* w, float* up, int Cout, int Cin, int CoutP, hipStream_t s);
 // repack reference-layout weights [Cout][Cin][ks][ks] (or NIN [Cin][Cout] when nin=1) -> packed layout above
 int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, int CinP, int CoutP, int nin,
                             int cout_off, hipStream_t s);

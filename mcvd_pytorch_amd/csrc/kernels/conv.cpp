@@ -31,6 +31,7 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     auto blocks = [&](int bpx) { return ((px + bpx - 1) / bpx) * ntc; };
     auto fits = [&](int bpx) { return bpx % a.W == 0 && (bpx / a.W <= a.H ? a.H % (bpx / a.W) == 0 : (bpx / a.W) % a.H == 0); };
     int shape;
+    if (a.shape_hint == 4) return launch_conv_wino(a, s);          // Winograd F(2x2,3x3)
     const int want = (a.shape_hint >= 0 && a.shape_hint <= 3) ? a.shape_hint : forced;
     if (want >= 0 && want <= 3 && fits(want == 0 ? 256 : want == 1 ? 128 : 64)) shape = want;
     else if (fits(256) && blocks(256) >= min_blocks) shape = 0;

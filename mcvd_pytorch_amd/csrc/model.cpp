@@ -168,6 +168,9 @@ struct Builder {
         p.CoutP = round_up(Cout, 32 * cot);
         p.wp = alloc_packed((int64_t)p.CinP * ks * ks * p.CoutP);
         p.bias = alloc_packed(p.CoutP);
+        if (wnames.size() == 1 && !nin && conv_wino_supported(ks, op.H, op.W))
+            p.wpw = alloc_packed((int64_t)p.CinP * 16 * p.CoutP);
+        op.wpw = p.wpw;
         m.packs.push_back(p);
         op.ks = ks;
         op.Cout = Cout;
@@ -569,6 +572,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const int64_t* lab, cons
             a.coef = op.coef.kind == REF_NONE ? nullptr : resolve(op.coef, x, cond, out, B);
             a.act = op.act;
             a.wp = packed + op.wp;
+            a.wpw = op.wpw >= 0 ? packed + op.wpw : nullptr;
             a.bias = packed + op.bias;
             a.res = op.res.kind == REF_NONE ? nullptr : resolve(op.res, x, cond, out, B);
             a.out_scale = op.out_scale;
@@ -652,6 +656,7 @@ int mcvd_model::autotune(int B) {
             a.coef = op.coef.kind == REF_NONE ? nullptr : resolve(op.coef, scratch_io, scratch_io, scratch_io, B);
             a.act = op.act;
             a.wp = packed + op.wp;
+            a.wpw = op.wpw >= 0 ? packed + op.wpw : nullptr;
             a.bias = packed + op.bias;
             a.res = op.res.kind == REF_NONE ? nullptr : resolve(op.res, scratch_io, scratch_io, scratch_io, B);
             a.out_scale = op.out_scale;
@@ -662,13 +667,14 @@ int mcvd_model::autotune(int B) {
             std::pair<int, int> choice{-1, op.cot};
             const int cots[2] = {op.cot, 1};
             for (int ci = 0; ci < (op.cot == 1 ? 1 : 2); ++ci) {
-                for (int shape = 0; shape < 4; ++shape) {
+                for (int shape = 0; shape < 5; ++shape) {
                     a.cot = cots[ci];
                     a.shape_hint = shape;
                     if (shape == 3 && (op.ks != 3 || !ctx->conv_wdma)) continue;      // 3 = split-K with double-buffered weights
+                    if (shape == 4 && (ci > 0 || !a.wpw || !ctx->winograd)) continue;  // 4 = Winograd F(2x2,3x3), own cout tile
                     const int bpx = shape == 0 ? 256 : shape == 1 ? 128 : 64;
                     const bool fits = bpx % op.W == 0 && (bpx / op.W <= op.H ? op.H % (bpx / op.W) == 0 : (bpx / op.W) % op.H == 0);
-                    if (!fits) continue;
+                    if (shape != 4 && !fits) continue;
                     if (launch_conv_mfma(a, s)) continue;                 // warm-up (and validity check)
                     MCVD_HIP_CHECK(hipEventRecord(e0, s));
                     for (int r = 0; r < 3; ++r)

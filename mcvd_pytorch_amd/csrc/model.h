@@ -14,6 +14,7 @@ struct mcvd_ctx {
     int naive_attn = 0;
     int graph = 0;
     int conv_shape = -1;           // -1 auto, 0/1/2 force a conv tile shape (tests)
+    int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
     int conv_wdma = 1;             // weight chunks by LDS-DMA (1) or register staging (0)
     int side_stream = 0;           // 1: run the ResBlock shortcut 1x1 convs on a second stream (measured -2 %: off by default)
     hipStream_t side = nullptr;
@@ -63,6 +64,7 @@ struct Op {
     int act = 0;
     // conv
     int64_t wp = -1, bias = -1;    // packed blob offsets
+    int64_t wpw = -1;              // Winograd-transformed weights (3x3 convs at supported resolutions), else -1
     int CinP = 0, CoutP = 0, cot = 0;
     float out_scale = 1.f;
     // fir
@@ -88,6 +90,7 @@ struct ConvPack {
     std::vector<std::string> biases;
     int Cout_each, Cin, ks, CinP, CoutP, nin;
     int64_t wp, bias;
+    int64_t wpw = -1;
 };
 
 }  // namespace mcvd

@@ -120,7 +120,7 @@ def sweep(f):
     shapes = [(96, 96, 64, 3), (192, 96, 64, 3), (288, 96, 64, 3), (192, 192, 32, 3), (480, 192, 32, 3), (288, 288, 16, 3),
               (672, 288, 16, 3), (384, 384, 8, 3), (768, 384, 8, 3), (192, 576, 32, 1), (288, 864, 16, 1), (384, 1152, 8, 1),
               (96, 192, 32, 1), (768, 384, 8, 1)]
-    f.write("# conv tile sweep at B=64: Cin Cout H ks res | shape0(256px) shape1(128px) shape2(64px split-K): us, TFLOP/s ; wdma=0 then wdma=1\n")
+    f.write("# conv tile sweep at B=64: Cin Cout H ks res | shape0(256px) shape1(128px) shape2(64px split-K) [shape3 split-K+wdb, shape4 Winograd]: us, effective TFLOP/s (direct-conv flops) ; wdma=0 then wdma=1\n")
     shapes = [(c, o, h, k, r) for (c, o, h, k) in shapes for r in ((0, 1) if k == 3 and c == o else (0,))]
     for cin, cout, H, ks, use_res in shapes:
         x = torch.randn(B, cin, H, H, device="cuda")
@@ -132,7 +132,9 @@ def sweep(f):
         line = f"{cin:4d} {cout:4d} {H:3d} k{ks} r{use_res} |"
         for wdma in (0, 1):
             ctx.opt("conv_wdma", wdma)
-            for shape in (0, 1, 2):
+            for shape in ((0, 1, 2, 3, 4) if ks == 3 else (0, 1, 2)):
+                if shape >= 3 and wdma == 0:
+                    continue
                 ctx.opt("conv_shape", shape)
                 try:
                     for _ in range(2):

@@ -53,6 +53,12 @@ CONV_CASES = [
     (2, 96, 0, 5, 64, 3, True, 1, False, -1),       # final conv, Cout=5
     (1, 32, 0, 32, 128, 3, True, 1, True, 0),       # 128x128 rows
     (1, 32, 0, 32, 128, 3, True, 1, True, 1),
+    (2, 96, 0, 96, 64, 3, True, 1, True, 4),        # Winograd F(2x2,3x3): ResBlock Conv_1 @64
+    (2, 10, 0, 96, 64, 3, False, 0, False, 4),      # Winograd: stem (Cin not a multiple of the chunk)
+    (3, 192, 96, 192, 32, 3, True, 1, False, 4),    # Winograd: up-path concat input
+    (3, 64, 0, 128, 16, 3, True, 1, True, 4),       # Winograd: 64-channel cout tile
+    (2, 96, 0, 5, 64, 3, True, 1, False, 4),        # Winograd: final conv, Cout=5
+    (1, 32, 0, 32, 128, 3, True, 1, True, 4),       # Winograd: 128x128
     (2, 96, 0, 192, 32, 1, False, 0, False, -1),    # 1x1 shortcut
     (2, 96, 96, 192, 32, 1, False, 0, False, 0),    # 1x1 shortcut over a concat
     (2, 192, 0, 576, 32, 1, True, 0, False, 1),     # fused q|k|v projection with GN affine prologue (no SiLU)

@@ -52,3 +52,25 @@ def test_attention_index_maps(B, C, heads, S):
     want = torch.matmul(v, w.transpose(1, 2)).reshape(B, C, S)
     got = E.attn_emulate(qkv.numpy(), heads)
     np.testing.assert_allclose(got, want.numpy(), rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W,COT", [(1, 6, 5, 40, 16, 16, 2), (2, 8, 0, 96, 8, 32, 3), (1, 16, 8, 32, 16, 32, 1)])
+def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT):
+    """conv_wino.cpp: staging roles, U/V LDS layouts, MFMA lane maps, the LDS exchange and the 2x2 inverse transform."""
+    g = torch.Generator().manual_seed(4)
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    Cin = C0 + C1
+    w = torch.randn(Cout, Cin, 3, 3, generator=g)
+    bias = torch.randn(Cout, generator=g)
+    coef = torch.stack([1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], -1)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    CinP, CoutP = _round_up(Cin, 16), _round_up(Cout, 32 * COT)
+    up = E.pack_wino_weight(w.numpy(), CinP, CoutP)
+    got = E.wino_emulate(x0.numpy(), None if x1 is None else x1.numpy(), up, bias.numpy(), coef.numpy(), 1, res.numpy(), 0.5,
+                         Cout, CoutP, CinP, COT)
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    xin = xin * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]
+    xin = xin * torch.sigmoid(xin)
+    want = (F.conv2d(xin.double(), w.double(), bias.double(), padding=1) + res.double()) * 0.5
+    np.testing.assert_allclose(got, want.numpy(), rtol=1e-6, atol=1e-6)
