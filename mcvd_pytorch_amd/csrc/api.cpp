@@ -44,6 +44,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     if (const char* t = getenv("MCVD_AUTOTUNE")) c->autotune = atoi(t);
     if (const char* t = getenv("MCVD_SIDE_STREAM")) c->side_stream = atoi(t);
     if (const char* t = getenv("MCVD_WINOGRAD")) c->winograd = atoi(t);
+    if (const char* t = getenv("MCVD_CONV_DMA1")) c->conv_dma1 = atoi(t);
     const char* e = getenv("MCVD_NAIVE");
     if (e) {
         const int v = atoi(e);
@@ -87,6 +88,8 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "autotune")) ctx->autotune = value;
     else if (!strcmp(key, "side_stream")) ctx->side_stream = value;
     else if (!strcmp(key, "winograd")) ctx->winograd = value;
+    else if (!strcmp(key, "conv_dma1")) ctx->conv_dma1 = value;
+    else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
     else {
         set_error("unknown option '%s'", key);
         return MCVD_EINVAL;
@@ -518,6 +521,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.wp = ctx->scratch;
     a.bias = ctx->scratch + wfloats;
     a.shape_hint = ctx->conv_shape;
+    if (ctx->conv_shape == 5 && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
     a.wdma = ctx->conv_wdma;
     a.dbg = ctx->dbg;
     return ctx->naive_conv ? launch_conv_naive(a, ctx->stream) : launch_conv_mfma(a, ctx->stream);

@@ -47,7 +47,7 @@ struct ConvArgs {
     int B, Cin, CinP, Cout, CoutP, H, W;
     int ks;               // 1 or 3
     int cot;              // cout tile in units of 32 channels (1..4); CoutP % (32*cot) == 0
-    int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile (tests)
+    int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile, 3 split-K+WDB, 4 Winograd, 5 all-DMA 1x1 GEMM
     int wdma;             // 1: stage weight chunks by LDS-DMA (default), 0: through registers
     unsigned long long* dbg;   // optional: per-block phase cycle counters [n_blocks][8] (diagnostics), else null
 };
@@ -58,6 +58,10 @@ int launch_conv_naive(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2,3x3) variant (conv_wino.cpp): tile shape id 4 of the dispatcher
 bool conv_wino_supported(int ks, int H, int W);
 int launch_conv_wino(const ConvArgs& a, hipStream_t s);
+// all-DMA 1x1 GEMM (conv1x1_dma.cpp): tile shape id 5; cot_req <= 0 picks the default cout tile
+bool conv1x1_dma_supported(const ConvArgs& a);
+int conv1x1_dma_cout_tile(int CoutP);
+int launch_conv1x1_dma(const ConvArgs& a, int cot_req, hipStream_t s);
 int launch_pack_wino_weight(const float* w, float* up, int Cout, int Cin, int CoutP, hipStream_t s);
 // repack reference-layout weights [Cout][Cin][ks][ks] (or NIN [Cin][Cout] when nin=1) -> packed layout above
 int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, int CinP, int CoutP, int nin,

@@ -23,15 +23,23 @@ static int env_int(const char* name, int dflt) {
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     MCVD_REQUIRE(a.ks == 1 || a.ks == 3, "conv: kernel size %d unsupported", a.ks);
     MCVD_REQUIRE(a.W >= 8 && (a.W & (a.W - 1)) == 0 && a.W <= 256, "conv: W=%d must be a power of two in [8,256]", a.W);
-    MCVD_REQUIRE(a.cot >= 1 && a.cot <= 4, "conv: cout tile %d", a.cot);
     static const int forced = env_int("MCVD_CONV_SHAPE", -1);
     static const int min_blocks = env_int("MCVD_CONV_MIN_BLOCKS", 400);
     const long px = (long)a.B * a.H * a.W;
-    const int ntc = a.CoutP / (32 * a.cot);
+    const int ntc = a.CoutP / (32 * (a.cot > 0 ? a.cot : 1));
     auto blocks = [&](int bpx) { return ((px + bpx - 1) / bpx) * ntc; };
     auto fits = [&](int bpx) { return bpx % a.W == 0 && (bpx / a.W <= a.H ? a.H % (bpx / a.W) == 0 : (bpx / a.W) % a.H == 0); };
     int shape;
-    if (a.shape_hint == 4) return launch_conv_wino(a, s);          // Winograd F(2x2,3x3)
+    // hints 4 / 5 select the specialised kernels where they apply and fall back to the tile heuristic elsewhere
+    if (a.shape_hint == 4 && conv_wino_supported(a.ks, a.H, a.W) && a.wpw && (a.C1 == 0 || a.C0 % 8 == 0))
+        return launch_conv_wino(a, s);                              // Winograd F(2x2,3x3)
+    if (a.shape_hint == 5 && conv1x1_dma_supported(a)) return launch_conv1x1_dma(a, a.cot, s);   // all-DMA 1x1 GEMM
+    if (a.cot < 1 || a.cot > 4 || a.CoutP % (32 * a.cot) != 0) {   // a cout tile meant for another kernel: use this one's
+        ConvArgs b = a;
+        b.cot = conv_cout_tile(a.Cout);
+        if (a.CoutP % (32 * b.cot) != 0) b.cot = 1;
+        return launch_conv_mfma(b, s);
+    }
     const int want = (a.shape_hint >= 0 && a.shape_hint <= 3) ? a.shape_hint : forced;
     if (want >= 0 && want <= 3 && fits(want == 0 ? 256 : want == 1 ? 128 : 64)) shape = want;
     else if (fits(256) && blocks(256) >= min_blocks) shape = 0;

@@ -19,18 +19,21 @@
 //     position values (conflict-free) into the double-buffered V.  Two barriers per chunk, both between MFMA groups.
 //   * epilogue: per 32-cout sub-tile the 16 position planes go through LDS, each thread inverse-transforms 2 (cout, tile)
 //     pairs (A^T M A), adds bias (+ residual), scales, and stores 2x2 pixels as two 8-byte stores.
+#include <stdlib.h>
+
 #include "../common.h"
 
 namespace mcvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 constexpr int WINO_CK = 8;       // input channels per chunk
 constexpr int WINO_T = 32;       // tiles per workgroup (4 x 8)
 
-template <int COT>
+template <int COT, int PRO, int VAR>     // PRO: 0 raw input, 1 affine, 2 affine + SiLU;  VAR: software-pipeline variant (see the K loop)
 __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
     constexpr int NT = 512;
     constexpr int CK = WINO_CK, T = WINO_T, BCO = 32 * COT;
@@ -46,7 +49,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
     constexpr int MAXP = (PCOUNT + 511) / 512;
     float* sU = smem;                           // [2][USZ]
     float* sV = smem + 2 * USZ;                 // [2][VSZ]
-    float* sP = smem + 2 * USZ + 2 * VSZ;       // [PSZ] + 4 floats of dump space for unused patch slots
+    constexpr int PBUF = PSZ + 4;               // + 4 floats of dump space for unused patch slots
+    float* sP = smem + 2 * USZ + 2 * VSZ;       // [2][PBUF]: patch(ch+2) is written while patch(ch+1) is transformed
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int H = a.H, W = a.W, HW = H * W, Cin = a.Cin;
@@ -63,7 +67,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
     const int p_rd = s_ci * 10 * PP + (2 * s_ty + s_h) * PP + 2 * s_tx;        // rows s_h..s_h+2 of the 4x4 window in the LDS patch
 
     // ---- patch-load slots (chunk invariant): element e -> (channel, patch row, patch col)
-    int p_lds[MAXP], p_goff[MAXP], p_ci[MAXP];      // p_ci = channel-in-chunk | (inside image) << 8 ; -1 = unused slot
+    // p_ci = channel-in-chunk, or CK + channel-in-chunk when the element is zero padding / an unused slot
+    int p_lds[MAXP], p_goff[MAXP], p_ci[MAXP];
 #pragma unroll
     for (int sl = 0; sl < MAXP; ++sl) {
         const int e = sl * NT + tid;
@@ -74,9 +79,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
             const bool inside = y >= 0 && y < H && x >= 0 && x < W;
             p_lds[sl] = ci * 10 * PP + r * PP + c;
             p_goff[sl] = min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-            p_ci[sl] = ci | (inside ? 256 : 0);
+            p_ci[sl] = ci + (inside ? 0 : CK);
         } else {
-            p_lds[sl] = PSZ; p_goff[sl] = 0; p_ci[sl] = -1;         // unused slot: harmless load, store into the dump word
+            p_lds[sl] = PSZ; p_goff[sl] = 0; p_ci[sl] = CK;         // unused slot: harmless load, store into the dump word
         }
     }
 
@@ -100,40 +105,46 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
                 (const __attribute__((address_space(1))) void*)(usrc + u_goff[s]),                              \
                 (__attribute__((address_space(3))) void*)(udst + (s * NT + wave * 64) * 4), 16, 0, 0);          \
     }
-    /* issue the (unconditional, clamped) loads of the raw input patch of chunk `ch` */
+    /* issue the (unconditional, clamped) loads of the raw input patch of chunk `ch`.  The chunk never straddles the     \
+       concat seam (launch check), so source tensor and base are wave-uniform; channels past Cin re-read the last one. */ \
 #define WINO_LOAD_P(ch)                                                                                         \
     {                                                                                                           \
+        const int cb = min((ch) * CK, Cin - 1);                                                                 \
+        const int cmax = Cin - 1 - cb;                        /* last valid channel-in-chunk (>= 0) */           \
+        const bool second = cb >= a.C0;                                                                         \
+        const float* srcb = second ? a.x1 + ((long)b * a.C1 + (cb - a.C0)) * HW : a.x0 + ((long)b * a.C0 + cb) * HW; \
+        const bool hc = PRO && a.coef;               /* SiLU without an affine: identity coefficients */        \
+        const float* cfb = hc ? a.coef + ((long)b * Cin + cb) * 2 : a.wpw;                                      \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
-            const int c = (ch) * CK + (p_ci[sl] & 255);                                                         \
-            const int cc = (p_ci[sl] >= 0 && c < Cin) ? c : 0;                                                  \
-            const float* src = (cc < a.C0) ? a.x0 + ((long)b * a.C0 + cc) * HW                                  \
-                                           : a.x1 + ((long)b * a.C1 + (cc - a.C0)) * HW;                        \
-            pd[sl] = src[p_goff[sl]];                                                                           \
-            const float* cs = a.coef ? a.coef + ((long)b * Cin + cc) * 2 : a.bias;                              \
-            pA[sl] = cs[0];                                                                                     \
-            pB[sl] = cs[1];                                                                                     \
+            const int cl = min(p_ci[sl] & (CK - 1), cmax);                                                      \
+            pd[sl] = srcb[cl * HW + p_goff[sl]];                                                                \
+            const f32x2 cf = *reinterpret_cast<const f32x2*>(cfb + (hc ? cl * 2 : 0));                          \
+            pA[sl] = hc ? cf.x : 1.0f;                                                                          \
+            pB[sl] = hc ? cf.y : 0.0f;                                                                          \
         }                                                                                                       \
     }
     /* activate once per pixel and park the patch in LDS (zero padding applies AFTER the activation) */
 #define WINO_WRITE_P(ch)                                                                                        \
     {                                                                                                           \
+        float* sPw = sP + (((ch) & 1) ? PBUF : 0);                                                              \
+        const int nvalid = Cin - (ch) * CK;                   /* channels-in-chunk below this are real */         \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
             float v = pd[sl];                                                                                   \
-            if (a.coef) v = v * pA[sl] + pB[sl];                                                                \
-            if (a.act) v = silu_w(v);                                                                           \
-            const bool live = (p_ci[sl] >= 0) && (p_ci[sl] & 256) && ((ch) * CK + (p_ci[sl] & 255) < Cin);      \
-            sP[p_lds[sl]] = live ? v : 0.0f;                                                                    \
+            if (PRO >= 1) v = v * pA[sl] + pB[sl];                                                              \
+            if (PRO == 2) v = silu_w(v);                                                                        \
+            sPw[p_lds[sl]] = (p_ci[sl] < min(nvalid, CK)) ? v : 0.0f;                                           \
         }                                                                                                       \
     }
     /* B^T d B, two of the four rows of B^T d per thread (s_h), -> 8 of the 16 position planes of V(ch) */
 #define WINO_WRITE_V(ch)                                                                                        \
     {                                                                                                           \
         float* vdst = sV + (((ch) & 1) ? VSZ : 0) + s_ci * 16 * T + s_tile;                                     \
+        const float* sPr = sP + (((ch) & 1) ? PBUF : 0);                                                        \
         float ra[4], rb[4], rcc[4];                               /* window rows s_h, s_h+1, s_h+2 */           \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-            ra[j] = sP[p_rd + j];                                                                               \
-            rb[j] = sP[p_rd + PP + j];                                                                          \
-            rcc[j] = sP[p_rd + 2 * PP + j];                                                                     \
+            ra[j] = sPr[p_rd + j];                                                                              \
+            rb[j] = sPr[p_rd + PP + j];                                                                         \
+            rcc[j] = sPr[p_rd + 2 * PP + j];                                                                    \
         }                                                                                                       \
         float mA[4], mB[4];              /* s_h=0: rows 0 (t0-t2), 1 (t1+t2)   s_h=1: rows 3 (t1-t3), 2 (t2-t1) */ \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
@@ -169,28 +180,94 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[q][ct][r] = 0.0f;
 
     const int nchunks = a.CinP / CK;
-    WINO_DMA_U(0);
-    WINO_LOAD_P(0);
-    WINO_WRITE_P(0);
-    __syncthreads();                       // patch(0) visible
-    WINO_WRITE_V(0);
-    if (nchunks > 1) WINO_LOAD_P(1);
-    __syncthreads();                       // V(0) visible, U(0) landed (the fence drains the DMA)
-
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const bool more = ch + 1 < nchunks;
-        if (more) WINO_DMA_U(ch + 1);
-        const float* sUc = sU + ((ch & 1) ? USZ : 0);
-        const float* sVc = sV + ((ch & 1) ? VSZ : 0);
-        WINO_MFMA(0)
-        if (more) WINO_WRITE_P(ch + 1);    // registers were loaded during the previous chunk
-        WINO_MFMA(1)
-        __syncthreads();                   // patch(ch+1) visible to the tile transforms
-        if (ch + 2 < nchunks) WINO_LOAD_P(ch + 2);
-        WINO_MFMA(2)
-        if (more) WINO_WRITE_V(ch + 1);
-        WINO_MFMA(3)
-        __syncthreads();                   // chunk ch consumed by every wave; V(ch+1) visible; U(ch+1) landed
+    if (VAR == 0) {
+        // two barriers per chunk: patch(ch+1) is written before the mid-chunk barrier and transformed after it
+        WINO_DMA_U(0);
+        WINO_LOAD_P(0);
+        WINO_WRITE_P(0);
+        __syncthreads();                       // patch(0) visible
+        WINO_WRITE_V(0);
+        WINO_LOAD_P(1);
+        __syncthreads();                       // V(0) visible, U(0) landed (the fence drains the DMA)
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const bool more = ch + 1 < nchunks;
+            if (more) WINO_DMA_U(ch + 1);
+            const float* sUc = sU + ((ch & 1) ? USZ : 0);
+            const float* sVc = sV + ((ch & 1) ? VSZ : 0);
+            WINO_MFMA(0)
+            if (more) WINO_WRITE_P(ch + 1);    // registers were loaded during the previous chunk
+            WINO_MFMA(1)
+            __syncthreads();                   // patch(ch+1) visible to the tile transforms
+            if (more) WINO_LOAD_P(ch + 2);
+            WINO_MFMA(2)
+            if (more) WINO_WRITE_V(ch + 1);
+            WINO_MFMA(3)
+            __syncthreads();                   // chunk ch consumed by every wave; V(ch+1) visible; U(ch+1) landed
+        }
+    } else {
+        // ONE barrier per chunk.  While the MFMAs consume (U, V)(ch): patch(ch+2) is activated out of the registers loaded
+        // one chunk earlier into the other patch buffer, the raw loads of patch(ch+3) and the DMA of U(ch+1) are issued (all
+        // at the top, so the barrier's vmcnt(0) never waits on a young load), V(ch+1) is made from patch(ch+1).
+        // Chunks past the end are staged as zeros (clamped loads), so the loop body carries no branches.
+        WINO_DMA_U(0);
+        WINO_LOAD_P(0);
+        WINO_WRITE_P(0);
+        WINO_LOAD_P(1);
+        __syncthreads();                       // patch(0) visible
+        WINO_WRITE_V(0);
+        WINO_WRITE_P(1);
+        WINO_LOAD_P(2);
+        __syncthreads();                       // V(0), patch(1) visible, U(0) landed
+        for (int ch = 0; ch + 1 < nchunks; ++ch) {
+            const float* sUc = sU + ((ch & 1) ? USZ : 0);
+            const float* sVc = sV + ((ch & 1) ? VSZ : 0);
+            WINO_WRITE_P(ch + 2);
+            WINO_LOAD_P(ch + 3);
+            WINO_DMA_U(ch + 1);
+            if (VAR == 2) {
+                // the two waves of a SIMD (w, w+4) run their VALU-heavy tile transforms at different points of the chunk
+                if (wave < 4) {
+                    WINO_MFMA(0)
+                    WINO_WRITE_V(ch + 1);
+                    WINO_MFMA(1)
+                    WINO_MFMA(2)
+                    WINO_MFMA(3)
+                } else {
+                    WINO_MFMA(0)
+                    WINO_MFMA(1)
+                    WINO_MFMA(2)
+                    WINO_WRITE_V(ch + 1);
+                    WINO_MFMA(3)
+                }
+            } else {
+                WINO_MFMA(0)
+                WINO_WRITE_V(ch + 1);
+                WINO_MFMA(1)
+                WINO_MFMA(2)
+                WINO_MFMA(3)
+                if (VAR == 3) {
+                    // pin an interleave: every MFMA is followed by a slice of the staging work of this iteration
+                    _Pragma("unroll") for (int i = 0; i < 8 * COT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
+                        __builtin_amdgcn_sched_group_barrier(0x002, 24 / COT, 0);   // VALU
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+                    }
+                }
+            }
+            __syncthreads();                   // chunk ch consumed by every wave; V(ch+1), patch(ch+2) visible; U(ch+1) landed
+        }
+        {
+            const int ch = nchunks - 1;
+            const float* sUc = sU + ((ch & 1) ? USZ : 0);
+            const float* sVc = sV + ((ch & 1) ? VSZ : 0);
+            WINO_MFMA(0)
+            WINO_MFMA(1)
+            WINO_MFMA(2)
+            WINO_MFMA(3)
+            __syncthreads();                   // the epilogue reuses the LDS
+        }
     }
 
     // ---------------- inverse transform + epilogue, one 32-cout sub-tile at a time ----------------
@@ -255,26 +332,50 @@ int conv_wino_cout_tile(int Cout) {
     return 1;
 }
 
-template <int COT>
-static int wino_launch(const ConvArgs& a, hipStream_t s) {
+static int env_int_w(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int COT, int PRO, int VAR>
+static int wino_launch3(const ConvArgs& a, hipStream_t s) {
     constexpr int BCO = 32 * COT;
-    const size_t lds = (size_t)(2 * WINO_CK * 16 * BCO + 2 * WINO_CK * 16 * WINO_T + WINO_CK * 10 * 20 + 4) * sizeof(float);
+    const size_t lds = (size_t)(2 * WINO_CK * 16 * BCO + 2 * WINO_CK * 16 * WINO_T + 2 * (WINO_CK * 10 * 20 + 4)) * sizeof(float);
     static bool raised = false;
     if (!raised) {
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<COT>),
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<COT, PRO, VAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
     dim3 grid(a.B * (a.H / 8) * (a.W / 16), a.CoutP / BCO);
-    hipLaunchKernelGGL(conv_wino_kernel<COT>, grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv_wino_kernel<COT, PRO, VAR>), grid, dim3(512), lds, s, a);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+template <int COT, int PRO>
+static int wino_launch2(const ConvArgs& a, hipStream_t s) {
+    static const int var = env_int_w("MCVD_WINO_VAR", 2);
+    switch (var) {
+        case 0: return wino_launch3<COT, PRO, 0>(a, s);
+        case 3: return wino_launch3<COT, PRO, 3>(a, s);
+        case 1: return wino_launch3<COT, PRO, 1>(a, s);
+        default: return wino_launch3<COT, PRO, 2>(a, s);
+    }
+}
+
+template <int COT>
+static int wino_launch(const ConvArgs& a, hipStream_t s) {
+    if (!a.coef && !a.act) return wino_launch2<COT, 0>(a, s);
+    if (!a.act) return wino_launch2<COT, 1>(a, s);
+    return wino_launch2<COT, 2>(a, s);
 }
 
 int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
     MCVD_REQUIRE(conv_wino_supported(a.ks, a.H, a.W), "winograd conv: ks=%d H=%d W=%d unsupported", a.ks, a.H, a.W);
     MCVD_REQUIRE(a.wpw, "winograd conv: transformed weights missing");
     MCVD_REQUIRE(a.CinP % WINO_CK == 0, "winograd conv: CinP=%d", a.CinP);
+    MCVD_REQUIRE(a.C1 == 0 || a.C0 % WINO_CK == 0, "winograd conv: concat seam at %d is not a multiple of %d", a.C0, WINO_CK);
     const int cot = conv_wino_cout_tile(a.Cout);
     MCVD_REQUIRE(a.CoutP % (32 * cot) == 0, "winograd conv: CoutP=%d vs tile %d", a.CoutP, 32 * cot);
     switch (cot) {

@@ -665,25 +665,40 @@ int mcvd_model::autotune(int B) {
             a.wdma = ctx->conv_wdma;
             float best_ms = 1e30f;
             std::pair<int, int> choice{-1, op.cot};
+            auto time_candidate = [&](int shape, int cot) -> int {
+                a.cot = cot;
+                a.shape_hint = shape;
+                if (launch_conv_mfma(a, s)) return 0;                     // warm-up (and validity check)
+                MCVD_HIP_CHECK(hipEventRecord(e0, s));
+                for (int r = 0; r < 3; ++r)
+                    if (int rc = launch_conv_mfma(a, s)) return rc;
+                MCVD_HIP_CHECK(hipEventRecord(e1, s));
+                MCVD_HIP_CHECK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                MCVD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best_ms) { best_ms = ms; choice = {shape, cot}; }
+                return 0;
+            };
             const int cots[2] = {op.cot, 1};
             for (int ci = 0; ci < (op.cot == 1 ? 1 : 2); ++ci) {
                 for (int shape = 0; shape < 5; ++shape) {
-                    a.cot = cots[ci];
-                    a.shape_hint = shape;
                     if (shape == 3 && (op.ks != 3 || !ctx->conv_wdma)) continue;      // 3 = split-K with double-buffered weights
-                    if (shape == 4 && (ci > 0 || !a.wpw || !ctx->winograd)) continue;  // 4 = Winograd F(2x2,3x3), own cout tile
+                    if (shape == 4 && (ci > 0 || !a.wpw || !ctx->winograd || !conv_wino_supported(op.ks, op.H, op.W) ||
+                                       (a.C1 > 0 && a.C0 % 8 != 0))) continue;         // 4 = Winograd F(2x2,3x3), own cout tile
                     const int bpx = shape == 0 ? 256 : shape == 1 ? 128 : 64;
                     const bool fits = bpx % op.W == 0 && (bpx / op.W <= op.H ? op.H % (bpx / op.W) == 0 : (bpx / op.W) % op.H == 0);
                     if (shape != 4 && !fits) continue;
-                    if (launch_conv_mfma(a, s)) continue;                 // warm-up (and validity check)
-                    MCVD_HIP_CHECK(hipEventRecord(e0, s));
-                    for (int r = 0; r < 3; ++r)
-                        if (int rc = launch_conv_mfma(a, s)) return rc;
-                    MCVD_HIP_CHECK(hipEventRecord(e1, s));
-                    MCVD_HIP_CHECK(hipEventSynchronize(e1));
-                    float ms = 0.f;
-                    MCVD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-                    if (ms < best_ms) { best_ms = ms; choice = {shape, cots[ci]}; }
+                    if (int rc = time_candidate(shape, cots[ci])) return rc;
+                }
+            }
+            a.cot = op.cot;
+            if (op.ks == 1 && ctx->conv_dma1 && conv1x1_dma_supported(a)) {       // 5 = all-DMA 1x1 GEMM, cout tiles of its own
+                static const int g1_cots[] = {9, 6, 4, 3, 2, 1};
+                int tried = 0;
+                for (int c : g1_cots) {
+                    if ((op.CoutP / 32) % c != 0 || tried >= 3) continue;
+                    ++tried;
+                    if (int rc = time_candidate(5, c)) return rc;
                 }
             }
             it = best.emplace(k, choice).first;

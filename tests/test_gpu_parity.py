@@ -64,6 +64,15 @@ CONV_CASES = [
     (2, 192, 0, 576, 32, 1, True, 0, False, 1),     # fused q|k|v projection with GN affine prologue (no SiLU)
     (3, 128, 0, 128, 8, 1, False, 0, True, 2),      # NIN_3 with residual, split-K
     (3, 72, 0, 64, 16, 1, False, 0, True, -1),
+    (2, 96, 0, 192, 32, 1, False, 0, False, 5),     # all-DMA 1x1 GEMM: shortcut
+    (2, 96, 96, 192, 32, 1, False, 0, False, 5),    # all-DMA: shortcut over a concat
+    (2, 192, 0, 576, 32, 1, True, 0, False, 5),     # all-DMA: q|k|v projection with the GN affine applied at the operand read
+    (2, 192, 0, 576, 32, 1, True, 0, False, 5 + 16 * 9),   # ... cout tile 9
+    (3, 288, 0, 288, 8, 1, False, 0, True, 5 + 16 * 3),    # all-DMA: NIN_3 with residual, two images per pixel tile, ragged tile
+    (3, 288, 0, 288, 8, 1, True, 1, True, 5 + 16 * 9),     # all-DMA: affine + SiLU prologue
+    (3, 128, 0, 128, 16, 1, True, 0, True, 5 + 16 * 4),
+    (1, 96, 0, 96, 64, 1, False, 0, False, 5 + 16 * 1),
+    (3, 72, 0, 64, 16, 1, False, 0, True, 5),       # Cin not a multiple of the DMA chunk: falls back to the staged kernel
 ]
 
 
@@ -90,11 +99,13 @@ def test_conv2d(ctx, case, naive):
         want = want + res
     want = want * scale
     ctx.opt("naive_conv", naive)
-    ctx.opt("conv_shape", shape)
+    ctx.opt("conv_shape", shape & 15 if shape >= 0 else shape)
+    ctx.opt("conv_cot", shape >> 4 if shape >= 0 else 0)
     dev = lambda t: t.cuda().contiguous() if t is not None else None
     got = ctx.conv2d(dev(x0), dev(w), dev(bias), x1=dev(x1), coef=dev(coef), act=act, res=dev(res), scale=scale)
     ctx.opt("naive_conv", 0)
     ctx.opt("conv_shape", -1)
+    ctx.opt("conv_cot", 0)
     _close(got, want, what=f"conv {case}")
 
 

@@ -249,7 +249,11 @@ def wino_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT
     Cin = C0 + C1
     CK, T, BCO, NT, PP = 8, 32, 32 * COT, 512, 20
     USZ, VSZ, PSZ = CK * 16 * BCO, CK * 16 * T, CK * 10 * PP
-    src_all = x0 if x1 is None else np.concatenate([x0, x1], 1)
+    assert C1 == 0 or C0 % CK == 0, "the kernel needs the concat seam on a chunk boundary"
+    HW = H * W
+    x0f = x0.reshape(-1)
+    x1f = None if x1 is None else x1.reshape(-1)
+    coef_f = None if coef is None else coef.reshape(-1)
     y = np.zeros((B, Cout, H, W))
     silu = lambda v: v / (1 + np.exp(-v))
     rx_n, ry_n = W // 16, H // 8
@@ -283,13 +287,22 @@ def wino_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT
                         r, cc_ = rem // 18, rem % 18
                         yy, xx = oy0 - 1 + r, ox0 - 1 + cc_
                         inside = 0 <= yy < H and 0 <= xx < W
-                        c = ch * CK + ci
-                        v = src_all[b, min(c, Cin - 1), min(max(yy, 0), H - 1), min(max(xx, 0), W - 1)]
+                        p_ci = ci + (0 if inside else CK)
+                        goff = min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)
+                        # WINO_LOAD_P: wave-uniform source / base, lane offset cl*HW + goff
+                        cb = min(ch * CK, Cin - 1)
+                        cmax = Cin - 1 - cb
+                        second = cb >= C0
+                        srcb = (x1f, (b * C1 + (cb - C0)) * HW) if second else (x0f, (b * C0 + cb) * HW)
+                        cl = min(p_ci & (CK - 1), cmax)
+                        v = srcb[0][srcb[1] + cl * HW + goff]
                         if coef is not None:
-                            v = v * coef[b, min(c, Cin - 1), 0] + coef[b, min(c, Cin - 1), 1]
+                            cfo = (b * Cin + cb) * 2 + cl * 2
+                            v = v * coef_f[cfo] + coef_f[cfo + 1]
                         if act:
                             v = silu(v)
-                        sP[ci * 10 * PP + r * PP + cc_] = v if (inside and c < Cin) else 0.0
+                        nvalid = Cin - ch * CK
+                        sP[ci * 10 * PP + r * PP + cc_] = v if p_ci < min(nvalid, CK) else 0.0
                 for tid in range(NT):
                     s_ci, s_tile, s_h = (tid & 255) >> 5, tid & 31, tid >> 8
                     s_ty, s_tx = s_tile >> 3, s_tile & 7
@@ -343,3 +356,104 @@ def wino_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT
                                         v += res[b, co, yy, xx]
                                     y[b, co, yy, xx] = v * scale
     return y
+
+
+def gemm1x1_emulate(x0, x1, wp, bias, coef, act, res, scale, Cout, CoutP, CinP, COT):
+    """Lane-level emulation of conv1x1_dma_kernel's addressing (conv1x1_dma.cpp): DMA piece maps of W and x, the
+    coefficient table, MFMA lane maps, block id -> (pixel tile, cout tile), ragged last pixel tile."""
+    B, C0, H, W = x0.shape
+    C1 = 0 if x1 is None else x1.shape[1]
+    Cin = C0 + C1
+    CK, PT, BCO, MAXIMG = 16, 128, 32 * COT, 4
+    HW = H * W
+    NPX = B * HW
+    assert Cin % CK == 0 and CinP % CK == 0 and (C1 == 0 or C0 % CK == 0) and HW % 32 == 0
+    assert HW % PT == 0 or (PT % HW == 0 and PT // HW <= MAXIMG)
+    WSZ, XSZ = CK * BCO, CK * PT
+    WP, XP = WSZ // 4, XSZ // 4
+    MAXW, MAXX = (WP + 255) // 256, XP // 256
+    x0f = x0.reshape(-1)
+    x1f = None if x1 is None else x1.reshape(-1)
+    wpf = wp.reshape(-1)
+    coef_f = None if coef is None else coef.reshape(-1)
+    resf = None if res is None else res.reshape(-1)
+    yf = np.full(B * Cout * HW, np.nan)
+    silu = lambda v: v / (1 + np.exp(-v))
+    ptiles = (NPX + PT - 1) // PT
+    nct = CoutP // BCO
+    for bid in range(((ptiles + 7) // 8) * 8 * nct):
+        xcd, slot = bid & 7, bid >> 3
+        ptile, ctile = (slot // nct) * 8 + xcd, slot % nct
+        if ptile >= ptiles:
+            continue
+        co0 = ctile * BCO
+        gp0 = ptile * PT
+        acc = np.zeros((4, COT, 16, 64))
+        b_first = gp0 // HW
+        nimg = 1 if HW >= PT else PT // HW
+        for ch in range(Cin // CK):
+            cb = ch * CK
+            sW = np.full(WSZ, np.nan)
+            sX = np.full(XSZ, np.nan)
+            sC = np.full(MAXIMG * CK * 2, np.nan)
+            for tid in range(256):
+                wave, lane = tid >> 6, tid & 63
+                for s in range(MAXW):
+                    if not (MAXW * 256 == WP or s * 256 + wave * 64 < WP):
+                        continue
+                    e = min(s * 256 + tid, WP - 1)
+                    row, c4 = e // (BCO // 4), e % (BCO // 4)
+                    g = cb * CoutP + row * CoutP + co0 + c4 * 4
+                    dst = (s * 256 + wave * 64) * 4 + lane * 4
+                    assert 0 <= g and g + 4 <= wpf.size and dst + 4 <= WSZ
+                    sW[dst:dst + 4] = wpf[g:g + 4]
+                xg = min(gp0 + (tid & 31) * 4, NPX - 4)
+                xb, xp = xg // HW, xg % HW
+                x_ci = tid >> 5
+                second = cb >= C0
+                src = x1f if second else x0f
+                base = (cb - C0) * HW if second else cb * HW
+                voff = ((xb * C1 + x_ci) * HW + xp) if second else ((xb * C0 + x_ci) * HW + xp)
+                for s in range(MAXX):
+                    g = base + s * 8 * HW + voff
+                    dst = (s * 256 + wave * 64) * 4 + lane * 4
+                    assert 0 <= g and g + 4 <= src.size and dst + 4 <= XSZ
+                    sX[dst:dst + 4] = src[g:g + 4]
+                if coef is not None and tid < nimg * CK:
+                    c_img, c_ci = min(b_first + tid // CK, B - 1), tid % CK
+                    o = (c_img * Cin + cb + c_ci) * 2
+                    sC[tid * 2:tid * 2 + 2] = coef_f[o:o + 2]
+            assert not np.isnan(sW).any() and not np.isnan(sX).any()
+            for wave in range(4):
+                my_img = 0 if HW >= PT else (wave * 32) // HW
+                for kp in range(CK // 2):
+                    bv = np.zeros(64)
+                    for l in range(64):
+                        row = 2 * kp + (l >> 5)
+                        v = sX[row * PT + wave * 32 + (l & 31)]
+                        if coef is not None:
+                            v = v * sC[(my_img * CK + row) * 2] + sC[(my_img * CK + row) * 2 + 1]
+                            if act:
+                                v = silu(v)
+                        bv[l] = v
+                    for ct in range(COT):
+                        av = np.array([sW[(2 * kp + (l >> 5)) * BCO + ct * 32 + (l & 31)] for l in range(64)])
+                        mfma_32x32x2(av, bv, acc[wave, ct])
+        for wave in range(4):
+            for lane in range(64):
+                gp = gp0 + wave * 32 + (lane & 31)
+                if gp >= NPX:
+                    continue
+                ob, op = gp // HW, gp % HW
+                obase = ob * Cout * HW + op
+                for ct in range(COT):
+                    for r in range(16):
+                        co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+                        if co < Cout:
+                            v = acc[wave, ct, r, lane] + bias[co]
+                            if resf is not None:
+                                v += resf[obase + co * HW]
+                            assert np.isnan(yf[obase + co * HW])        # every output written exactly once
+                            yf[obase + co * HW] = v * scale
+    assert not np.isnan(yf).any()
+    return yf.reshape(B, Cout, H, W)
