@@ -58,6 +58,7 @@ int launch_conv_naive(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2,3x3) variant (conv_wino.cpp): tile shape id 4 of the dispatcher
 bool conv_wino_supported(int ks, int H, int W);
 int launch_conv_wino(const ConvArgs& a, hipStream_t s);
+int launch_conv_wino16(const ConvArgs& a, int cot, hipStream_t s);   // 1024-thread variant, called by launch_conv_wino
 // all-DMA 1x1 GEMM (conv1x1_dma.cpp): tile shape id 5; cot_req <= 0 picks the default cout tile
 bool conv1x1_dma_supported(const ConvArgs& a);
 int conv1x1_dma_cout_tile(int CoutP);

@@ -119,8 +119,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
             const int cl = min(p_ci[sl] & (CK - 1), cmax);                                                      \
             pd[sl] = srcb[cl * HW + p_goff[sl]];                                                                \
             const f32x2 cf = *reinterpret_cast<const f32x2*>(cfb + (hc ? cl * 2 : 0));                          \
-            pA[sl] = hc ? cf.x : 1.0f;                                                                          \
-            pB[sl] = hc ? cf.y : 0.0f;                                                                          \
+            pA[sl] = cf.x;                              /* raw: consuming it here would expose the latency */ \
+            pB[sl] = cf.y;                                                                                      \
         }                                                                                                       \
     }
     /* activate once per pixel and park the patch in LDS (zero padding applies AFTER the activation) */
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
         const int nvalid = Cin - (ch) * CK;                   /* channels-in-chunk below this are real */         \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
             float v = pd[sl];                                                                                   \
-            if (PRO >= 1) v = v * pA[sl] + pB[sl];                                                              \
+            if (PRO >= 1) v = a.coef ? v * pA[sl] + pB[sl] : v;                                                 \
             if (PRO == 2) v = silu_w(v);                                                                        \
             sPw[p_lds[sl]] = (p_ci[sl] < min(nvalid, CK)) ? v : 0.0f;                                           \
         }                                                                                                       \
@@ -378,6 +378,8 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
     MCVD_REQUIRE(a.C1 == 0 || a.C0 % WINO_CK == 0, "winograd conv: concat seam at %d is not a multiple of %d", a.C0, WINO_CK);
     const int cot = conv_wino_cout_tile(a.Cout);
     MCVD_REQUIRE(a.CoutP % (32 * cot) == 0, "winograd conv: CoutP=%d vs tile %d", a.CoutP, 32 * cot);
+    static const int var = env_int_w("MCVD_WINO_VAR", 4);
+    if (var == 4 && a.Cin <= 1024) return launch_conv_wino16(a, cot, s);    // 1024-thread workgroups (conv_wino16.cpp)
     switch (cot) {
         case 1: return wino_launch<1>(a, s);
         case 2: return wino_launch<2>(a, s);

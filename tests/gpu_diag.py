@@ -194,11 +194,45 @@ def phases(f):
     ctx.opt("conv_shape", -1)
 
 
+def wphases(f):
+    """Winograd (conv_wino16.cpp) phase breakdown of one wave (env MCVD_DBG_WAVE), shader-clock units."""
+    from tests.hiputil import Ctx, P
+    ctx = Ctx()
+    B = 64
+    names = ["prologue", "K-loop", "-", "-", "-", "epilogue"]
+    cases = [(96, 96, 64, 0), (192, 192, 32, 0)]
+    f.write(f"# winograd phase breakdown, B=64, wave {os.environ.get('MCVD_DBG_WAVE', '0')} (mean over blocks)\n")
+    ctx.opt("conv_shape", 4)
+    for cin, cout, H, use_res in cases:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda")
+        res = torch.randn(B, cout, H, H, device="cuda") if use_res else None
+        dbg = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
+        for _ in range(2):
+            ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
+        _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
+        ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
+        torch.cuda.synchronize()
+        f.write(f"[diag {os.environ.get('MCVD_WINO_DIAG', '0')}] ")
+        _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
+        d = dbg.view(-1, 8).cpu().double()
+        d = d[d[:, 7] > 0]
+        m = d.mean(0)
+        nch = m[6]
+        f.write(f"cin{cin} cout{cout} H{H} res{use_res}: {d.shape[0]} blocks, {nch:.0f} chunks, block total {m[7]:.0f} | " +
+                " ".join(f"{n} {m[i]:.0f} ({100 * m[i] / m[7]:.1f}%)" for i, n in enumerate(names)) +
+                f" | K loop per chunk: {m[1] / nch:.0f}\n")
+        f.flush()
+    ctx.opt("conv_shape", -1)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["precision", "ops", "sweep"]
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 

@@ -55,7 +55,8 @@ def test_attention_index_maps(B, C, heads, S):
 
 
 @pytest.mark.parametrize("B,C0,C1,Cout,H,W,COT", [(1, 8, 5, 40, 16, 16, 2), (2, 8, 0, 96, 8, 32, 3), (1, 16, 8, 32, 16, 32, 1), (1, 10, 0, 32, 8, 16, 1)])
-def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT):
+@pytest.mark.parametrize("emu", ["wino_emulate", "wino16_emulate"])
+def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT, emu):
     """conv_wino.cpp: staging roles, U/V LDS layouts, MFMA lane maps, the LDS exchange and the 2x2 inverse transform."""
     g = torch.Generator().manual_seed(4)
     x0 = torch.randn(B, C0, H, W, generator=g)
@@ -67,7 +68,7 @@ def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT):
     res = torch.randn(B, Cout, H, W, generator=g)
     CinP, CoutP = _round_up(Cin, 16), _round_up(Cout, 32 * COT)
     up = E.pack_wino_weight(w.numpy(), CinP, CoutP)
-    got = E.wino_emulate(x0.numpy(), None if x1 is None else x1.numpy(), up, bias.numpy(), coef.numpy(), 1, res.numpy(), 0.5,
+    got = getattr(E, emu)(x0.numpy(), None if x1 is None else x1.numpy(), up, bias.numpy(), coef.numpy(), 1, res.numpy(), 0.5,
                          Cout, CoutP, CinP, COT)
     xin = torch.cat([x0, x1], 1) if C1 else x0
     xin = xin * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]
