@@ -245,7 +245,7 @@ int mcvd_model_finalize(mcvd_model* m) {
             MCVD_HIP_CHECK(hipMemcpyAsync(m->packed + p.bias + j * p.Cout_each, m->blob + b.off,
                                           (size_t)p.Cout_each * sizeof(float), hipMemcpyDeviceToDevice, s));
             if (p.wpw >= 0)
-                if (int rc = launch_pack_wino_weight(m->blob + w.off, m->packed + p.wpw, p.Cout_each, p.Cin, p.CoutP, s)) return rc;
+                if (int rc = launch_pack_wino_weight(m->blob + w.off, m->packed + p.wpw, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
         }
     }
     for (const DenseEntry& e : m->dense) {
@@ -513,7 +513,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats) * sizeof(float))) return rc;
     MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP + ufloats) * sizeof(float), ctx->stream));
     if (wino) {
-        if (int rc = launch_pack_wino_weight(w, ctx->scratch + wfloats + a.CoutP, Cout, a.Cin, a.CoutP, ctx->stream)) return rc;
+        if (int rc = launch_pack_wino_weight(w, ctx->scratch + wfloats + a.CoutP, Cout, a.Cin, a.CinP, a.CoutP, ctx->stream)) return rc;
         a.wpw = ctx->scratch + wfloats + a.CoutP;
     }
     if (int rc = launch_pack_conv_weight(w, ctx->scratch, Cout, a.Cin, ks, a.CinP, a.CoutP, 0, 0, ctx->stream)) return rc;

@@ -63,7 +63,14 @@ int launch_conv_wino16(const ConvArgs& a, int cot, hipStream_t s);   // 1024-thr
 bool conv1x1_dma_supported(const ConvArgs& a);
 int conv1x1_dma_cout_tile(int CoutP);
 int launch_conv1x1_dma(const ConvArgs& a, int cot_req, hipStream_t s);
-int launch_pack_wino_weight(const float* w, float* up, int Cout, int Cin, int CoutP, hipStream_t s);
+int launch_pack_wino_weight(const float* w, float* up, int Cout, int Cin, int CinP, int CoutP, hipStream_t s);
+// register-fed Winograd kernel (conv_wino16r.cpp) and its operand-major weight layout
+bool conv_wino16r_supported(const ConvArgs& a);
+int launch_conv_wino16r(const ConvArgs& a, int cot, hipStream_t s);
+int launch_pack_wino_weight_r(const float* w, float* up, int Cout, int Cin, int CinP, int CoutP, int cot, hipStream_t s);
+int conv_wino_variant();                      // which Winograd kernel serves shape id 4 (env MCVD_WINO_VAR)
+int conv_wino_cout_tile(int Cout);
+bool conv_wino_usable(const ConvArgs& a);     // shape id 4 applies to this launch (active variant, packed weights present)
 // repack reference-layout weights [Cout][Cin][ks][ks] (or NIN [Cin][Cout] when nin=1) -> packed layout above
 int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, int CinP, int CoutP, int nin,
                             int cout_off, hipStream_t s);

@@ -31,8 +31,7 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     auto fits = [&](int bpx) { return bpx % a.W == 0 && (bpx / a.W <= a.H ? a.H % (bpx / a.W) == 0 : (bpx / a.W) % a.H == 0); };
     int shape;
     // hints 4 / 5 select the specialised kernels where they apply and fall back to the tile heuristic elsewhere
-    if (a.shape_hint == 4 && conv_wino_supported(a.ks, a.H, a.W) && a.wpw && (a.C1 == 0 || a.C0 % 8 == 0))
-        return launch_conv_wino(a, s);                              // Winograd F(2x2,3x3)
+    if (a.shape_hint == 4 && conv_wino_usable(a)) return launch_conv_wino(a, s);                              // Winograd F(2x2,3x3)
     if (a.shape_hint == 5 && conv1x1_dma_supported(a)) return launch_conv1x1_dma(a, a.cot, s);   // all-DMA 1x1 GEMM
     if (a.cot < 1 || a.cot > 4 || a.CoutP % (32 * a.cot) != 0) {   // a cout tile meant for another kernel: use this one's
         ConvArgs b = a;

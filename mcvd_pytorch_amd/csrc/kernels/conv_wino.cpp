@@ -355,8 +355,7 @@ static int wino_launch3(const ConvArgs& a, hipStream_t s) {
 
 template <int COT, int PRO>
 static int wino_launch2(const ConvArgs& a, hipStream_t s) {
-    static const int var = env_int_w("MCVD_WINO_VAR", 2);
-    switch (var) {
+    switch (conv_wino_variant()) {
         case 0: return wino_launch3<COT, PRO, 0>(a, s);
         case 3: return wino_launch3<COT, PRO, 3>(a, s);
         case 1: return wino_launch3<COT, PRO, 1>(a, s);
@@ -371,14 +370,27 @@ static int wino_launch(const ConvArgs& a, hipStream_t s) {
     return wino_launch2<COT, 2>(a, s);
 }
 
+// Which Winograd kernel serves shape id 4 (env MCVD_WINO_VAR, read once): 5 = 1024 threads, weights register-fed from global
+// memory (conv_wino16r.cpp, default); 4 = 1024 threads, weights LDS-staged by DMA (conv_wino16.cpp); 0..3 = the 512-thread
+// kernel of this file with its pipeline variants.  The packed weight layout depends on it (launch_pack_wino_weight).
+int conv_wino_variant() {
+    static const int var = env_int_w("MCVD_WINO_VAR", 5);
+    return var;
+}
+
+bool conv_wino_usable(const ConvArgs& a) {
+    if (!conv_wino_supported(a.ks, a.H, a.W) || !a.wpw) return false;
+    if (conv_wino_variant() == 5) return conv_wino16r_supported(a);
+    return a.CinP % WINO_CK == 0 && (a.C1 == 0 || a.C0 % WINO_CK == 0);
+}
+
 int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
-    MCVD_REQUIRE(conv_wino_supported(a.ks, a.H, a.W), "winograd conv: ks=%d H=%d W=%d unsupported", a.ks, a.H, a.W);
-    MCVD_REQUIRE(a.wpw, "winograd conv: transformed weights missing");
-    MCVD_REQUIRE(a.CinP % WINO_CK == 0, "winograd conv: CinP=%d", a.CinP);
-    MCVD_REQUIRE(a.C1 == 0 || a.C0 % WINO_CK == 0, "winograd conv: concat seam at %d is not a multiple of %d", a.C0, WINO_CK);
+    MCVD_REQUIRE(conv_wino_usable(a), "winograd conv: unsupported (ks=%d H=%d W=%d Cin=%d C0=%d, packed weights %s)", a.ks, a.H, a.W,
+                 a.Cin, a.C0, a.wpw ? "present" : "missing");
     const int cot = conv_wino_cout_tile(a.Cout);
     MCVD_REQUIRE(a.CoutP % (32 * cot) == 0, "winograd conv: CoutP=%d vs tile %d", a.CoutP, 32 * cot);
-    static const int var = env_int_w("MCVD_WINO_VAR", 4);
+    const int var = conv_wino_variant();
+    if (var == 5) return launch_conv_wino16r(a, cot, s);
     if (var == 4 && a.Cin <= 1024) return launch_conv_wino16(a, cot, s);    // 1024-thread workgroups (conv_wino16.cpp)
     switch (cot) {
         case 1: return wino_launch<1>(a, s);
@@ -416,7 +428,9 @@ __global__ void pack_wino_weight_kernel(const float* w, float* up, int Cout, int
     }
 }
 
-int launch_pack_wino_weight(const float* w, float* up, int Cout, int Cin, int CoutP, hipStream_t s) {
+// `up` (CinP*16*CoutP floats) must be zero-filled by the caller: padded channels stay zero in either layout.
+int launch_pack_wino_weight(const float* w, float* up, int Cout, int Cin, int CinP, int CoutP, hipStream_t s) {
+    if (conv_wino_variant() == 5) return launch_pack_wino_weight_r(w, up, Cout, Cin, CinP, CoutP, conv_wino_cout_tile(Cout), s);
     const long n = (long)Cout * Cin;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(pack_wino_weight_kernel, dim3(blocks), dim3(256), 0, s, w, up, Cout, Cin, CoutP);

@@ -51,11 +51,16 @@ __global__ __launch_bounds__(1024) void conv_wino16_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int H = a.H, W = a.W, HW = H * W, Cin = a.Cin;
     const int rx_n = W >> 4, ry_n = H >> 3;
-    const int reg_id = blockIdx.x;
+    // block id -> (region, cout tile): the cout tiles of one region get ids congruent mod 8 and adjacent in dispatch order, i.e.
+    // they run at the same time on the SAME XCD and share the region's input patch through that XCD's L2.
+    const int nct = a.CoutP / BCO;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int reg_id = (slot / nct) * 8 + xcd;
+    if (reg_id >= a.B * rx_n * ry_n) return;
     const int b = reg_id / (rx_n * ry_n);
     const int rr = reg_id - b * (rx_n * ry_n);
     const int oy0 = (rr / rx_n) * 8, ox0 = (rr % rx_n) * 16;
-    const int co0 = blockIdx.y * BCO;
+    const int co0 = (slot - (slot / nct) * nct) * BCO;
     const int grp = wave >> 2;                  // row of B^T d this wave's threads make == pipeline phase of the wave
 
     // ---- transform role: (channel-in-chunk, tile) = tid & 255, row = grp
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(1024) void conv_wino16_kernel(ConvArgs a) {
     if (rec) {
         const unsigned long long now = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
-            unsigned long long* d = a.dbg + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+            unsigned long long* d = a.dbg + (long)blockIdx.x * 8;
             d[0] = dt[0]; d[1] = dt[1]; d[2] = 0; d[3] = 0; d[4] = 0;      // prologue, K loop
             d[5] = now - tprev;            // epilogue
             d[6] = (unsigned long long)nchunks;
@@ -349,7 +354,8 @@ static int wino16_launch2(const ConvArgs& a, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    dim3 grid(a.B * (a.H / 8) * (a.W / 16), a.CoutP / BCO);
+    const int nreg = a.B * (a.H / 8) * (a.W / 16);
+    dim3 grid(((nreg + 7) / 8) * 8 * (a.CoutP / BCO));
     ConvArgs k = a;
     if (k.dbg) {
         const char* w = getenv("MCVD_DBG_WAVE");       // which wave records its phase times (diagnostics)

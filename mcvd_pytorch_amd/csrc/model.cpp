@@ -683,8 +683,7 @@ int mcvd_model::autotune(int B) {
             for (int ci = 0; ci < (op.cot == 1 ? 1 : 2); ++ci) {
                 for (int shape = 0; shape < 5; ++shape) {
                     if (shape == 3 && (op.ks != 3 || !ctx->conv_wdma)) continue;      // 3 = split-K with double-buffered weights
-                    if (shape == 4 && (ci > 0 || !a.wpw || !ctx->winograd || !conv_wino_supported(op.ks, op.H, op.W) ||
-                                       (a.C1 > 0 && a.C0 % 8 != 0))) continue;         // 4 = Winograd F(2x2,3x3), own cout tile
+                    if (shape == 4 && (ci > 0 || !ctx->winograd || !conv_wino_usable(a))) continue;   // 4 = Winograd F(2x2,3x3), own cout tile
                     const int bpx = shape == 0 ? 256 : shape == 1 ? 128 : 64;
                     const bool fits = bpx % op.W == 0 && (bpx / op.W <= op.H ? op.H % (bpx / op.W) == 0 : (bpx / op.W) % op.H == 0);
                     if (shape != 4 && !fits) continue;

@@ -54,8 +54,8 @@ def test_attention_index_maps(B, C, heads, S):
     np.testing.assert_allclose(got, want.numpy(), rtol=1e-8, atol=1e-8)
 
 
-@pytest.mark.parametrize("B,C0,C1,Cout,H,W,COT", [(1, 8, 5, 40, 16, 16, 2), (2, 8, 0, 96, 8, 32, 3), (1, 16, 8, 32, 16, 32, 1), (1, 10, 0, 32, 8, 16, 1)])
-@pytest.mark.parametrize("emu", ["wino_emulate", "wino16_emulate"])
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W,COT", [(1, 8, 5, 40, 16, 16, 2), (2, 8, 0, 96, 8, 32, 3), (1, 16, 8, 32, 16, 32, 1), (1, 10, 0, 32, 8, 16, 1), (3, 16, 20, 40, 8, 16, 2)])
+@pytest.mark.parametrize("emu", ["wino_emulate", "wino16_emulate", "wino16r_emulate"])
 def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT, emu):
     """conv_wino.cpp: staging roles, U/V LDS layouts, MFMA lane maps, the LDS exchange and the 2x2 inverse transform."""
     g = torch.Generator().manual_seed(4)
@@ -67,7 +67,12 @@ def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT, emu):
     coef = torch.stack([1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], -1)
     res = torch.randn(B, Cout, H, W, generator=g)
     CinP, CoutP = _round_up(Cin, 16), _round_up(Cout, 32 * COT)
-    up = E.pack_wino_weight(w.numpy(), CinP, CoutP)
+    if emu == "wino16r_emulate":
+        if C1 and C0 % 16:
+            pytest.skip("the register-fed kernel needs the concat seam on a 16-channel boundary")
+        up = E.pack_wino_weight_r(w.numpy(), CinP, CoutP, COT)
+    else:
+        up = E.pack_wino_weight(w.numpy(), CinP, CoutP)
     got = getattr(E, emu)(x0.numpy(), None if x1 is None else x1.numpy(), up, bias.numpy(), coef.numpy(), 1, res.numpy(), 0.5,
                          Cout, CoutP, CinP, COT)
     xin = torch.cat([x0, x1], 1) if C1 else x0

@@ -472,6 +472,132 @@ def wino16_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, C
 
 
 
+def pack_wino_weight_r(w, CinP, CoutP, COT):
+    """Mirror of pack_wino_weight_r_kernel (conv_wino16r.cpp): operand-major layout
+    up[((((cotile*nunits + ci//8)*16 + xi)*COT + idx//4)*64 + lane)*4 + idx%4], idx = ((ci%8)//2)*COT + (co%BCO)//32,
+    lane = (ci%2)*32 + co%32."""
+    Cout, Cin = w.shape[:2]
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    BCO, nunits = 32 * COT, CinP // 8
+    up = np.zeros(CinP * 16 * CoutP)
+    for co in range(Cout):
+        for ci in range(Cin):
+            U = G @ w[co, ci].astype(np.float64) @ G.T
+            cotile, ct, lane = co // BCO, (co % BCO) // 32, (ci & 1) * 32 + (co & 31)
+            idx = ((ci & 7) >> 1) * COT + ct
+            for xi in range(16):
+                up[((((cotile * nunits + (ci >> 3)) * 16 + xi) * COT + (idx >> 2)) * 64 + lane) * 4 + (idx & 3)] = U[xi // 4, xi % 4]
+    return up
+
+
+def wino16r_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT):
+    """Lane-level emulation of conv_wino16r_kernel's addressing (conv_wino16r.cpp): 1024 threads, 16-channel chunks, A operands
+    straight from the operand-major packed weights, patch slots, two transform tasks per thread, block id -> (region, cout tile)."""
+    B, C0, H, W = x0.shape
+    C1 = 0 if x1 is None else x1.shape[1]
+    Cin = C0 + C1
+    CK, T, BCO, NT, PP = 16, 32, 32 * COT, 1024, 20
+    VSZ, PSZ = CK * 16 * T, CK * 10 * PP
+    assert CinP % CK == 0 and (C1 == 0 or C0 % CK == 0)
+    HW = H * W
+    x0f = x0.reshape(-1)
+    x1f = None if x1 is None else x1.reshape(-1)
+    coef_f = None if coef is None else coef.reshape(-1)
+    y = np.full((B, Cout, H, W), np.nan)
+    silu = lambda v: v / (1 + np.exp(-v))
+    rx_n, ry_n = W // 16, H // 8
+    nreg, nct, nunits = B * rx_n * ry_n, CoutP // BCO, CinP // 8
+    for bid in range(((nreg + 7) // 8) * 8 * nct):
+        xcd, slot = bid & 7, bid >> 3
+        reg_id = (slot // nct) * 8 + xcd
+        if reg_id >= nreg:
+            continue
+        b = reg_id // (rx_n * ry_n)
+        rr = reg_id - b * (rx_n * ry_n)
+        oy0, ox0 = (rr // rx_n) * 8, (rr % rx_n) * 16
+        cotile = slot - (slot // nct) * nct
+        co0 = cotile * BCO
+        acc = np.zeros((16, COT, 16, 64))              # wave, ct, reg, lane
+        for ch in range(CinP // CK):
+            sV = np.full(VSZ, np.nan)
+            sP = np.full(PSZ + 4, np.nan)
+            for tid in range(NT):
+                for sl in range((CK * 180 + NT - 1) // NT):
+                    e = sl * NT + tid
+                    if e >= CK * 180:
+                        sP[PSZ] = 0.0
+                        continue
+                    ci, rem = e // 180, e % 180
+                    r, cc_ = rem // 18, rem % 18
+                    yy, xx = oy0 - 1 + r, ox0 - 1 + cc_
+                    inside = 0 <= yy < H and 0 <= xx < W
+                    p_ci = ci + (0 if inside else CK)
+                    goff = min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)
+                    cb = min(ch * CK, Cin - 1)
+                    cmax = Cin - 1 - cb
+                    second = cb >= C0
+                    srcb = (x1f, (b * C1 + (cb - C0)) * HW) if second else (x0f, (b * C0 + cb) * HW)
+                    cl = min(p_ci & (CK - 1), cmax)
+                    v = srcb[0][srcb[1] + cl * HW + goff]
+                    if coef is not None:
+                        cch = min(ch * CK + (p_ci & (CK - 1)), Cin - 1)
+                        v = v * coef_f[(b * Cin + cch) * 2] + coef_f[(b * Cin + cch) * 2 + 1]
+                    if act:
+                        v = silu(v)
+                    nvalid = Cin - ch * CK
+                    sP[ci * 10 * PP + r * PP + cc_] = v if p_ci < min(nvalid, CK) else 0.0
+            for tid in range(NT):
+                s_ci, s_tile, grp = (tid & 255) >> 5, tid & 31, tid >> 8
+                s_ty, s_tx = s_tile >> 3, s_tile & 7
+                p_rd = s_ci * 10 * PP + 2 * s_ty * PP + 2 * s_tx
+                p_rdA, p_rdB = p_rd + (0 if grp == 0 else 1) * PP, p_rd + (3 if grp == 3 else 2) * PP
+                v_fa, v_fb = (-1.0 if grp == 2 else 1.0), (1.0 if grp in (1, 2) else -1.0)
+                v_wr = s_ci * 16 * T + grp * 4 * T + s_tile
+                for k2 in range(2):
+                    m = [v_fb * sP[p_rdB + k2 * 8 * 10 * PP + j] + v_fa * sP[p_rdA + k2 * 8 * 10 * PP + j] for j in range(4)]
+                    base = v_wr + k2 * 8 * 16 * T
+                    sV[base + 0 * T] = m[0] - m[2]
+                    sV[base + 1 * T] = m[1] + m[2]
+                    sV[base + 2 * T] = m[2] - m[1]
+                    sV[base + 3 * T] = m[1] - m[3]
+            assert not np.isnan(sV).any()
+            for wave in range(16):
+                for g in range(8):
+                    bv = np.array([sV[((2 * g + (l >> 5)) * 16 + wave) * T + (l & 31)] for l in range(64)])
+                    u, kp = 2 * ch + (g >> 2), g & 3
+                    for ct in range(COT):
+                        idx = kp * COT + ct
+                        av = np.array([up[((((cotile * nunits + u) * 16 + wave) * COT + (idx >> 2)) * 64 + l) * 4 + (idx & 3)]
+                                       for l in range(64)])
+                        mfma_32x32x2(av, bv, acc[wave, ct])
+        for ct in range(COT):
+            sM = np.full(16 * 32 * T, np.nan)
+            for wave in range(16):
+                for lane in range(64):
+                    for r in range(16):
+                        col = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+                        sM[(wave * 32 + col) * T + (lane & 31)] = acc[wave, ct, r, lane]
+            for tid in range(NT):
+                e_tile, col = tid & 31, tid >> 5
+                e_ty, e_tx = e_tile >> 3, e_tile & 7
+                co = co0 + ct * 32 + col
+                mm = np.array([sM[(xi * 32 + col) * T + e_tile] for xi in range(16)])
+                t0 = [mm[0 + l] + mm[4 + l] + mm[8 + l] for l in range(4)]
+                t1 = [mm[4 + l] - mm[8 + l] - mm[12 + l] for l in range(4)]
+                ys = [[t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]], [t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]]]
+                if co < Cout:
+                    for r in range(2):
+                        for cc in range(2):
+                            yy, xx = oy0 + 2 * e_ty + r, ox0 + 2 * e_tx + cc
+                            v = ys[r][cc] + bias[co]
+                            if res is not None:
+                                v += res[b, co, yy, xx]
+                            assert np.isnan(y[b, co, yy, xx])
+                            y[b, co, yy, xx] = v * scale
+    assert not np.isnan(y).any()
+    return y
+
+
 def gemm1x1_emulate(x0, x1, wp, bias, coef, act, res, scale, Cout, CoutP, CinP, COT):
     """Lane-level emulation of conv1x1_dma_kernel's addressing (conv1x1_dma.cpp): DMA piece maps of W and x, the
     coefficient table, MFMA lane maps, block id -> (pixel tile, cout tile), ragged last pixel tile."""

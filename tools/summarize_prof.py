@@ -76,7 +76,40 @@ def mfma():
                   f"(/1024 SIMDs = {mf / gui / 1024:5.3f}, /256 CUs = {mf / gui / 256:5.3f})  sq_busy/gui {d.get('SQ_BUSY_CYCLES', 0) / gui:8.2f}")
 
 
+def traffic(out_json):
+    """HBM-side bytes per launch of the dominant kernel (largest total time in the kernel stats) from the two PMC passes."""
+    import json
+    agg = defaultdict(float)
+    for f in glob.glob(os.path.join(OUT, "prof", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[short(r["Name"])] += float(r["TotalDurationNs"])
+    if not agg:
+        return
+    dom = max(agg, key=agg.get)
+    res = {"kernel": dom}
+    for key, dirname, counter in (("fetch", "pmc_fetch", "FETCH_SIZE"), ("write", "pmc_write", "WRITE_SIZE")):
+        n, v = 0, 0.0
+        for f in glob.glob(os.path.join(OUT, dirname, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == counter and short(r["Kernel_Name"]) == dom:
+                    n += 1
+                    v += float(r["Counter_Value"])
+        res[f"launches_{key}"] = n
+        res[f"{key}_size_kib_per_launch_raw"] = v / max(n, 1)
+    fetch = res["fetch_size_kib_per_launch_raw"] * 1024.0
+    write = res["write_size_kib_per_launch_raw"] * 1024.0
+    res["fetch_correction"] = "x2 (gfx950 FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)"
+    res["traffic_bytes_per_launch"] = 2.0 * fetch + write
+    res["note"] = ("separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (kernel-trace only), bench.py --subsample 5 (6 forwards) incl. "
+                   "the autotuner's timing launches; averaged over every layer shape the kernel serves; Infinity-Cache hits are counted")
+    json.dump(res, open(out_json, "w"), indent=1)
+    print("wrote", out_json, res)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "traffic":
+        traffic(sys.argv[2])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mfma":
         mfma()
         sys.exit(0)
