@@ -187,7 +187,7 @@ def main():
                          tflops=round(a["flops"] / a["ms"] / 1e9, 2), gbs=round(a["bytes"] / a["ms"] / 1e6, 1))
                  for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     # ---- dominant kernel: the 3x3 convs.  Which implementation each layer runs is the autotuner's choice (op_info):
-    # shape 4 = Winograd F(2x2,3x3) (conv_wino16_kernel), else the direct implicit GEMM (conv_mfma_kernel).
+    # shape 4 = Winograd F(2x2,3x3) (conv_wino_kernel), else the direct implicit GEMM (conv_mfma_kernel).
     info = (C.c_int * 8)()
     wino = dict(launches=0, ms=0.0, flops=0.0, bytes=0.0)
     for i in range(n):
@@ -200,7 +200,7 @@ def main():
     dom, dom_name = c3, "conv_mfma_kernel<3x3> (direct implicit GEMM, v_mfma_f32_32x32x2_f32)"
     mult_ratio = 1.0
     if wino["ms"] > 0.5 * c3["ms"]:
-        dom, dom_name = wino, "conv_wino16_kernel (3x3 conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)"
+        dom, dom_name = wino, "conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)"
         mult_ratio = 16.0 / 36.0          # multiplies executed per output tile: 16 (Winograd) vs 36 (direct form)
     achieved = dom["flops"] / dom["ms"] / 1e9
     traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/, tools/gpu_check.sh prof)

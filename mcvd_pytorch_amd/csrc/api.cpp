@@ -521,7 +521,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.wp = ctx->scratch;
     a.bias = ctx->scratch + wfloats;
     a.shape_hint = ctx->conv_shape;
-    if (ctx->conv_shape == 5 && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
+    if ((ctx->conv_shape == 5 || ctx->conv_shape == 6) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
     a.wdma = ctx->conv_wdma;
     a.dbg = ctx->dbg;
     return ctx->naive_conv ? launch_conv_naive(a, ctx->stream) : launch_conv_mfma(a, ctx->stream);

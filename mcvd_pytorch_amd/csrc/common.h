@@ -39,7 +39,7 @@ struct ConvArgs {
     const float* coef;    // [B][Cin][2] per-(sample,channel) affine (A,B), or null
     int act;              // SiLU after the affine
     const float* wp;      // packed weights
-    const float* wpw;     // Winograd-transformed packed weights Up[(cin*16 + xi)*CoutP + cout] (3x3 only), or null
+    const float* wpw;     // Winograd-transformed weights, operand-major (conv_wino.cpp: pack_wino_weight_kernel; 3x3 only), or null
     const float* bias;    // [Cout]
     const float* res;     // residual [B][Cout][H][W] or null
     float out_scale;
@@ -47,7 +47,7 @@ struct ConvArgs {
     int B, Cin, CinP, Cout, CoutP, H, W;
     int ks;               // 1 or 3
     int cot;              // cout tile in units of 32 channels (1..4); CoutP % (32*cot) == 0
-    int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile, 3 split-K+WDB, 4 Winograd, 5 all-DMA 1x1 GEMM
+    int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile, 3 split-K+WDB, 4 Winograd, 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels per chunk)
     int wdma;             // 1: stage weight chunks by LDS-DMA (default), 0: through registers
     unsigned long long* dbg;   // optional: per-block phase cycle counters [n_blocks][8] (diagnostics), else null
 };
@@ -55,22 +55,17 @@ int conv_cout_tile(int Cout);                 // 32-channel units per block alon
 int conv_chunk(int ks);                       // input-channel chunk the MFMA kernel consumes per stage
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 int launch_conv_naive(const ConvArgs& a, hipStream_t s);
-// Winograd F(2x2,3x3) variant (conv_wino.cpp): tile shape id 4 of the dispatcher
-bool conv_wino_supported(int ks, int H, int W);
-int launch_conv_wino(const ConvArgs& a, hipStream_t s);
-int launch_conv_wino16(const ConvArgs& a, int cot, hipStream_t s);   // 1024-thread variant, called by launch_conv_wino
-// all-DMA 1x1 GEMM (conv1x1_dma.cpp): tile shape id 5; cot_req <= 0 picks the default cout tile
-bool conv1x1_dma_supported(const ConvArgs& a);
-int conv1x1_dma_cout_tile(int CoutP);
-int launch_conv1x1_dma(const ConvArgs& a, int cot_req, hipStream_t s);
-int launch_pack_wino_weight(const float* w, float* up, int Cout, int Cin, int CinP, int CoutP, hipStream_t s);
-// register-fed Winograd kernel (conv_wino16r.cpp) and its operand-major weight layout
-bool conv_wino16r_supported(const ConvArgs& a);
-int launch_conv_wino16r(const ConvArgs& a, int cot, hipStream_t s);
-int launch_pack_wino_weight_r(const float* w, float* up, int Cout, int Cin, int CinP, int CoutP, int cot, hipStream_t s);
-int conv_wino_variant();                      // which Winograd kernel serves shape id 4 (env MCVD_WINO_VAR)
+// Winograd F(2x2,3x3) kernel (conv_wino.cpp): tile shape id 4 of the dispatcher
+bool conv_wino_supported(int ks, int H, int W);      // geometry only (decides whether transformed weights are packed at all)
 int conv_wino_cout_tile(int Cout);
-bool conv_wino_usable(const ConvArgs& a);     // shape id 4 applies to this launch (active variant, packed weights present)
+bool conv_wino_usable(const ConvArgs& a);            // shape id 4 applies to this launch
+int launch_conv_wino(const ConvArgs& a, hipStream_t s);
+// all-DMA 1x1 GEMM (conv1x1_dma.cpp): tile shape ids 5 / 6; cot_req <= 0 picks the default cout tile
+bool conv1x1_dma_supported(const ConvArgs& a, int ck);     // ck: channels per chunk, 16 (shape id 5) or 32 (shape id 6)
+int conv1x1_dma_cout_tile(int CoutP);
+int launch_conv1x1_dma(const ConvArgs& a, int cot_req, int ck, hipStream_t s);
+// [Cout][Cin][3][3] -> operand-major transformed weights (zero-filled destination of CinP*16*CoutP floats)
+int launch_pack_wino_weight(const float* w, float* up, int Cout, int Cin, int CinP, int CoutP, hipStream_t s);
 // repack reference-layout weights [Cout][Cin][ks][ks] (or NIN [Cin][Cout] when nin=1) -> packed layout above
 int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, int CinP, int CoutP, int nin,
                             int cout_off, hipStream_t s);

@@ -19,13 +19,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float silu_g(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-constexpr int G1_CK = 16;        // input channels per chunk
 constexpr int G1_PT = 128;       // pixels per workgroup
 constexpr int G1_MAXIMG = 4;     // images a pixel tile may span (HW >= 32)
 
-template <int COT, int PRO>      // PRO: 0 raw input, 1 affine, 2 affine + SiLU
+// PRO: 0 raw input, 1 affine, 2 affine + SiLU;  CK: input channels per chunk (16 or 32)
+template <int COT, int PRO, int CK>
 __global__ __launch_bounds__(256) void conv1x1_dma_kernel(ConvArgs a, int ptiles, int nct) {
-    constexpr int CK = G1_CK, PT = G1_PT, BCO = 32 * COT;
+    constexpr int PT = G1_PT, BCO = 32 * COT;
     constexpr int WSZ = CK * BCO, XSZ = CK * PT;
     constexpr int WPIECES = WSZ / 4, XPIECES = XSZ / 4;          // 16-byte pieces per chunk
     constexpr int MAXW = (WPIECES + 255) / 256, MAXX = XPIECES / 256;
@@ -163,8 +163,9 @@ int conv1x1_dma_cout_tile(int CoutP) {
     return 1;
 }
 
-bool conv1x1_dma_supported(const ConvArgs& a) {
+bool conv1x1_dma_supported(const ConvArgs& a, int ck) {
     const int HW = a.H * a.W;
+    const int G1_CK = ck;
     if (a.ks != 1 || HW % 32 != 0) return false;
     if (!(HW % G1_PT == 0 || (HW < G1_PT && G1_PT % HW == 0 && G1_PT / HW <= G1_MAXIMG))) return false;
     if (a.Cin % G1_CK != 0 || a.CinP % G1_CK != 0) return false;            // no partial chunk: every staged row is real data
@@ -174,7 +175,7 @@ bool conv1x1_dma_supported(const ConvArgs& a) {
     return true;
 }
 
-template <int COT>
+template <int COT, int G1_CK>
 static int g1_launch(const ConvArgs& a, hipStream_t s) {
     const int HW = a.H * a.W;
     const long NPX = (long)a.B * HW;
@@ -182,30 +183,46 @@ static int g1_launch(const ConvArgs& a, hipStream_t s) {
     const int nct = a.CoutP / (32 * COT);
     const size_t lds = (size_t)(2 * G1_CK * 32 * COT + 2 * G1_CK * G1_PT + 2 * G1_MAXIMG * G1_CK * 2) * sizeof(float);
     const dim3 grid(((ptiles + 7) / 8) * 8 * nct);
+    static bool raised = false;
+    if (!raised && lds > 48 * 1024) {
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 0, G1_CK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 1, G1_CK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 2, G1_CK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
     if (!a.coef)
-        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 0>), grid, dim3(256), lds, s, a, ptiles, nct);
+        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 0, G1_CK>), grid, dim3(256), lds, s, a, ptiles, nct);
     else if (!a.act)
-        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 1>), grid, dim3(256), lds, s, a, ptiles, nct);
+        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 1, G1_CK>), grid, dim3(256), lds, s, a, ptiles, nct);
     else
-        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 2>), grid, dim3(256), lds, s, a, ptiles, nct);
+        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 2, G1_CK>), grid, dim3(256), lds, s, a, ptiles, nct);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// cot_req: requested cout tile (32-channel units); <= 0 or unsupported -> the default rule.
-int launch_conv1x1_dma(const ConvArgs& a, int cot_req, hipStream_t s) {
-    MCVD_REQUIRE(conv1x1_dma_supported(a), "conv1x1 dma: unsupported shape (ks=%d H=%d W=%d Cin=%d C0=%d)", a.ks, a.H, a.W,
-                 a.Cin, a.C0);
+template <int G1_CK>
+static int g1_dispatch(const ConvArgs& a, int cot, hipStream_t s) {
+    switch (cot) {
+        case 1: return g1_launch<1, G1_CK>(a, s);
+        case 2: return g1_launch<2, G1_CK>(a, s);
+        case 3: return g1_launch<3, G1_CK>(a, s);
+        case 4: return g1_launch<4, G1_CK>(a, s);
+        case 6: return g1_launch<6, G1_CK>(a, s);
+        default: return g1_launch<9, G1_CK>(a, s);
+    }
+}
+
+// cot_req: requested cout tile (32-channel units); <= 0 or unsupported -> the default rule.  ck: channels per chunk, 16 or 32.
+int launch_conv1x1_dma(const ConvArgs& a, int cot_req, int ck, hipStream_t s) {
+    MCVD_REQUIRE((ck == 16 || ck == 32) && conv1x1_dma_supported(a, ck), "conv1x1 dma: unsupported shape (ks=%d H=%d W=%d Cin=%d C0=%d ck=%d)",
+                 a.ks, a.H, a.W, a.Cin, a.C0, ck);
     const int n32 = a.CoutP / 32;
     const int cot = g1_cot_ok(n32, cot_req) ? cot_req : conv1x1_dma_cout_tile(a.CoutP);
-    switch (cot) {
-        case 1: return g1_launch<1>(a, s);
-        case 2: return g1_launch<2>(a, s);
-        case 3: return g1_launch<3>(a, s);
-        case 4: return g1_launch<4>(a, s);
-        case 6: return g1_launch<6>(a, s);
-        default: return g1_launch<9>(a, s);
-    }
+    MCVD_REQUIRE(!(ck == 32 && cot == 9), "conv1x1 dma: cout tile 9 with 32-channel chunks exceeds the LDS budget");
+    return ck == 32 ? g1_dispatch<32>(a, cot, s) : g1_dispatch<16>(a, cot, s);
 }
 
 }  // namespace mcvd

@@ -1,24 +1,37 @@
-// 3x3 convolution by Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32 -- 2.25x fewer matrix-pipe MACs than the direct
-// implicit GEMM, still exact-fp32 arithmetic (measured forward error vs fp64: 2.3e-6 against 1.8e-6 for the direct form).
+// 3x3 convolution by Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32 -- 2.25x fewer matrix-pipe multiplies than the direct
+// implicit GEMM (conv_mfma.h), still exact-fp32 arithmetic (measured forward error vs fp64: 2.3e-6 against 1.8e-6 direct).
 //
 //   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, d = 4x4 input patch of silu?(A_c x + B_c)
 //
 // For each of the 16 transform positions xi the channel contraction is an independent GEMM
 //   M_xi[co][tile] = sum_ci U_xi[co][ci] * V_xi[ci][tile]
-// MFMA A-operand = transformed weights U (rows = cout), B-operand = transformed patches V (cols = tiles).
+// MFMA A operand = transformed weights U (rows = cout), B operand = transformed patches V (cols = tiles).
 //
-// Workgroup (512 threads = 8 waves = TWO waves per SIMD, one workgroup per CU): a region of 8 x 16 output pixels =
-// 4 x 8 = 32 tiles of one sample, 32*COT output channels, all 16 positions: wave w owns positions 2w, 2w+1 (2*COT
-// accumulator tiles, <= 96 registers, so two waves fit a SIMD and one wave's staging VALU work overlaps its partner's MFMAs).
-//   * U chunks (8 input channels x 16 positions x 32*COT couts) stream HBM/L2 -> LDS by LDS-DMA, double-buffered;
-//     the packed layout is the direct kernel's with 16 "taps": Up[(ci*16 + xi)*CoutP + co].
-//   * staging of chunk i+1 rides inside the MFMA loop of chunk i in two steps: (a) the region's 10 x 18 input patch of the
-//     8 channels is loaded row-wise (coalesced, one chunk ahead), GroupNorm/temb affine + SiLU applied ONCE per pixel,
-//     zero padding AFTER the activation, written to a small LDS patch; barrier; (b) thread pair (t, t+256) takes (channel
-//     (t&255)>>5, tile t&31), reads its window from the LDS patch, applies B^T d B (two of the four rows each) and writes
-//     position values (conflict-free) into the double-buffered V.  Two barriers per chunk, both between MFMA groups.
-//   * epilogue: per 32-cout sub-tile the 16 position planes go through LDS, each thread inverse-transforms 2 (cout, tile)
-//     pairs (A^T M A), adds bias (+ residual), scales, and stores 2x2 pixels as two 8-byte stores.
+// Workgroup = 1024 threads = 16 waves = FOUR waves per SIMD, one workgroup per CU: a region of 8 x 16 output pixels = 4 x 8 = 32
+// tiles of one sample, 32*COT output channels, all 16 positions; the transformed weights are fed to the matrix pipe
+// STRAIGHT FROM GLOBAL MEMORY INTO REGISTERS:
+//
+// Wave w owns transform position xi = w (COT accumulator tiles = 48 registers at COT = 3, inside the 128-VGPR budget of four
+// waves per SIMD).  Its MFMA A operand for (k-pair kp, cout sub-tile ct) is
+//     lane l  ->  U_xi[co = ct*32 + (l & 31)][ci = 2*kp + (l >> 5)]
+// i.e. ONE value per lane, and no other wave ever needs it: staging U through LDS (an earlier version: 48 KiB of DMA writes
+// plus 48 KiB of operand reads per 8 channels and workgroup) buys nothing.  The weights are therefore packed per (cout tile,
+// 8-channel unit, position) as [COT][64 lanes][4] floats (pack_wino_weight_kernel) and every wave fetches its 4*COT A operands
+// of an 8-channel unit with COT fully coalesced global_load_dwordx4 (L2-resident data), one unit ahead of its use.
+//   * LDS holds only the transformed patches V (B operand) and the activated input patch: 16 input channels per chunk
+//     (HALF the barriers of the 8-channel predecessor) in 96 KiB.
+//   * per chunk and wave: 8 MFMA groups (k-pairs) of COT MFMAs; the LAST group is issued after the chunk barrier (its
+//     operands are in registers), so the matrix pipe has work while the first B reads of the next chunk are in flight.
+//   * staging per chunk: 2880 patch elements (<= 3 per thread, raw loads one chunk ahead, affine + SiLU from an LDS
+//     coefficient table, zero padding after the activation); the tile transform B^T d B is split by row of B^T d over the four
+//     256-thread wave groups, two (channel, tile) tasks per thread, and wave group g runs it in its own slot of the chunk so
+//     that the four waves of a SIMD (one per group) are never in the same VALU-heavy phase; all of it sits in the first half of
+//     the chunk, the second half is MFMAs only, so the waves reach the barrier together.
+//   * every VMEM operation of the K loop is issued through inline asm and waited for with explicit in-order vmcnt counts:
+//     the compiler's s_waitcnt insertion falls back to vmcnt(0) for loop-carried loads, which would serialise the weight
+//     prefetch behind the patch loads.  The wait points and the counts are spelled out at each use below; the destination
+//     registers are verified (ISA) not to be copied between a load and its wait.
+//   * epilogue: per 32-cout sub-tile the 16 position planes go through LDS and every thread inverse-transforms one (cout, tile).
 #include <stdlib.h>
 
 #include "../common.h"
@@ -26,48 +39,57 @@
 namespace mcvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_wr(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-constexpr int WINO_CK = 8;       // input channels per chunk
-constexpr int WINO_T = 32;       // tiles per workgroup (4 x 8)
+constexpr int WR_CK = 16;        // input channels per chunk (two 8-channel weight units)
+constexpr int WR_T = 32;         // tiles per workgroup (4 x 8 tiles = 8 x 16 output pixels)
+constexpr int WR_NT = 1024;
 
-template <int COT, int PRO, int VAR>     // PRO: 0 raw input, 1 affine, 2 affine + SiLU;  VAR: software-pipeline variant (see the K loop)
-__global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
-    constexpr int NT = 512;
-    constexpr int CK = WINO_CK, T = WINO_T, BCO = 32 * COT;
-    constexpr int USZ = CK * 16 * BCO;          // floats per U chunk
+// PRO: 0 raw input, 1 affine, 2 affine + SiLU
+template <int COT, int PRO>
+__global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
+    constexpr int NT = WR_NT, CK = WR_CK, T = WR_T, BCO = 32 * COT;
     constexpr int VSZ = CK * 16 * T;            // floats per V chunk
-    constexpr int UCOUNT = USZ / 4;             // float4 per U chunk
-    constexpr int MAXU = UCOUNT / 512;
-    static_assert(UCOUNT % 512 == 0, "every thread issues the same number of U DMA pieces");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PP = 20;                      // LDS patch row pitch (18 columns used)
     constexpr int PSZ = CK * 10 * PP;           // activated input patch of one chunk: [CK][10 rows][PP]
-    constexpr int PCOUNT = CK * 10 * 18;        // patch elements per chunk
-    constexpr int MAXP = (PCOUNT + 511) / 512;
-    float* sU = smem;                           // [2][USZ]
-    float* sV = smem + 2 * USZ;                 // [2][VSZ]
-    constexpr int PBUF = PSZ + 4;               // + 4 floats of dump space for unused patch slots
-    float* sP = smem + 2 * USZ + 2 * VSZ;       // [2][PBUF]: patch(ch+2) is written while patch(ch+1) is transformed
+    constexpr int PBUF = PSZ + 4;               // + dump space for unused patch slots
+    constexpr int PCOUNT = CK * 10 * 18;
+    constexpr int MAXP = (PCOUNT + NT - 1) / NT;
+    static_assert(MAXP == 3, "the vmcnt counts below assume 3 patch loads per thread and chunk");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sV = smem;                           // [2][VSZ]
+    float* sP = smem + 2 * VSZ;                 // [2][PBUF]
+    float* sCo = sP + 2 * PBUF;                 // [Cin][2] prologue coefficients (A_c, B_c) of this sample (PRO only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int H = a.H, W = a.W, HW = H * W, Cin = a.Cin;
     const int rx_n = W >> 4, ry_n = H >> 3;
-    const int reg_id = blockIdx.x;
+    // block id -> (region, cout tile): the cout tiles of one region get ids congruent mod 8 and adjacent in dispatch order, i.e.
+    // they run at the same time on the SAME XCD and share the region's input patch through that XCD's L2.
+    const int nct = a.CoutP / BCO;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int reg_id = (slot / nct) * 8 + xcd;
+    if (reg_id >= a.B * rx_n * ry_n) return;
     const int b = reg_id / (rx_n * ry_n);
     const int rr = reg_id - b * (rx_n * ry_n);
     const int oy0 = (rr / rx_n) * 8, ox0 = (rr % rx_n) * 16;
-    const int co0 = blockIdx.y * BCO;
+    const int cotile = slot - (slot / nct) * nct;
+    const int co0 = cotile * BCO;
+    const int grp = wave >> 2;                  // row of B^T d this wave's threads make == pipeline phase of the wave
 
-    // ---- staging role: (channel-in-chunk, tile)
-    const int s_ci = (tid & 255) >> 5, s_tile = tid & 31, s_h = tid >> 8;      // s_h: which two rows of B^T d this thread makes
+    // ---- transform role: tasks (channel-in-chunk, tile) = (tid & 255) and the same + 8 channels, row = grp
+    const int s_ci = (tid & 255) >> 5, s_tile = tid & 31;
     const int s_ty = s_tile >> 3, s_tx = s_tile & 7;
-    const int p_rd = s_ci * 10 * PP + (2 * s_ty + s_h) * PP + 2 * s_tx;        // rows s_h..s_h+2 of the 4x4 window in the LDS patch
+    // row grp of B^T d:  0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3
+    const int p_rd = s_ci * 10 * PP + 2 * s_ty * PP + 2 * s_tx;     // top-left of the 4x4 window in the LDS patch
+    const int p_rdA = p_rd + (grp == 0 ? 0 : 1) * PP, p_rdB = p_rd + (grp == 3 ? 3 : 2) * PP;
+    const float v_fa = grp == 2 ? -1.0f : 1.0f, v_fb = (grp == 1 || grp == 2) ? 1.0f : -1.0f;
+    const int v_wr = s_ci * 16 * T + grp * 4 * T + s_tile;
 
-    // ---- patch-load slots (chunk invariant): element e -> (channel, patch row, patch col)
-    // p_ci = channel-in-chunk, or CK + channel-in-chunk when the element is zero padding / an unused slot
+    // ---- patch-load slots (chunk invariant); p_ci = channel-in-chunk, or CK + channel when the element is padding / unused
     int p_lds[MAXP], p_goff[MAXP], p_ci[MAXP];
 #pragma unroll
     for (int sl = 0; sl < MAXP; ++sl) {
@@ -81,219 +103,230 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
             p_goff[sl] = min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
             p_ci[sl] = ci + (inside ? 0 : CK);
         } else {
-            p_lds[sl] = PSZ; p_goff[sl] = 0; p_ci[sl] = CK;         // unused slot: harmless load, store into the dump word
+            p_lds[sl] = PSZ; p_goff[sl] = 0; p_ci[sl] = CK;
         }
     }
 
-    int u_goff[MAXU];
-#pragma unroll
-    for (int s = 0; s < MAXU; ++s) {
-        const int e = s * NT + tid;
-        const int row = e / (BCO / 4);
-        const int c4 = e - row * (BCO / 4);
-        u_goff[s] = row * a.CoutP + co0 + c4 * 4;
-    }
+    // ---- weight fetch: unit u = 8 input channels; this wave's COT float4 per unit at  wr_base + u * (16 * COT * 256 floats)
+    const int nunits = a.CinP / 8;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);       // provably uniform: the asm loads take an SGPR base
+    const float* wr_base = a.wpw + (((long)cotile * nunits * 16 + wave_u) * COT) * 256;
+    const unsigned wr_voff = (unsigned)lane * 16u;
 
-    float pd[MAXP], pA[MAXP], pB[MAXP];
-
-#define WINO_DMA_U(ch)                                                                                          \
+    /* A operands of weight unit `u` -> register set S (COT float4 = 4*COT operands, index kp*COT + ct); asm: see header */
+#define WR_LOAD_A(u, S)                                                                                         \
     {                                                                                                           \
-        const float* usrc = a.wpw + (long)(ch) * CK * 16 * a.CoutP;                                             \
-        float* udst = sU + (((ch) & 1) ? USZ : 0);                                                              \
-        _Pragma("unroll") for (int s = 0; s < MAXU; ++s)                                                        \
-            __builtin_amdgcn_global_load_lds(                                                                   \
-                (const __attribute__((address_space(1))) void*)(usrc + u_goff[s]),                              \
-                (__attribute__((address_space(3))) void*)(udst + (s * NT + wave * 64) * 4), 16, 0, 0);          \
+        const float* ub = wr_base + (long)(u) * (16 * COT * 256);                                               \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(S[0]) : "v"(wr_voff), "s"(ub) : "memory");         \
+        if (COT > 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(S[COT > 1 ? 1 : 0]) : "v"(wr_voff), "s"(ub) : "memory"); \
+        if (COT > 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(S[COT > 2 ? 2 : 0]) : "v"(wr_voff), "s"(ub) : "memory"); \
     }
-    /* issue the (unconditional, clamped) loads of the raw input patch of chunk `ch`.  The chunk never straddles the     \
-       concat seam (launch check), so source tensor and base are wave-uniform; channels past Cin re-read the last one. */ \
-#define WINO_LOAD_P(ch)                                                                                         \
+    /* wait until all but the N youngest VMEM operations of this wave have completed; the register set S is threaded through \
+       the asm so that nothing reading it can be scheduled above the wait */                                               \
+#define WR_WAIT_A(N, S)                                                                                         \
+    {                                                                                                           \
+        if (COT == 1) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(S[0]) :: "memory");                         \
+        if (COT == 2) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(S[0]), "+v"(S[1]) :: "memory");             \
+        if (COT == 3) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]) :: "memory"); \
+    }
+    /* unconditional, clamped raw loads of the patch of chunk `ch` into pd[]; the chunk never straddles the concat seam      \
+       (launch check: C0 % 16 == 0 when C1 > 0), channels past Cin re-read the last one and are zeroed at the write */         \
+#define WR_LOAD_P(ch, D)                                                                                        \
     {                                                                                                           \
         const int cb = min((ch) * CK, Cin - 1);                                                                 \
-        const int cmax = Cin - 1 - cb;                        /* last valid channel-in-chunk (>= 0) */           \
+        const int cmax = Cin - 1 - cb;                                                                          \
         const bool second = cb >= a.C0;                                                                         \
         const float* srcb = second ? a.x1 + ((long)b * a.C1 + (cb - a.C0)) * HW : a.x0 + ((long)b * a.C0 + cb) * HW; \
-        const bool hc = PRO && a.coef;               /* SiLU without an affine: identity coefficients */        \
-        const float* cfb = hc ? a.coef + ((long)b * Cin + cb) * 2 : a.wpw;                                      \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
-            const int cl = min(p_ci[sl] & (CK - 1), cmax);                                                      \
-            pd[sl] = srcb[cl * HW + p_goff[sl]];                                                                \
-            const f32x2 cf = *reinterpret_cast<const f32x2*>(cfb + (hc ? cl * 2 : 0));                          \
-            pA[sl] = cf.x;                              /* raw: consuming it here would expose the latency */ \
-            pB[sl] = cf.y;                                                                                      \
+            const unsigned off = (unsigned)(min(p_ci[sl] & (CK - 1), cmax) * HW + p_goff[sl]) * 4u;             \
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(D[sl]) : "v"(off), "s"(srcb) : "memory");        \
         }                                                                                                       \
     }
-    /* activate once per pixel and park the patch in LDS (zero padding applies AFTER the activation) */
-#define WINO_WRITE_P(ch)                                                                                        \
+#define WR_WAIT_P(N, D) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]) :: "memory");
+    /* activate once per pixel (coefficients from the LDS table) and park the patch in LDS; zero padding applies AFTER     \
+       the activation */                                                                                           \
+#define WR_WRITE_P(ch, D)                                                                                        \
     {                                                                                                           \
         float* sPw = sP + (((ch) & 1) ? PBUF : 0);                                                              \
-        const int nvalid = Cin - (ch) * CK;                   /* channels-in-chunk below this are real */         \
+        const int nvalid = Cin - (ch) * CK;                                                                     \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
-            float v = pd[sl];                                                                                   \
-            if (PRO >= 1) v = a.coef ? v * pA[sl] + pB[sl] : v;                                                 \
-            if (PRO == 2) v = silu_w(v);                                                                        \
+            float v = D[sl];                                                                                    \
+            if (PRO >= 1) {                                                                                     \
+                const int cch = min((ch) * CK + (p_ci[sl] & (CK - 1)), Cin - 1);                                \
+                const f32x2 cf = *reinterpret_cast<const f32x2*>(sCo + cch * 2);                                \
+                v = v * cf.x + cf.y;                                                                            \
+            }                                                                                                   \
+            if (PRO == 2) v = silu_wr(v);                                                                       \
             sPw[p_lds[sl]] = (p_ci[sl] < min(nvalid, CK)) ? v : 0.0f;                                           \
         }                                                                                                       \
     }
-    /* B^T d B, two of the four rows of B^T d per thread (s_h), -> 8 of the 16 position planes of V(ch) */
-#define WINO_WRITE_V(ch)                                                                                        \
+    /* row grp of B^T d (rows RA, RB of the window, combined with wave-uniform +-1 factors), then (.) B: four position     \
+       values -> V(ch)[ci][grp*4 + j][tile]; two (channel, tile) tasks per thread (channels s_ci and s_ci + 8) */            \
+#define WR_WRITE_V(ch)                                                                                          \
     {                                                                                                           \
-        float* vdst = sV + (((ch) & 1) ? VSZ : 0) + s_ci * 16 * T + s_tile;                                     \
         const float* sPr = sP + (((ch) & 1) ? PBUF : 0);                                                        \
-        float ra[4], rb[4], rcc[4];                               /* window rows s_h, s_h+1, s_h+2 */           \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-            ra[j] = sPr[p_rd + j];                                                                              \
-            rb[j] = sPr[p_rd + PP + j];                                                                         \
-            rcc[j] = sPr[p_rd + 2 * PP + j];                                                                    \
-        }                                                                                                       \
-        float mA[4], mB[4];              /* s_h=0: rows 0 (t0-t2), 1 (t1+t2)   s_h=1: rows 3 (t1-t3), 2 (t2-t1) */ \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-            mA[j] = ra[j] - rcc[j];                                                                             \
-            mB[j] = s_h ? (rb[j] - ra[j]) : (rb[j] + rcc[j]);                                                   \
-        }                                                                                                       \
-        const int iA = s_h ? 3 : 0, iB = s_h ? 2 : 1;                                                           \
-        vdst[(iA * 4 + 0) * T] = mA[0] - mA[2];                                                                 \
-        vdst[(iA * 4 + 1) * T] = mA[1] + mA[2];                                                                 \
-        vdst[(iA * 4 + 2) * T] = mA[2] - mA[1];                                                                 \
-        vdst[(iA * 4 + 3) * T] = mA[1] - mA[3];                                                                 \
-        vdst[(iB * 4 + 0) * T] = mB[0] - mB[2];                                                                 \
-        vdst[(iB * 4 + 1) * T] = mB[1] + mB[2];                                                                 \
-        vdst[(iB * 4 + 2) * T] = mB[2] - mB[1];                                                                 \
-        vdst[(iB * 4 + 3) * T] = mB[1] - mB[3];                                                                 \
-    }
-#define WINO_MFMA(kp)                                                                                           \
-    {                                                                                                           \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                         \
-            const int row = (2 * (kp) + half) * 16 + wave * 2 + q;                                              \
-            const float bv = sVc[row * T + l31];                                                                \
-            _Pragma("unroll") for (int ct = 0; ct < COT; ++ct)                                                  \
-                acc[q][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(sUc[row * BCO + ct * 32 + l31], bv, acc[q][ct], 0, 0, 0); \
+        float* vdst = sV + (((ch) & 1) ? VSZ : 0) + v_wr;                                                       \
+        _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                                                      \
+            float m[4];                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+                const float va = sPr[p_rdA + k2 * 8 * 10 * PP + j], vb = sPr[p_rdB + k2 * 8 * 10 * PP + j];     \
+                m[j] = __builtin_fmaf(v_fb, vb, v_fa * va);  /* +-va +- vb, exact: the factors are +-1 */        \
+            }                                                                                                   \
+            vdst[k2 * 8 * 16 * T + 0 * T] = m[0] - m[2];                                                        \
+            vdst[k2 * 8 * 16 * T + 1 * T] = m[1] + m[2];                                                        \
+            vdst[k2 * 8 * 16 * T + 2 * T] = m[2] - m[1];                                                        \
+            vdst[k2 * 8 * 16 * T + 3 * T] = m[1] - m[3];                                                        \
         }                                                                                                       \
     }
+    /* B operand of MFMA group g (k-pair g of the 16-channel chunk): V[ci = 2g + half][xi = wave][tile l31] */
+#define WR_LOAD_B(g, BV) BV = sVc[((2 * (g) + half) * 16 + wave) * T + l31];
+    /* MFMA group: k-pair kp (0..3) of the weight unit held in register set S */
+#define WR_DO_MFMA(kp, BV, S)                                                                                   \
+    _Pragma("unroll") for (int ct = 0; ct < COT; ++ct)                                                          \
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(S[((kp) * COT + ct) >> 2][((kp) * COT + ct) & 3], BV, acc[ct], 0, 0, 0);
 
-    f32x16 acc[2][COT];
+    f32x16 acc[COT];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int ct = 0; ct < COT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < COT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][ct][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
 
+    // diagnostics (mcvd_ctx_set_debug_buffer): shader-clock time the wave a.wdma spends per phase
+    const bool rec = a.dbg != nullptr && wave == a.wdma;
+    unsigned long long tk0 = 0, tprev = 0, dt[2] = {0, 0};
+    if (rec) tk0 = tprev = __builtin_amdgcn_s_memtime();
+#define WR_STAMP(i)                                                                                             \
+    if (rec) {                                                                                                  \
+        const unsigned long long now = __builtin_amdgcn_s_memtime();                                            \
+        dt[i] += now - tprev;                                                                                   \
+        tprev = now;                                                                                            \
+    }
+
+    // ---- prologue: every global load of the first chunks + the coefficient table is issued before anything waits
     const int nchunks = a.CinP / CK;
-    if (VAR == 0) {
-        // two barriers per chunk: patch(ch+1) is written before the mid-chunk barrier and transformed after it
-        WINO_DMA_U(0);
-        WINO_LOAD_P(0);
-        WINO_WRITE_P(0);
-        __syncthreads();                       // patch(0) visible
-        WINO_WRITE_V(0);
-        WINO_LOAD_P(1);
-        __syncthreads();                       // V(0) visible, U(0) landed (the fence drains the DMA)
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const bool more = ch + 1 < nchunks;
-            if (more) WINO_DMA_U(ch + 1);
-            const float* sUc = sU + ((ch & 1) ? USZ : 0);
-            const float* sVc = sV + ((ch & 1) ? VSZ : 0);
-            WINO_MFMA(0)
-            if (more) WINO_WRITE_P(ch + 1);    // registers were loaded during the previous chunk
-            WINO_MFMA(1)
-            __syncthreads();                   // patch(ch+1) visible to the tile transforms
-            if (more) WINO_LOAD_P(ch + 2);
-            WINO_MFMA(2)
-            if (more) WINO_WRITE_V(ch + 1);
-            WINO_MFMA(3)
-            __syncthreads();                   // chunk ch consumed by every wave; V(ch+1) visible; U(ch+1) landed
-        }
-    } else {
-        // ONE barrier per chunk.  While the MFMAs consume (U, V)(ch): patch(ch+2) is activated out of the registers loaded
-        // one chunk earlier into the other patch buffer, the raw loads of patch(ch+3) and the DMA of U(ch+1) are issued (all
-        // at the top, so the barrier's vmcnt(0) never waits on a young load), V(ch+1) is made from patch(ch+1).
-        // Chunks past the end are staged as zeros (clamped loads), so the loop body carries no branches.
-        WINO_DMA_U(0);
-        WINO_LOAD_P(0);
-        WINO_WRITE_P(0);
-        WINO_LOAD_P(1);
-        __syncthreads();                       // patch(0) visible
-        WINO_WRITE_V(0);
-        WINO_WRITE_P(1);
-        WINO_LOAD_P(2);
-        __syncthreads();                       // V(0), patch(1) visible, U(0) landed
-        for (int ch = 0; ch + 1 < nchunks; ++ch) {
-            const float* sUc = sU + ((ch & 1) ? USZ : 0);
-            const float* sVc = sV + ((ch & 1) ? VSZ : 0);
-            WINO_WRITE_P(ch + 2);
-            WINO_LOAD_P(ch + 3);
-            WINO_DMA_U(ch + 1);
-            if (VAR == 2) {
-                // the two waves of a SIMD (w, w+4) run their VALU-heavy tile transforms at different points of the chunk
-                if (wave < 4) {
-                    WINO_MFMA(0)
-                    WINO_WRITE_V(ch + 1);
-                    WINO_MFMA(1)
-                    WINO_MFMA(2)
-                    WINO_MFMA(3)
-                } else {
-                    WINO_MFMA(0)
-                    WINO_MFMA(1)
-                    WINO_MFMA(2)
-                    WINO_WRITE_V(ch + 1);
-                    WINO_MFMA(3)
-                }
-            } else {
-                WINO_MFMA(0)
-                WINO_WRITE_V(ch + 1);
-                WINO_MFMA(1)
-                WINO_MFMA(2)
-                WINO_MFMA(3)
-                if (VAR == 3) {
-                    // pin an interleave: every MFMA is followed by a slice of the staging work of this iteration
-                    _Pragma("unroll") for (int i = 0; i < 8 * COT; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
-                        __builtin_amdgcn_sched_group_barrier(0x002, 24 / COT, 0);   // VALU
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
-                    }
-                }
-            }
-            __syncthreads();                   // chunk ch consumed by every wave; V(ch+1), patch(ch+2) visible; U(ch+1) landed
-        }
-        {
-            const int ch = nchunks - 1;
-            const float* sUc = sU + ((ch & 1) ? USZ : 0);
-            const float* sVc = sV + ((ch & 1) ? VSZ : 0);
-            WINO_MFMA(0)
-            WINO_MFMA(1)
-            WINO_MFMA(2)
-            WINO_MFMA(3)
-            __syncthreads();                   // the epilogue reuses the LDS
-        }
+    f32x4 A0[COT], A1[COT];                // A operands of the even / odd weight unit (first / second half of a chunk)
+    float pd[MAXP];                        // raw patch registers, loaded one chunk ahead of their activation
+    {
+        float q0[MAXP], q1[MAXP];          // patches of chunks 0 and 1: prologue only
+        f32x2 cfl = {1.0f, 0.0f};
+        WR_LOAD_A(0, A0)
+        WR_LOAD_A(1, A1)
+        WR_LOAD_P(0, q0)
+        WR_LOAD_P(1, q1)
+        WR_LOAD_P(2, pd)
+        if (PRO && a.coef && tid < Cin) cfl = *reinterpret_cast<const f32x2*>(a.coef + ((long)b * Cin + tid) * 2);
+        if (PRO && tid < Cin) *reinterpret_cast<f32x2*>(sCo + tid * 2) = cfl;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ONE memory latency for everything above (the asm loads are
+        WR_WAIT_A(0, A0)                                     // not tracked by the compiler: the waits are threaded through
+        WR_WAIT_A(0, A1)                                     // the destination registers)
+        WR_WAIT_P(0, q0)
+        WR_WAIT_P(0, q1)
+        WR_WAIT_P(0, pd)
+        if (PRO) __syncthreads();          // coefficient table visible
+        WR_WRITE_P(0, q0)
+        WR_WRITE_P(1, q1)
     }
+    __syncthreads();                       // patch(0), patch(1) visible
+    WR_WRITE_V(0)
+    __syncthreads();                       // V(0) visible
+    WR_STAMP(0)
+
+    // ---- K loop.  VMEM issue order of a wave in chunk c (in-order vmcnt counter; nothing else is outstanding):
+    //   top:  A1 <- unit 2c+1 (COT loads), patch(c+3) (3 loads)      mid (after group 3):  A0 <- unit 2c+2 (COT loads)
+    // wait points:  patch(c+2) write at the top, before the new loads: everything but the COT loads of `mid` of chunk c-1
+    //               first use of A1 (group 4): issued at the top, younger = 3 patch + COT mid loads
+    //               first use of A0 (group 0 of the next chunk): issued at mid, younger = COT + 3 loads of that chunk's top
+    float xb = 0.0f, yb = 0.0f;            // B operands; yb = 0: the first "deferred" group multiplies zeros
+    for (int c = 0; c + 1 < nchunks; ++c) {
+        const float* sVc = sV + ((c & 1) ? VSZ : 0);
+        WR_DO_MFMA(3, yb, A1)              // group 7 of the previous chunk (operands were read before the barrier)
+        WR_LOAD_B(0, xb)
+        if (COT == 1) { WR_WAIT_P(1, pd) } else if (COT == 2) { WR_WAIT_P(2, pd) } else { WR_WAIT_P(3, pd) }
+        WR_WRITE_P(c + 2, pd)
+        WR_LOAD_A(2 * c + 1, A1)
+        WR_LOAD_P(c + 3, pd)
+        if (grp == 3) WR_WRITE_V(c + 1)    // slot T
+        if (COT == 1) { WR_WAIT_A(4, A0) } else if (COT == 2) { WR_WAIT_A(5, A0) } else { WR_WAIT_A(6, A0) }
+        WR_DO_MFMA(0, xb, A0)              // g0
+        WR_LOAD_B(1, yb)
+        if (grp == 2) WR_WRITE_V(c + 1)
+        WR_DO_MFMA(1, yb, A0)              // g1
+        WR_LOAD_B(2, xb)
+        if (grp == 0) WR_WRITE_V(c + 1)
+        WR_DO_MFMA(2, xb, A0)              // g2
+        WR_LOAD_B(3, yb)
+        if (grp == 1) WR_WRITE_V(c + 1)
+        WR_DO_MFMA(3, yb, A0)              // g3
+        WR_LOAD_B(4, xb)
+        WR_LOAD_A(2 * c + 2, A0)           // mid: first unit of the next chunk
+        if (COT == 1) { WR_WAIT_A(4, A1) } else if (COT == 2) { WR_WAIT_A(5, A1) } else { WR_WAIT_A(6, A1) }
+        WR_DO_MFMA(0, xb, A1)              // g4
+        WR_LOAD_B(5, yb)
+        WR_DO_MFMA(1, yb, A1)              // g5
+        WR_LOAD_B(6, xb)
+        WR_DO_MFMA(2, xb, A1)              // g6
+        WR_LOAD_B(7, yb)                   // g7 is deferred past the barrier
+        // chunk c read by every wave; V(c+1), patch(c+2) visible.  LDS traffic only: no VMEM wait at the barrier.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    {
+        const int c = nchunks - 1;
+        const float* sVc = sV + ((c & 1) ? VSZ : 0);
+        WR_DO_MFMA(3, yb, A1)
+        WR_LOAD_A(2 * c + 1, A1)
+        WR_LOAD_B(0, xb)
+        if (COT == 1) { WR_WAIT_A(1, A0) } else if (COT == 2) { WR_WAIT_A(2, A0) } else { WR_WAIT_A(3, A0) }
+        WR_DO_MFMA(0, xb, A0)
+        WR_LOAD_B(1, yb)
+        WR_DO_MFMA(1, yb, A0)
+        WR_LOAD_B(2, xb)
+        WR_DO_MFMA(2, xb, A0)
+        WR_LOAD_B(3, yb)
+        WR_DO_MFMA(3, yb, A0)
+        WR_LOAD_B(4, xb)
+        WR_WAIT_A(0, A1)
+        WR_DO_MFMA(0, xb, A1)
+        WR_LOAD_B(5, yb)
+        WR_DO_MFMA(1, yb, A1)
+        WR_LOAD_B(6, xb)
+        WR_DO_MFMA(2, xb, A1)
+        WR_LOAD_B(7, yb)
+        WR_DO_MFMA(3, yb, A1)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stray patch prefetches past the last chunk
 
     // ---------------- inverse transform + epilogue, one 32-cout sub-tile at a time ----------------
-    float* sM = smem;                      // [16][32 couts][32 tiles] = 64 KiB, the K loop is done with the LDS
-    const int e_tile = tid & 31;
+    // The barriers below guard LDS only (s_waitcnt lgkmcnt(0) + s_barrier): the residual loads of the NEXT sub-tile are issued
+    // a round ahead and stay in flight across them.
+    float* sM = smem;                      // [16 positions][32 couts][32 tiles] = 64 KiB
+    const int e_tile = tid & 31, e_col = tid >> 5;
     const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
     const long pix = (long)(oy0 + 2 * e_ty) * W + ox0 + 2 * e_tx;
+    f32x2 rn0 = {0.0f, 0.0f}, rn1 = {0.0f, 0.0f};
+#define WR_LOAD_RES(ct)                                                                                         \
+    if (a.res) {                                                                                                \
+        const long o = ((long)b * a.Cout + min(co0 + (ct) * 32 + e_col, a.Cout - 1)) * HW + pix;                \
+        rn0 = *reinterpret_cast<const f32x2*>(a.res + o);                                                       \
+        rn1 = *reinterpret_cast<const f32x2*>(a.res + o + W);                                                   \
+    }
+    WR_LOAD_RES(0)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the K loop is done with the LDS
+    WR_STAMP(1)
 #pragma unroll
     for (int ct = 0; ct < COT; ++ct) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int xi = wave * 2 + q;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = (r & 3) + 8 * (r >> 2) + 4 * half;
-                sM[(xi * 32 + col) * T + l31] = acc[q][ct][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int col = (r & 3) + 8 * (r >> 2) + 4 * half;
+            sM[(wave * 32 + col) * T + l31] = acc[ct][r];
         }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int col = (tid >> 5) + 16 * k;                // cout within the sub-tile
-            const int co = co0 + ct * 32 + col;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            const f32x2 r0 = rn0, r1 = rn1;
+            if (ct + 1 < COT) WR_LOAD_RES(ct + 1)
+            const int co = co0 + ct * 32 + e_col;
             float mm[16];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) mm[xi] = sM[(xi * 32 + col) * T + e_tile];
+            for (int xi = 0; xi < 16; ++xi) mm[xi] = sM[(xi * 32 + e_col) * T + e_tile];
             float t0[4], t1[4];                                 // A^T M
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
@@ -305,23 +338,68 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(ConvArgs a) {
             const float bvv = a.bias[co];                       // zero-padded to CoutP
             if (co < a.Cout) {
                 const long o = ((long)b * a.Cout + co) * HW + pix;
-                y00 += bvv; y01 += bvv; y10 += bvv; y11 += bvv;
-                if (a.res) {
-                    const float2 r0 = *reinterpret_cast<const float2*>(a.res + o);
-                    const float2 r1 = *reinterpret_cast<const float2*>(a.res + o + W);
-                    y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
-                }
+                y00 += bvv + r0.x; y01 += bvv + r0.y; y10 += bvv + r1.x; y11 += bvv + r1.y;
                 *reinterpret_cast<float2*>(a.y + o) = make_float2(y00 * a.out_scale, y01 * a.out_scale);
                 *reinterpret_cast<float2*>(a.y + o + W) = make_float2(y10 * a.out_scale, y11 * a.out_scale);
             }
         }
-        __syncthreads();
+        if (ct + 1 < COT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-#undef WINO_DMA_U
-#undef WINO_LOAD_P
-#undef WINO_WRITE_P
-#undef WINO_WRITE_V
-#undef WINO_MFMA
+#undef WR_LOAD_RES
+    if (rec) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* d = a.dbg + (long)blockIdx.x * 8;
+            d[0] = dt[0]; d[1] = dt[1]; d[2] = 0; d[3] = 0; d[4] = 0;      // prologue, K loop
+            d[5] = now - tprev;            // epilogue
+            d[6] = (unsigned long long)nchunks;
+            d[7] = now - tk0;
+        }
+    }
+#undef WR_STAMP
+#undef WR_LOAD_A
+#undef WR_WAIT_A
+#undef WR_LOAD_P
+#undef WR_WAIT_P
+#undef WR_WRITE_P
+#undef WR_WRITE_V
+#undef WR_LOAD_B
+#undef WR_DO_MFMA
+}
+
+static size_t wino_lds_bytes(int Cin) {
+    const size_t k = (size_t)(2 * WR_CK * 16 * WR_T + 2 * (WR_CK * 10 * 20 + 4) + 2 * Cin) * sizeof(float);
+    const size_t epi = (size_t)16 * 32 * WR_T * sizeof(float);        // sM of the epilogue
+    return k > epi ? k : epi;
+}
+
+template <int COT, int PRO>
+static int wino_launch2(const ConvArgs& a, hipStream_t s) {
+    constexpr int BCO = 32 * COT;
+    const size_t lds = wino_lds_bytes(a.Cin);
+    static bool raised = false;
+    if (!raised) {
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<COT, PRO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    const int nreg = a.B * (a.H / 8) * (a.W / 16);
+    dim3 grid(((nreg + 7) / 8) * 8 * (a.CoutP / BCO));
+    ConvArgs k = a;
+    if (k.dbg) {
+        const char* w = getenv("MCVD_DBG_WAVE");       // which wave records its phase times (diagnostics)
+        k.wdma = w ? atoi(w) : 0;
+    }
+    hipLaunchKernelGGL((conv_wino_kernel<COT, PRO>), grid, dim3(WR_NT), lds, s, k);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int COT>
+static int wino_launch(const ConvArgs& a, hipStream_t s) {
+    if (!a.coef && !a.act) return wino_launch2<COT, 0>(a, s);
+    if (!a.act) return wino_launch2<COT, 1>(a, s);
+    return wino_launch2<COT, 2>(a, s);
 }
 
 bool conv_wino_supported(int ks, int H, int W) { return ks == 3 && H % 8 == 0 && W % 16 == 0 && H >= 8 && W >= 16; }
@@ -332,66 +410,20 @@ int conv_wino_cout_tile(int Cout) {
     return 1;
 }
 
-static int env_int_w(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
-template <int COT, int PRO, int VAR>
-static int wino_launch3(const ConvArgs& a, hipStream_t s) {
-    constexpr int BCO = 32 * COT;
-    const size_t lds = (size_t)(2 * WINO_CK * 16 * BCO + 2 * WINO_CK * 16 * WINO_T + 2 * (WINO_CK * 10 * 20 + 4)) * sizeof(float);
-    static bool raised = false;
-    if (!raised) {
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<COT, PRO, VAR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised = true;
-    }
-    dim3 grid(a.B * (a.H / 8) * (a.W / 16), a.CoutP / BCO);
-    hipLaunchKernelGGL((conv_wino_kernel<COT, PRO, VAR>), grid, dim3(512), lds, s, a);
-    MCVD_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-template <int COT, int PRO>
-static int wino_launch2(const ConvArgs& a, hipStream_t s) {
-    switch (conv_wino_variant()) {
-        case 0: return wino_launch3<COT, PRO, 0>(a, s);
-        case 3: return wino_launch3<COT, PRO, 3>(a, s);
-        case 1: return wino_launch3<COT, PRO, 1>(a, s);
-        default: return wino_launch3<COT, PRO, 2>(a, s);
-    }
-}
-
-template <int COT>
-static int wino_launch(const ConvArgs& a, hipStream_t s) {
-    if (!a.coef && !a.act) return wino_launch2<COT, 0>(a, s);
-    if (!a.act) return wino_launch2<COT, 1>(a, s);
-    return wino_launch2<COT, 2>(a, s);
-}
-
-// Which Winograd kernel serves shape id 4 (env MCVD_WINO_VAR, read once): 5 = 1024 threads, weights register-fed from global
-// memory (conv_wino16r.cpp, default); 4 = 1024 threads, weights LDS-staged by DMA (conv_wino16.cpp); 0..3 = the 512-thread
-// kernel of this file with its pipeline variants.  The packed weight layout depends on it (launch_pack_wino_weight).
-int conv_wino_variant() {
-    static const int var = env_int_w("MCVD_WINO_VAR", 5);
-    return var;
-}
-
+// Shape id 4 applies to this launch: geometry, channel layout, packed weights present.
 bool conv_wino_usable(const ConvArgs& a) {
-    if (!conv_wino_supported(a.ks, a.H, a.W) || !a.wpw) return false;
-    if (conv_wino_variant() == 5) return conv_wino16r_supported(a);
-    return a.CinP % WINO_CK == 0 && (a.C1 == 0 || a.C0 % WINO_CK == 0);
+    return conv_wino_supported(a.ks, a.H, a.W) && a.wpw && a.Cin <= 1024 && a.CinP % WR_CK == 0 &&
+           (a.C1 == 0 || a.C0 % WR_CK == 0) &&                                       // a chunk never straddles the concat seam
+           (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) &&      // 32-bit byte offsets of the patch loads
+           wino_lds_bytes(a.Cin) <= 160 * 1024;
 }
 
+// a.wpw must hold the operand-major layout (launch_pack_wino_weight) packed for conv_wino_cout_tile(Cout).
 int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
     MCVD_REQUIRE(conv_wino_usable(a), "winograd conv: unsupported (ks=%d H=%d W=%d Cin=%d C0=%d, packed weights %s)", a.ks, a.H, a.W,
                  a.Cin, a.C0, a.wpw ? "present" : "missing");
     const int cot = conv_wino_cout_tile(a.Cout);
     MCVD_REQUIRE(a.CoutP % (32 * cot) == 0, "winograd conv: CoutP=%d vs tile %d", a.CoutP, 32 * cot);
-    const int var = conv_wino_variant();
-    if (var == 5) return launch_conv_wino16r(a, cot, s);
-    if (var == 4 && a.Cin <= 1024) return launch_conv_wino16(a, cot, s);    // 1024-thread workgroups (conv_wino16.cpp)
     switch (cot) {
         case 1: return wino_launch<1>(a, s);
         case 2: return wino_launch<2>(a, s);
@@ -399,9 +431,12 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
     }
 }
 
-// U = G g G^T per (cout, cin):  [Cout][Cin][3][3] -> Up[(ci*16 + xi)*CoutP + co]
-__global__ void pack_wino_weight_kernel(const float* w, float* up, int Cout, int Cin, int CoutP) {
+// U = G g G^T per (cout, cin), stored operand-major:
+//   up[((((cotile*nunits + ci/8)*16 + xi)*COT + idx/4)*64 + lane)*4 + idx%4],   idx = ((ci%8)/2)*COT + (co%BCO)/32,
+//   lane = (ci%2)*32 + co%32.   The buffer (CinP*16*CoutP floats) must be zero-filled: padded channels stay zero.
+__global__ void pack_wino_weight_kernel(const float* w, float* up, int Cout, int Cin, int CinP, int CoutP, int COT) {
     const long n = (long)Cout * Cin;
+    const int BCO = 32 * COT, nunits = CinP / 8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int ci = (int)(i % Cin), co = (int)(i / Cin);
         const float* g = w + i * 9;
@@ -413,27 +448,31 @@ __global__ void pack_wino_weight_kernel(const float* w, float* up, int Cout, int
             t[2][j] = 0.5f * (g[0 * 3 + j] - g[1 * 3 + j] + g[2 * 3 + j]);
             t[3][j] = g[2 * 3 + j];
         }
+        const int cotile = co / BCO, ct = (co % BCO) / 32, lane = (ci & 1) * 32 + (co & 31);
+        const int idx = ((ci & 7) >> 1) * COT + ct;
+        const long base = ((((long)cotile * nunits + (ci >> 3)) * 16) * COT + (idx >> 2)) * 256 + lane * 4 + (idx & 3);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                           // (.) G^T
             const float u0 = t[r][0];
             const float u1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
             const float u2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
             const float u3 = t[r][2];
-            float* dst = up + ((long)ci * 16 + r * 4) * CoutP + co;
-            dst[0] = u0;
-            dst[(long)CoutP] = u1;
-            dst[2L * CoutP] = u2;
-            dst[3L * CoutP] = u3;
+            const long stride = (long)COT * 256;                // one position further
+            up[base + (r * 4 + 0) * stride] = u0;
+            up[base + (r * 4 + 1) * stride] = u1;
+            up[base + (r * 4 + 2) * stride] = u2;
+            up[base + (r * 4 + 3) * stride] = u3;
         }
     }
 }
 
-// `up` (CinP*16*CoutP floats) must be zero-filled by the caller: padded channels stay zero in either layout.
+// `up` (CinP*16*CoutP floats) must be zero-filled by the caller: padded channels stay zero.
 int launch_pack_wino_weight(const float* w, float* up, int Cout, int Cin, int CinP, int CoutP, hipStream_t s) {
-    if (conv_wino_variant() == 5) return launch_pack_wino_weight_r(w, up, Cout, Cin, CinP, CoutP, conv_wino_cout_tile(Cout), s);
+    const int cot = conv_wino_cout_tile(Cout);
+    MCVD_REQUIRE(CinP % 8 == 0 && CoutP % (32 * cot) == 0, "pack_wino_weight: CinP=%d CoutP=%d cot=%d", CinP, CoutP, cot);
     const long n = (long)Cout * Cin;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    hipLaunchKernelGGL(pack_wino_weight_kernel, dim3(blocks), dim3(256), 0, s, w, up, Cout, Cin, CoutP);
+    hipLaunchKernelGGL(pack_wino_weight_kernel, dim3(blocks), dim3(256), 0, s, w, up, Cout, Cin, CinP, CoutP, cot);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -691,13 +691,16 @@ int mcvd_model::autotune(int B) {
                 }
             }
             a.cot = op.cot;
-            if (op.ks == 1 && ctx->conv_dma1 && conv1x1_dma_supported(a)) {       // 5 = all-DMA 1x1 GEMM, cout tiles of its own
+            if (op.ks == 1 && ctx->conv_dma1) {        // 5 / 6 = all-DMA 1x1 GEMM (16 / 32 channels per chunk), cout tiles of its own
                 static const int g1_cots[] = {9, 6, 4, 3, 2, 1};
-                int tried = 0;
-                for (int c : g1_cots) {
-                    if ((op.CoutP / 32) % c != 0 || tried >= 3) continue;
-                    ++tried;
-                    if (int rc = time_candidate(5, c)) return rc;
+                for (int ck = 16; ck <= 32; ck += 16) {
+                    if (!conv1x1_dma_supported(a, ck)) continue;
+                    int tried = 0;
+                    for (int c : g1_cots) {
+                        if ((op.CoutP / 32) % c != 0 || tried >= 3 || (ck == 32 && c == 9)) continue;
+                        ++tried;
+                        if (int rc = time_candidate(ck == 16 ? 5 : 6, c)) return rc;
+                    }
                 }
             }
             it = best.emplace(k, choice).first;

@@ -195,7 +195,7 @@ def phases(f):
 
 
 def wphases(f):
-    """Winograd (conv_wino16.cpp) phase breakdown of one wave (env MCVD_DBG_WAVE), shader-clock units."""
+    """Winograd (conv_wino.cpp) coarse phase breakdown of one wave (env MCVD_DBG_WAVE), shader-clock units."""
     from tests.hiputil import Ctx, P
     ctx = Ctx()
     B = 64
@@ -215,7 +215,6 @@ def wphases(f):
         _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
         ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
         torch.cuda.synchronize()
-        f.write(f"[diag {os.environ.get('MCVD_WINO_DIAG', '0')}] ")
         _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
         d = dbg.view(-1, 8).cpu().double()
         d = d[d[:, 7] > 0]

@@ -73,6 +73,9 @@ CONV_CASES = [
     (3, 128, 0, 128, 16, 1, True, 0, True, 5 + 16 * 4),
     (1, 96, 0, 96, 64, 1, False, 0, False, 5 + 16 * 1),
     (3, 72, 0, 64, 16, 1, False, 0, True, 5),       # Cin not a multiple of the DMA chunk: falls back to the staged kernel
+    (2, 192, 0, 576, 32, 1, True, 0, False, 6 + 16 * 3),   # all-DMA, 32-channel chunks
+    (2, 96, 96, 192, 32, 1, False, 0, False, 6 + 16 * 6),  # ... over a concat, cout tile 6 (82 KiB of LDS)
+    (3, 288, 0, 288, 8, 1, True, 1, True, 6 + 16 * 1),     # ... two images per pixel tile, affine + SiLU, residual
 ]
 
 

@@ -54,10 +54,10 @@ def test_attention_index_maps(B, C, heads, S):
     np.testing.assert_allclose(got, want.numpy(), rtol=1e-8, atol=1e-8)
 
 
-@pytest.mark.parametrize("B,C0,C1,Cout,H,W,COT", [(1, 8, 5, 40, 16, 16, 2), (2, 8, 0, 96, 8, 32, 3), (1, 16, 8, 32, 16, 32, 1), (1, 10, 0, 32, 8, 16, 1), (3, 16, 20, 40, 8, 16, 2)])
-@pytest.mark.parametrize("emu", ["wino_emulate", "wino16_emulate", "wino16r_emulate"])
-def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT, emu):
-    """conv_wino.cpp: staging roles, U/V LDS layouts, MFMA lane maps, the LDS exchange and the 2x2 inverse transform."""
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W,COT", [(1, 16, 5, 40, 16, 16, 2), (2, 8, 0, 96, 8, 32, 3), (1, 16, 8, 32, 16, 32, 1), (1, 10, 0, 32, 8, 16, 1), (3, 16, 20, 40, 8, 16, 2)])
+def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT):
+    """conv_wino.cpp: patch slots, transform tasks, V layout, operand-major weights, MFMA lane maps, block id -> (region, cout
+    tile), the LDS exchange and the 2x2 inverse transform."""
     g = torch.Generator().manual_seed(4)
     x0 = torch.randn(B, C0, H, W, generator=g)
     x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
@@ -67,13 +67,8 @@ def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT, emu):
     coef = torch.stack([1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], -1)
     res = torch.randn(B, Cout, H, W, generator=g)
     CinP, CoutP = _round_up(Cin, 16), _round_up(Cout, 32 * COT)
-    if emu == "wino16r_emulate":
-        if C1 and C0 % 16:
-            pytest.skip("the register-fed kernel needs the concat seam on a 16-channel boundary")
-        up = E.pack_wino_weight_r(w.numpy(), CinP, CoutP, COT)
-    else:
-        up = E.pack_wino_weight(w.numpy(), CinP, CoutP)
-    got = getattr(E, emu)(x0.numpy(), None if x1 is None else x1.numpy(), up, bias.numpy(), coef.numpy(), 1, res.numpy(), 0.5,
+    up = E.pack_wino_weight(w.numpy(), CinP, CoutP, COT)
+    got = E.wino_emulate(x0.numpy(), None if x1 is None else x1.numpy(), up, bias.numpy(), coef.numpy(), 1, res.numpy(), 0.5,
                          Cout, CoutP, CinP, COT)
     xin = torch.cat([x0, x1], 1) if C1 else x0
     xin = xin * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]
@@ -82,6 +77,7 @@ def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT, emu):
     np.testing.assert_allclose(got, want.numpy(), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("CK", [16, 32])
 @pytest.mark.parametrize("B,C0,C1,Cout,H,W,COT,pro", [
     (3, 16, 0, 40, 8, 8, 2, 1),        # HW=64: two images per pixel tile, B odd -> ragged last tile, ragged Cout
     (1, 16, 16, 96, 16, 16, 3, 0),     # concat, COT=3 (384 weight pieces: 1.5 DMA rounds)
@@ -89,9 +85,11 @@ def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT, emu):
     (1, 16, 0, 288, 16, 8, 9, 1),      # COT=9
     (2, 16, 0, 64, 16, 16, 1, 1),      # several cout tiles per pixel tile (XCD-grouped block ids)
 ])
-def test_gemm1x1_index_maps(B, C0, C1, Cout, H, W, COT, pro):
+def test_gemm1x1_index_maps(B, C0, C1, Cout, H, W, COT, pro, CK):
     """conv1x1_dma.cpp: DMA piece maps, coefficient table, block id -> tile map, epilogue map."""
     g = torch.Generator().manual_seed(5)
+    if CK == 32:
+        C0, C1 = 2 * C0, 2 * C1            # 32-channel chunks: channel counts and the concat seam on 32-boundaries
     x0 = torch.randn(B, C0, H, W, generator=g)
     x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
     Cin = C0 + C1
@@ -102,7 +100,7 @@ def test_gemm1x1_index_maps(B, C0, C1, Cout, H, W, COT, pro):
     CinP, CoutP = _round_up(Cin, 32), _round_up(Cout, 32 * COT)
     wp = E.pack_weight(w.numpy(), CinP, CoutP)
     got = E.gemm1x1_emulate(x0.numpy(), None if x1 is None else x1.numpy(), wp, bias.numpy(),
-                            coef.numpy() if pro else None, pro == 2, res.numpy(), 0.5, Cout, CoutP, CinP, COT)
+                            coef.numpy() if pro else None, pro == 2, res.numpy(), 0.5, Cout, CoutP, CinP, COT, CK)
     xin = torch.cat([x0, x1], 1) if C1 else x0
     if pro:
         xin = xin * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]

@@ -229,251 +229,8 @@ def attn_emulate(qkv, heads):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def pack_wino_weight(w, CinP, CoutP):
-    """Mirror of pack_wino_weight_kernel: Up[(ci*16 + xi)*CoutP + co] = (G g G^T)[xi]."""
-    Cout, Cin = w.shape[:2]
-    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
-    up = np.zeros(CinP * 16 * CoutP)
-    for co in range(Cout):
-        for ci in range(Cin):
-            U = G @ w[co, ci].astype(np.float64) @ G.T
-            for xi in range(16):
-                up[(ci * 16 + xi) * CoutP + co] = U[xi // 4, xi % 4]
-    return up
-
-
-def wino_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT):
-    """Lane-level emulation of conv_wino_kernel's addressing (conv_wino.cpp): 512 threads, wave w owns positions 2w, 2w+1."""
-    B, C0, H, W = x0.shape
-    C1 = 0 if x1 is None else x1.shape[1]
-    Cin = C0 + C1
-    CK, T, BCO, NT, PP = 8, 32, 32 * COT, 512, 20
-    USZ, VSZ, PSZ = CK * 16 * BCO, CK * 16 * T, CK * 10 * PP
-    assert C1 == 0 or C0 % CK == 0, "the kernel needs the concat seam on a chunk boundary"
-    HW = H * W
-    x0f = x0.reshape(-1)
-    x1f = None if x1 is None else x1.reshape(-1)
-    coef_f = None if coef is None else coef.reshape(-1)
-    y = np.zeros((B, Cout, H, W))
-    silu = lambda v: v / (1 + np.exp(-v))
-    rx_n, ry_n = W // 16, H // 8
-    assert (USZ // 4) % NT == 0
-    for reg_id in range(B * rx_n * ry_n):
-        b = reg_id // (rx_n * ry_n)
-        rr = reg_id - b * (rx_n * ry_n)
-        oy0, ox0 = (rr // rx_n) * 8, (rr % rx_n) * 16
-        for cotile in range(CoutP // BCO):
-            co0 = cotile * BCO
-            acc = np.zeros((8, 2, COT, 16, 64))            # wave, q, ct, reg, lane
-            for ch in range(CinP // CK):
-                sU = np.full(USZ, np.nan)
-                sV = np.full(VSZ, np.nan)
-                sP = np.full(PSZ + 4, np.nan)
-                for tid in range(NT):
-                    wave = tid >> 6
-                    for s in range(USZ // 4 // NT):
-                        e = s * NT + tid
-                        row, c4 = e // (BCO // 4), e % (BCO // 4)
-                        g = ch * CK * 16 * CoutP + row * CoutP + co0 + c4 * 4
-                        # DMA image: wave-uniform base (s*NT + wave*64)*4 + lane*4 floats
-                        dst = (s * NT + wave * 64) * 4 + (tid & 63) * 4
-                        sU[dst:dst + 4] = up[g:g + 4]
-                    for sl in range((CK * 180 + NT - 1) // NT):
-                        e = sl * NT + tid
-                        if e >= CK * 180:
-                            sP[PSZ] = 0.0
-                            continue
-                        ci, rem = e // 180, e % 180
-                        r, cc_ = rem // 18, rem % 18
-                        yy, xx = oy0 - 1 + r, ox0 - 1 + cc_
-                        inside = 0 <= yy < H and 0 <= xx < W
-                        p_ci = ci + (0 if inside else CK)
-                        goff = min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)
-                        # WINO_LOAD_P: wave-uniform source / base, lane offset cl*HW + goff
-                        cb = min(ch * CK, Cin - 1)
-                        cmax = Cin - 1 - cb
-                        second = cb >= C0
-                        srcb = (x1f, (b * C1 + (cb - C0)) * HW) if second else (x0f, (b * C0 + cb) * HW)
-                        cl = min(p_ci & (CK - 1), cmax)
-                        v = srcb[0][srcb[1] + cl * HW + goff]
-                        if coef is not None:
-                            cfo = (b * Cin + cb) * 2 + cl * 2
-                            v = v * coef_f[cfo] + coef_f[cfo + 1]
-                        if act:
-                            v = silu(v)
-                        nvalid = Cin - ch * CK
-                        sP[ci * 10 * PP + r * PP + cc_] = v if p_ci < min(nvalid, CK) else 0.0
-                for tid in range(NT):
-                    s_ci, s_tile, s_h = (tid & 255) >> 5, tid & 31, tid >> 8
-                    s_ty, s_tx = s_tile >> 3, s_tile & 7
-                    p_rd = s_ci * 10 * PP + (2 * s_ty + s_h) * PP + 2 * s_tx
-                    ra = [sP[p_rd + j] for j in range(4)]
-                    rb = [sP[p_rd + PP + j] for j in range(4)]
-                    rc = [sP[p_rd + 2 * PP + j] for j in range(4)]
-                    mA = [ra[j] - rc[j] for j in range(4)]
-                    mB = [(rb[j] - ra[j]) if s_h else (rb[j] + rc[j]) for j in range(4)]
-                    iA, iB = (3, 2) if s_h else (0, 1)
-                    base = s_ci * 16 * T + s_tile
-                    for i, m in ((iA, mA), (iB, mB)):
-                        sV[base + (i * 4 + 0) * T] = m[0] - m[2]
-                        sV[base + (i * 4 + 1) * T] = m[1] + m[2]
-                        sV[base + (i * 4 + 2) * T] = m[2] - m[1]
-                        sV[base + (i * 4 + 3) * T] = m[1] - m[3]
-                assert not np.isnan(sV).any() and not np.isnan(sU).any()
-                for wave in range(8):
-                    for kp in range(CK // 2):
-                        for q in range(2):
-                            xi = wave * 2 + q
-                            bv = np.array([sV[((2 * kp + (l >> 5)) * 16 + xi) * T + (l & 31)] for l in range(64)])
-                            for ct in range(COT):
-                                av = np.array([sU[((2 * kp + (l >> 5)) * 16 + xi) * BCO + ct * 32 + (l & 31)] for l in range(64)])
-                                mfma_32x32x2(av, bv, acc[wave, q, ct])
-            for ct in range(COT):
-                sM = np.full(16 * 32 * T, np.nan)
-                for wave in range(8):
-                    for q in range(2):
-                        xi = wave * 2 + q
-                        for lane in range(64):
-                            for r in range(16):
-                                col = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-                                sM[(xi * 32 + col) * T + (lane & 31)] = acc[wave, q, ct, r, lane]
-                for tid in range(NT):
-                    e_tile = tid & 31
-                    e_ty, e_tx = e_tile >> 3, e_tile & 7
-                    for k in range(2):
-                        col = (tid >> 5) + 16 * k
-                        co = co0 + ct * 32 + col
-                        mm = np.array([sM[(xi * 32 + col) * T + e_tile] for xi in range(16)])
-                        t0 = [mm[0 + l] + mm[4 + l] + mm[8 + l] for l in range(4)]
-                        t1 = [mm[4 + l] - mm[8 + l] - mm[12 + l] for l in range(4)]
-                        ys = [[t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]], [t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]]]
-                        if co < Cout:
-                            for r in range(2):
-                                for cc in range(2):
-                                    yy, xx = oy0 + 2 * e_ty + r, ox0 + 2 * e_tx + cc
-                                    v = ys[r][cc] + bias[co]
-                                    if res is not None:
-                                        v += res[b, co, yy, xx]
-                                    y[b, co, yy, xx] = v * scale
-    return y
-
-
-def wino16_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT):
-    """Lane-level emulation of conv_wino16_kernel's addressing (conv_wino16.cpp): 1024 threads, wave w owns position w,
-    the tile transform is split by row of B^T d over the four 256-thread groups."""
-    B, C0, H, W = x0.shape
-    C1 = 0 if x1 is None else x1.shape[1]
-    Cin = C0 + C1
-    CK, T, BCO, NT, PP = 8, 32, 32 * COT, 1024, 20
-    USZ, VSZ, PSZ = CK * 16 * BCO, CK * 16 * T, CK * 10 * PP
-    assert C1 == 0 or C0 % CK == 0, "the kernel needs the concat seam on a chunk boundary"
-    HW = H * W
-    x0f = x0.reshape(-1)
-    x1f = None if x1 is None else x1.reshape(-1)
-    coef_f = None if coef is None else coef.reshape(-1)
-    y = np.zeros((B, Cout, H, W))
-    silu = lambda v: v / (1 + np.exp(-v))
-    rx_n, ry_n = W // 16, H // 8
-    assert (USZ // 4) % NT == 0
-    for reg_id in range(B * rx_n * ry_n):
-        b = reg_id // (rx_n * ry_n)
-        rr = reg_id - b * (rx_n * ry_n)
-        oy0, ox0 = (rr // rx_n) * 8, (rr % rx_n) * 16
-        for cotile in range(CoutP // BCO):
-            co0 = cotile * BCO
-            acc = np.zeros((16, COT, 16, 64))              # wave, ct, reg, lane
-            for ch in range(CinP // CK):
-                sU = np.full(USZ, np.nan)
-                sV = np.full(VSZ, np.nan)
-                sP = np.full(PSZ + 4, np.nan)
-                for tid in range(NT):
-                    wave = tid >> 6
-                    for s in range(USZ // 4 // NT):
-                        e = s * NT + tid
-                        row, c4 = e // (BCO // 4), e % (BCO // 4)
-                        g = ch * CK * 16 * CoutP + row * CoutP + co0 + c4 * 4
-                        # DMA image: wave-uniform base (s*NT + wave*64)*4 + lane*4 floats
-                        dst = (s * NT + wave * 64) * 4 + (tid & 63) * 4
-                        sU[dst:dst + 4] = up[g:g + 4]
-                    for sl in range((CK * 180 + NT - 1) // NT):
-                        e = sl * NT + tid
-                        if e >= CK * 180:
-                            sP[PSZ] = 0.0
-                            continue
-                        ci, rem = e // 180, e % 180
-                        r, cc_ = rem // 18, rem % 18
-                        yy, xx = oy0 - 1 + r, ox0 - 1 + cc_
-                        inside = 0 <= yy < H and 0 <= xx < W
-                        p_ci = ci + (0 if inside else CK)
-                        goff = min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)
-                        # WINO_LOAD_P: wave-uniform source / base, lane offset cl*HW + goff
-                        cb = min(ch * CK, Cin - 1)
-                        cmax = Cin - 1 - cb
-                        second = cb >= C0
-                        srcb = (x1f, (b * C1 + (cb - C0)) * HW) if second else (x0f, (b * C0 + cb) * HW)
-                        cl = min(p_ci & (CK - 1), cmax)
-                        v = srcb[0][srcb[1] + cl * HW + goff]
-                        if coef is not None:
-                            cfo = (b * Cin + cb) * 2 + cl * 2
-                            v = v * coef_f[cfo] + coef_f[cfo + 1]
-                        if act:
-                            v = silu(v)
-                        nvalid = Cin - ch * CK
-                        sP[ci * 10 * PP + r * PP + cc_] = v if p_ci < min(nvalid, CK) else 0.0
-                for tid in range(NT):
-                    s_ci, s_tile, grp = (tid & 255) >> 5, tid & 31, tid >> 8
-                    s_ty, s_tx = s_tile >> 3, s_tile & 7
-                    p_rd = s_ci * 10 * PP + 2 * s_ty * PP + 2 * s_tx
-                    p_rdA, p_rdB = p_rd + (0 if grp == 0 else 1) * PP, p_rd + (3 if grp == 3 else 2) * PP
-                    m = []
-                    for j in range(4):
-                        va, vb = sP[p_rdA + j], sP[p_rdB + j]
-                        m.append(va + vb if grp == 1 else (vb - va if grp == 2 else va - vb))
-                    base = s_ci * 16 * T + grp * 4 * T + s_tile
-                    sV[base + 0 * T] = m[0] - m[2]
-                    sV[base + 1 * T] = m[1] + m[2]
-                    sV[base + 2 * T] = m[2] - m[1]
-                    sV[base + 3 * T] = m[1] - m[3]
-                assert not np.isnan(sV).any() and not np.isnan(sU).any()
-                for wave in range(16):
-                    for kp in range(CK // 2):
-                        xi = wave
-                        bv = np.array([sV[((2 * kp + (l >> 5)) * 16 + xi) * T + (l & 31)] for l in range(64)])
-                        for ct in range(COT):
-                            av = np.array([sU[((2 * kp + (l >> 5)) * 16 + xi) * BCO + ct * 32 + (l & 31)] for l in range(64)])
-                            mfma_32x32x2(av, bv, acc[wave, ct])
-            for ct in range(COT):
-                sM = np.full(16 * 32 * T, np.nan)
-                for wave in range(16):
-                    for lane in range(64):
-                        for r in range(16):
-                            col = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-                            sM[(wave * 32 + col) * T + (lane & 31)] = acc[wave, ct, r, lane]
-                for tid in range(NT):
-                    e_tile = tid & 31
-                    e_ty, e_tx = e_tile >> 3, e_tile & 7
-                    for k in range(1):
-                        col = tid >> 5
-                        co = co0 + ct * 32 + col
-                        mm = np.array([sM[(xi * 32 + col) * T + e_tile] for xi in range(16)])
-                        t0 = [mm[0 + l] + mm[4 + l] + mm[8 + l] for l in range(4)]
-                        t1 = [mm[4 + l] - mm[8 + l] - mm[12 + l] for l in range(4)]
-                        ys = [[t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]], [t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]]]
-                        if co < Cout:
-                            for r in range(2):
-                                for cc in range(2):
-                                    yy, xx = oy0 + 2 * e_ty + r, ox0 + 2 * e_tx + cc
-                                    v = ys[r][cc] + bias[co]
-                                    if res is not None:
-                                        v += res[b, co, yy, xx]
-                                    y[b, co, yy, xx] = v * scale
-    return y
-
-
-
-
-def pack_wino_weight_r(w, CinP, CoutP, COT):
-    """Mirror of pack_wino_weight_r_kernel (conv_wino16r.cpp): operand-major layout
+def pack_wino_weight(w, CinP, CoutP, COT):
+    """Mirror of pack_wino_weight_kernel (conv_wino.cpp): operand-major layout
     up[((((cotile*nunits + ci//8)*16 + xi)*COT + idx//4)*64 + lane)*4 + idx%4], idx = ((ci%8)//2)*COT + (co%BCO)//32,
     lane = (ci%2)*32 + co%32."""
     Cout, Cin = w.shape[:2]
@@ -490,8 +247,8 @@ def pack_wino_weight_r(w, CinP, CoutP, COT):
     return up
 
 
-def wino16r_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT):
-    """Lane-level emulation of conv_wino16r_kernel's addressing (conv_wino16r.cpp): 1024 threads, 16-channel chunks, A operands
+def wino_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT):
+    """Lane-level emulation of conv_wino_kernel's addressing (conv_wino.cpp): 1024 threads, 16-channel chunks, A operands
     straight from the operand-major packed weights, patch slots, two transform tasks per thread, block id -> (region, cout tile)."""
     B, C0, H, W = x0.shape
     C1 = 0 if x1 is None else x1.shape[1]
@@ -598,13 +355,13 @@ def wino16r_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, 
     return y
 
 
-def gemm1x1_emulate(x0, x1, wp, bias, coef, act, res, scale, Cout, CoutP, CinP, COT):
+def gemm1x1_emulate(x0, x1, wp, bias, coef, act, res, scale, Cout, CoutP, CinP, COT, CK=16):
     """Lane-level emulation of conv1x1_dma_kernel's addressing (conv1x1_dma.cpp): DMA piece maps of W and x, the
     coefficient table, MFMA lane maps, block id -> (pixel tile, cout tile), ragged last pixel tile."""
     B, C0, H, W = x0.shape
     C1 = 0 if x1 is None else x1.shape[1]
     Cin = C0 + C1
-    CK, PT, BCO, MAXIMG = 16, 128, 32 * COT, 4
+    PT, BCO, MAXIMG = 128, 32 * COT, 4
     HW = H * W
     NPX = B * HW
     assert Cin % CK == 0 and CinP % CK == 0 and (C1 == 0 or C0 % CK == 0) and HW % 32 == 0

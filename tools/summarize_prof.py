@@ -67,13 +67,14 @@ def mfma():
             if "Start_Timestamp" in r and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
                 agg[k]["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                 agg[k]["n"] += 1
-        print("== per kernel: launches, total ms, GUI_ACTIVE cycles, eff. clock GHz, MFMA_BUSY/(GUI_ACTIVE*1024 SIMDs)")
-        for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("ns", 0))[:20]:
+        # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs
+        print("== per kernel: launches, total ms, effective shader clock (GUI_ACTIVE / 8 XCDs / duration), "
+              "MFMA-busy fraction of the SIMD-cycles (MFMA_BUSY / (GUI_ACTIVE/8 * 1024 SIMDs))")
+        for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("ns", 0))[:24]:
             ns, gui, mf = d.get("ns", 0), d.get("GRBM_GUI_ACTIVE", 0), d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
             if ns <= 0 or gui <= 0:
                 continue
-            print(f"{k:58s} {int(d['n']):5d} {ns / 1e6:9.2f} ms  gui {gui:.3e}  clk {gui / ns:5.2f} GHz  mfma_busy/gui {mf / gui:9.2f}  "
-                  f"(/1024 SIMDs = {mf / gui / 1024:5.3f}, /256 CUs = {mf / gui / 256:5.3f})  sq_busy/gui {d.get('SQ_BUSY_CYCLES', 0) / gui:8.2f}")
+            print(f"{k:58s} {int(d['n']):5d} {ns / 1e6:9.2f} ms  clk {gui / 8 / ns:5.2f} GHz  mfma_busy {mf / (gui / 8 * 1024):6.3f}")
 
 
 def traffic(out_json):
