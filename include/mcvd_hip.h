@@ -19,6 +19,9 @@
  *   mcvd_model_create/set_param/finalize  <- get_model + load_state_dict,
  *                                            runners/ncsn_runner.py:180-195, :923-932
  *   mcvd_unet_forward                     <- UNetMore_DDPM.forward, models/better/ncsnpp_more.py:753-770
+ *   mcvd_unet_forward_ft                  <- the same forward called with float timesteps (F-PNDM: t_list[1] = (t + t_next) / 2,
+ *                                            models/pndm.py:42; timesteps.float() in layers.py:504-518)
+ *   mcvd_pndm_transfer / mcvd_lincomb     <- transfer / the Runge-Kutta and Adams-Bashforth combinations, models/pndm.py:19-33, :15, :47
  *   mcvd_sampler_run                      <- ddpm_sampler / ddim_sampler, models/__init__.py:206-340 / :102-203
  *   mcvd_sampler_update                   <- the per-step update algebra, models/__init__.py:287-290, :165-168, :324-328
  *   mcvd_upfirdn2d                        <- pybind upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0..pad_y1),
@@ -124,6 +127,9 @@ int mcvd_model_set_temb_freqs(mcvd_model* m, const float* freqs_host, int n);
 
 /* eps = UNet(x, labels, cond).  x:[B, C*nf, S, S]  labels:[B] int64  cond:[B, C*nc, S, S] (NULL iff nc==0)  eps like x. */
 int mcvd_unet_forward(mcvd_model* m, const float* x, const int64_t* labels, const float* cond, float* eps_out, int B);
+/* Same forward with float timesteps t:[B] (device pointer), which may be fractional or negative: the F-PNDM sampler evaluates the
+ * network at (t + t_next) / 2 (models/pndm.py:42) and the reference's embedding takes timesteps.float() (layers.py:504-518). */
+int mcvd_unet_forward_ft(mcvd_model* m, const float* x, const float* t, const float* cond, float* eps_out, int B);
 /* SPADE models (model.spade): the gamma/beta modulation maps depend only on the conditioning frames (layerspp.py:164-168), so
  * they are computed by mcvd_model_prepare_cond and cached; later forwards that pass the SAME cond pointer and batch size reuse
  * them until mcvd_model_invalidate_cond / another prepare (the caller promises not to modify cond in between).  A forward whose
@@ -161,6 +167,16 @@ int mcvd_sampler_update(mcvd_ctx* ctx, int kind, float* x_inout, const float* ep
 /* z ~ N(0,1) from the same Philox stream mcvd_sampler_run uses: out:[B, per_sample]. */
 int mcvd_randn(mcvd_ctx* ctx, float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B,
                int64_t per_sample);
+/* F-PNDM building blocks (models/pndm.py), fp32 with one rounding per operation in the order of the reference's tensor
+ * expressions (no FMA contraction), n elements, device pointers:
+ *   mcvd_lincomb:        out = scale * (((w0*in0 + w1*in1) + w2*in2) + w3*in3), the first nin (1..4) terms; out may alias an input
+ *                        (runge_kutta :15: scale 1/6, w = 1,2,2,1;  gen_order_4 :47: scale 1/24, w = 55,-59,37,-9)
+ *   mcvd_pndm_transfer:  out = clip?( x + d * (c1 * x - c2 * e) ) with d = a_next - a, c1 = 1/(sqrt(a)(sqrt(a)+sqrt(a_next))),
+ *                        c2 = 1/(sqrt(a)(sqrt((1-a_next)a) + sqrt((1-a)a_next)))          (transfer :19-33) */
+int mcvd_lincomb(mcvd_ctx* ctx, float* out, const float* in0, const float* in1, const float* in2, const float* in3, float w0,
+                 float w1, float w2, float w3, float scale, int nin, int64_t n);
+int mcvd_pndm_transfer(mcvd_ctx* ctx, float* out, const float* x, const float* e, float d, float c1, float c2, int clip,
+                       int64_t n);
 
 /* ---- stand-alone ops (unit parity against the oracle; also the reference's only native op) ----------------- */
 /* upfirdn2d on [N, C, H, W] planes; kernel:[kh,kw] HOST pointer.  out:[N,C,oh,ow], oh=(H*up+pad0+pad1-kh)/down+1. */

@@ -6,11 +6,11 @@ Importing this package loads the shared library and raises if it is missing -- t
 """
 from . import _lib  # noqa: F401  (fails loudly when the HIP extension is not built)
 from .config import desc_from_config, dict2namespace, load_config  # noqa: F401
-from .samplers import ddim_sampler, ddpm_sampler, get_sampler  # noqa: F401
+from .samplers import ddim_sampler, ddpm_sampler, fpndm_sampler, get_sampler  # noqa: F401
 from .scorenet import HipScoreNet, get_model  # noqa: F401
 from .checkpoint import load_model, load_states_into  # noqa: F401
-from .runner import conditioning_fn, data_transform, inverse_data_transform, video_gen  # noqa: F401
+from .runner import conditioning_fn, data_transform, inverse_data_transform, save_video_pred, video_gen  # noqa: F401
 
-__all__ = ["HipScoreNet", "get_model", "ddpm_sampler", "ddim_sampler", "get_sampler", "dict2namespace", "load_config",
+__all__ = ["HipScoreNet", "get_model", "ddpm_sampler", "ddim_sampler", "fpndm_sampler", "get_sampler", "dict2namespace", "load_config",
            "desc_from_config", "load_model", "load_states_into", "conditioning_fn", "data_transform",
-           "inverse_data_transform", "video_gen"]
+           "inverse_data_transform", "video_gen", "save_video_pred"]

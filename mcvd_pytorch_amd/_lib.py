@@ -49,6 +49,7 @@ _PROTOS = {
     "mcvd_model_set_schedule": (_i, [_vp, _vp, _vp, _vp, _i]),
     "mcvd_model_set_temb_freqs": (_i, [_vp, _vp, _i]),
     "mcvd_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
+    "mcvd_unet_forward_ft": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     "mcvd_model_prepare_cond": (_i, [_vp, _vp, _i]),
     "mcvd_model_invalidate_cond": (_i, [_vp]),
     "mcvd_model_num_launches": (_i, [_vp, _i]),
@@ -58,6 +59,8 @@ _PROTOS = {
     "mcvd_sampler_run": (_i, [_vp, _i, _vp, _vp, _vp, _u64, _u64, _i, _i, _f, _i]),
     "mcvd_sampler_update": (_i, [_vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _i64]),
     "mcvd_randn": (_i, [_vp, _vp, _u64, _u64, _u64, _i, _i64]),
+    "mcvd_lincomb": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _i64]),
+    "mcvd_pndm_transfer": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _i64]),
     "mcvd_upfirdn2d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i]),
     "mcvd_op_conv2d": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _f, _vp, _i, _i, _i]),
     "mcvd_op_gn_coef": (_i, [_vp, _vp, _i, _vp, _i, _i, _f, _i, _vp, _vp, _i, _i, _vp, _i, _i]),

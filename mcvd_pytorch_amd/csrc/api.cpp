@@ -297,6 +297,31 @@ int mcvd_unet_forward(mcvd_model* m, const float* x, const int64_t* labels, cons
     API_CATCH
 }
 
+int mcvd_unet_forward_ft(mcvd_model* m, const float* x, const float* t, const float* cond, float* eps_out, int B) {
+    API_TRY
+    MCVD_REQUIRE(m, "forward: NULL model");
+    m->labels_f32 = 1;
+    const int rc = m->forward(x, t, cond, eps_out, B);
+    m->labels_f32 = 0;
+    return rc;
+    API_CATCH
+}
+
+int mcvd_lincomb(mcvd_ctx* ctx, float* out, const float* in0, const float* in1, const float* in2, const float* in3, float w0,
+                 float w1, float w2, float w3, float scale, int nin, int64_t n) {
+    MCVD_REQUIRE(ctx && out && in0 && nin >= 1 && nin <= 4 && n >= 0, "lincomb: bad arguments");
+    const float* in[4] = {in0, in1, in2, in3};
+    const float w[4] = {w0, w1, w2, w3};
+    for (int k = 0; k < nin; ++k) MCVD_REQUIRE(in[k], "lincomb: input %d is NULL", k);
+    return launch_lincomb(out, in, w, scale, nin, n, ctx->stream);
+}
+
+int mcvd_pndm_transfer(mcvd_ctx* ctx, float* out, const float* x, const float* e, float d, float c1, float c2, int clip,
+                       int64_t n) {
+    MCVD_REQUIRE(ctx && out && x && e && n >= 0, "pndm_transfer: bad arguments");
+    return launch_pndm_transfer(out, x, e, d, c1, c2, clip, n, ctx->stream);
+}
+
 int mcvd_model_num_launches(mcvd_model* m, int) {
     if (!m) return MCVD_EINVAL;
     int n = 0;

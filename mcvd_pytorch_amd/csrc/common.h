@@ -102,7 +102,8 @@ int launch_nearest_resize(const float* in, float* out, int BC, int H, int W, int
 
 // ------------------------------------------------------------------ time embedding
 // silu_temb[b][:] = SiLU( W1 * SiLU(W0 * emb(t_b) + b0) + b1 )      (ncsnpp_more.py:273-280 + layerspp.py:521)
-int launch_temb_mlp(const int64_t* labels, const float* freqs, const float* w0, const float* b0, const float* w1,
+// labels: int64 [B], or float [B] when labels_f32 (fractional timesteps of the F-PNDM sampler)
+int launch_temb_mlp(const void* labels, int labels_f32, const float* freqs, const float* w0, const float* b0, const float* w1,
                     const float* b1, float* silu_temb, int B, int nf, hipStream_t s);
 // out[b][n] = sum_k act[b][k] * wt[k][n] + bias[n]   (all Dense_0 projections of a forward in one launch)
 int launch_dense_all(const float* act, const float* wt, const float* bias, float* out, int B, int K, int N,
@@ -120,5 +121,11 @@ int launch_renoise(float* x, const float* noise, float ca, float cb, int64_t n, 
 int launch_axpy_out(float* x, const float* eps, float c, int64_t n, hipStream_t s);   // x -= c * eps
 int launch_randn(float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample,
                  hipStream_t s);
+// out = scale * sum_k w[k] * in[k], k < nin <= 4 (left-to-right, separately rounded, as the reference's tensor expression);
+// out may alias an input
+int launch_lincomb(float* out, const float* const* in, const float* w, float scale, int nin, int64_t n, hipStream_t s);
+// F-PNDM transfer (models/pndm.py:19-33): out = clip?( x + d * (c1 * x - c2 * e) )
+int launch_pndm_transfer(float* out, const float* x, const float* e, float d, float c1, float c2, int clip, int64_t n,
+                         hipStream_t s);
 
 }  // namespace mcvd

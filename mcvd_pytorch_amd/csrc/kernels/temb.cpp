@@ -8,7 +8,7 @@ namespace mcvd {
 __device__ __forceinline__ float silu_t(float v) { return v / (1.0f + expf(-v)); }
 
 // one workgroup per sample; hidden width T = 4*nf <= 1024 (nf <= 256)
-__global__ __launch_bounds__(256) void temb_mlp_kernel(const int64_t* labels, const float* freqs, const float* w0,
+__global__ __launch_bounds__(256) void temb_mlp_kernel(const void* labels, int labels_f32, const float* freqs, const float* w0,
                                                         const float* b0, const float* w1, const float* b1,
                                                         float* silu_temb, int nf) {
     __shared__ float emb[256];
@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void temb_mlp_kernel(const int64_t* labels, co
     const int b = blockIdx.x;
     const int T = 4 * nf;
     const int half = nf / 2;
-    const float t = (float)labels[b];                       // timesteps.float()
+    // timesteps.float(): int64 labels (samplers) or already-float, possibly fractional ones (F-PNDM's (t + t_next) / 2)
+    const float t = labels_f32 ? static_cast<const float*>(labels)[b] : (float)static_cast<const int64_t*>(labels)[b];
     for (int i = threadIdx.x; i < nf; i += 256) {
         float v = 0.0f;                                     // odd nf: zero pad (layers.py:515-516)
         if (i < half) v = sinf(t * freqs[i]);
@@ -39,10 +40,10 @@ __global__ __launch_bounds__(256) void temb_mlp_kernel(const int64_t* labels, co
     }
 }
 
-int launch_temb_mlp(const int64_t* labels, const float* freqs, const float* w0, const float* b0, const float* w1,
+int launch_temb_mlp(const void* labels, int labels_f32, const float* freqs, const float* w0, const float* b0, const float* w1,
                     const float* b1, float* silu_temb, int B, int nf, hipStream_t s) {
     MCVD_REQUIRE(nf <= 256 && nf >= 4, "temb: ngf=%d out of range [4,256]", nf);
-    hipLaunchKernelGGL(temb_mlp_kernel, dim3(B), dim3(256), 0, s, labels, freqs, w0, b0, w1, b1, silu_temb, nf);
+    hipLaunchKernelGGL(temb_mlp_kernel, dim3(B), dim3(256), 0, s, labels, labels_f32, freqs, w0, b0, w1, b1, silu_temb, nf);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -527,7 +527,7 @@ float* mcvd_model::resolve(const TRef& r, const float* x, const float* cond, flo
     }
 }
 
-int mcvd_model::launch_op(const Op& op, const float* x, const int64_t* lab, const float* cond, float* out, int B) {
+int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const float* cond, float* out, int B) {
     hipStream_t s = op_stream ? op_stream : ctx->stream;
     switch (op.kind) {
         case OP_TEMB: {
@@ -535,7 +535,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const int64_t* lab, cons
             const float* b0 = blob + params[find_param("unet.all_modules.0.bias")].off;
             const float* w1 = blob + params[find_param("unet.all_modules.1.weight")].off;
             const float* b1 = blob + params[find_param("unet.all_modules.1.bias")].off;
-            return launch_temb_mlp(lab, packed + freqs_off, w0, b0, w1, b1, resolve(op.dst, x, cond, out, B), B, d.ngf, s);
+            return launch_temb_mlp(lab, labels_f32, packed + freqs_off, w0, b0, w1, b1, resolve(op.dst, x, cond, out, B), B, d.ngf, s);
         }
         case OP_DENSE:
             return launch_dense_all(resolve(op.src0, x, cond, out, B), packed + dense_wt, packed + dense_bias,
@@ -742,7 +742,7 @@ int mcvd_model::prepare_cond(const float* cond, int B) {
     return 0;
 }
 
-int mcvd_model::forward(const float* x, const int64_t* lab, const float* cond, float* out, int B) {
+int mcvd_model::forward(const float* x, const void* lab, const float* cond, float* out, int B) {
     MCVD_REQUIRE(finalized, "forward before mcvd_model_finalize");
     MCVD_REQUIRE(B > 0 && x && lab && out, "forward: bad arguments");
     if (int rc = prepare_B(B)) return rc;

@@ -148,7 +148,8 @@ struct mcvd_model {
     int add_param(const std::string& name, std::initializer_list<int64_t> shape);
     int find_param(const char* name) const;
     int ensure_workspace(int B);
-    int forward(const float* x, const int64_t* labels, const float* cond, float* out, int B);
-    int launch_op(const mcvd::Op& op, const float* x, const int64_t* labels, const float* cond, float* out, int B);
+    int labels_f32 = 0;            // the labels of the forward in flight are float [B] instead of int64 [B] (mcvd_unet_forward_ft)
+    int forward(const float* x, const void* labels, const float* cond, float* out, int B);
+    int launch_op(const mcvd::Op& op, const float* x, const void* labels, const float* cond, float* out, int B);
     float* resolve(const mcvd::TRef& r, const float* x, const float* cond, float* out, int B) const;
 };

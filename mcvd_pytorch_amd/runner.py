@@ -105,3 +105,11 @@ def video_gen(config, scorenet, cond, num_frames_pred=None, init_noise_fn=None, 
         # cond <- [cond[:, C*nf:], gen[:, C*max(0, nf - nc):]]                            :1537-1539
         cond = torch.cat([cond[:, C * nf:], gen[:, C * max(0, nf - nc):]], dim=1).contiguous()
     return torch.cat(preds, dim=1)[:, :C * nfp]                                         # :1569
+
+
+def save_video_pred(path, cond, pred, real):
+    """The on-disk result of NCSNRunner.video_gen: torch.save({"cond", "pred", "real"}) of the [0,1]-range CPU tensors
+    (runners/ncsn_runner.py:2106-2112, `videos_pred_<ckpt>.pt`), so downstream metric scripts read our output unchanged."""
+    to_cpu = lambda t: None if t is None else t.detach().to("cpu")
+    torch.save({"cond": to_cpu(cond), "pred": to_cpu(pred), "real": to_cpu(real)}, path)
+    return path

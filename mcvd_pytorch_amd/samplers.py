@@ -1,4 +1,4 @@
-"""DDPM / DDIM samplers with the reference's call surface (models/__init__.py:206-209, :102-104).
+"""DDPM / DDIM / F-PNDM samplers with the reference's call surface (models/__init__.py:206-209, :102-104, :37-38).
 
     sampler(x_mod, scorenet, cond=None, final_only=..., denoise=..., subsample_steps=..., clip_before=...,
             t_min=..., verbose=..., log=..., **kwargs) -> Tensor [(1 | n_saved), B, C*nf, H, W]
@@ -194,6 +194,81 @@ def ddim_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, sub
                    gamma=gamma, **kwargs)
 
 
+@torch.no_grad()
+def fpndm_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsample_steps=None, verbose=False, log=True,
+                  clip_before=True, t_min=-1, gamma=False, **kwargs):
+    """F-PNDM: reference models/__init__.py:38-99 (FPNDM_sampler) with models/pndm.py (gen_order_4 :41-52, runge_kutta :3-17,
+    transfer :19-33), behaviour mirrored statement by statement: steps 0, skip, 2*skip, ... with t_next = the previous step
+    (-1 first), alpha table = flipped `alphas` indexed by t + 1, network label = t, float midpoint label (t + t_next) / 2;
+    Runge-Kutta for the first three steps (4 network evaluations each), 4th-order Adams-Bashforth afterwards.  `denoise`,
+    `t_min`, `gamma`, `verbose`, `log` are accepted and unused, as in the reference.  Deterministic (no noise draws).
+    The network evaluations are HIP forwards; the combinations and the transfer are the library's mcvd_lincomb /
+    mcvd_pndm_transfer kernels (one rounding per operation, in the reference's order)."""
+    net = _unwrap(scorenet)
+    if subsample_steps is None:
+        raise TypeError("FPNDM_sampler needs subsample_steps (the reference divides by it, models/__init__.py:60)")
+    net.sync_parameters(force=True)
+    dev = net.device
+    x = x_mod.to(device=dev, dtype=torch.float32).contiguous().clone()
+    if cond is not None:
+        cond = cond.to(device=dev, dtype=torch.float32).contiguous()
+    B, n = x.shape[0], x.numel()
+    alphas_old = net.alphas.cpu().flip(0)                                           # :57
+    T = len(alphas_old)
+    skip = T // subsample_steps                                                     # :60
+    steps = list(range(0, T, skip))
+    steps_next = [-1] + steps[:-1]                                                  # :62
+
+    def model(xx, t_value, as_float):
+        dtype = torch.float32 if as_float else torch.int64
+        return net(xx, torch.full((B,), t_value, device=dev, dtype=dtype), cond=cond)
+
+    def transfer(xx, t_idx, tn_idx, et):                                            # pndm.py:19-33
+        at, an = alphas_old[int(t_idx) + 1], alphas_old[int(tn_idx) + 1]            # t.long() truncates toward zero, as int()
+        d = _f(an - at)
+        c1 = _f(1 / (at.sqrt() * (at.sqrt() + an.sqrt())))
+        c2 = _f(1 / (at.sqrt() * (((1 - an) * at).sqrt() + ((1 - at) * an).sqrt())))
+        out = torch.empty_like(xx)
+        with torch.cuda.device(dev):
+            net._bind_stream()
+            _lib.check(_lib.lib.mcvd_pndm_transfer(net._ctx, C.c_void_p(out.data_ptr()), C.c_void_p(xx.data_ptr()),
+                                                   C.c_void_p(et.data_ptr()), d, c1, c2, 1 if clip_before else 0, n),
+                       "pndm_transfer")
+        return out
+
+    def lincomb(ins, ws, scale):
+        out = torch.empty_like(ins[0])
+        ptr = [C.c_void_p(t.data_ptr()) for t in ins] + [None] * (4 - len(ins))
+        w = list(ws) + [0.0] * (4 - len(ws))
+        with torch.cuda.device(dev):
+            net._bind_stream()
+            _lib.check(_lib.lib.mcvd_lincomb(net._ctx, C.c_void_p(out.data_ptr()), ptr[0], ptr[1], ptr[2], ptr[3],
+                                             w[0], w[1], w[2], w[3], scale, len(ins), n), "lincomb")
+        return out
+
+    images, ets = [], []
+    for i, t in enumerate(steps):
+        t_next = steps_next[i]
+        t_mid = (t + t_next) / 2                                                    # pndm.py:42: true division
+        if len(ets) > 2:                                                            # pndm.py:44-47
+            ets.append(model(x, t, False))
+            noise = lincomb([ets[-1], ets[-2], ets[-3], ets[-4]], [55.0, -59.0, 37.0, -9.0], _f(torch.tensor(1 / 24)))
+            ets = ets[-4:]                                                          # older estimates are never read again
+        else:                                                                       # runge_kutta, pndm.py:3-17
+            e_1 = model(x, t, False)
+            ets.append(e_1)
+            e_2 = model(transfer(x, t, t_mid, e_1), t_mid, True)
+            e_3 = model(transfer(x, t, t_mid, e_2), t_mid, True)
+            e_4 = model(transfer(x, t, t_next, e_3), t_next, False)
+            noise = lincomb([e_1, e_2, e_3, e_4], [1.0, 2.0, 2.0, 1.0], _f(torch.tensor(1 / 6)))
+        x = transfer(x, t, t_next, noise)                                           # pndm.py:51
+        if not final_only:
+            images.append(x.to("cpu"))
+    if final_only:
+        return x.unsqueeze(0)
+    return torch.stack(images)
+
+
 def get_sampler(config):
     """Reference: runners/ncsn_runner.py:2702-2714 (DDPM / DDIM versions)."""
     version = getattr(config.model, "version", "DDPM").upper()
@@ -201,4 +276,6 @@ def get_sampler(config):
         return partial(ddpm_sampler, config=config)
     if version == "DDIM":
         return partial(ddim_sampler, config=config)
-    raise NotImplementedError(f"sampler version {version} is not on the HIP path yet (FPNDM: SURVEY 8f rank 2)")
+    if version == "FPNDM":
+        return partial(fpndm_sampler, config=config)
+    raise NotImplementedError(f"sampler version {version} is not on the HIP path (SMLD: out of scope, DESIGN.md section 8)")

@@ -233,7 +233,10 @@ class HipScoreNet:
         if d.num_frames_cond > 0:
             if cond is None or tuple(cond.shape) != (B, d.channels * d.num_frames_cond, d.image_size, d.image_size):
                 raise RuntimeError("cond missing or mis-shaped")
-        y = y.to(device=self.device, dtype=torch.int64).contiguous()
+        # integer labels as the DDPM/DDIM samplers pass them; float (possibly fractional) timesteps for F-PNDM's midpoints:
+        # the reference's embedding takes timesteps.float() either way (layers.py:504-518)
+        float_t = y.is_floating_point()
+        y = y.to(device=self.device, dtype=torch.float32 if float_t else torch.int64).contiguous()
         if y.shape != (B,):
             raise RuntimeError(f"labels have shape {tuple(y.shape)}")
         out = torch.empty_like(x)
@@ -246,8 +249,9 @@ class HipScoreNet:
                     _lib.check(_lib.lib.mcvd_model_prepare_cond(self._model, _fptr(cond), B), "prepare_cond")
                     self._cond_key = key
                     self._cond_keepalive = cond
-            _lib.check(_lib.lib.mcvd_unet_forward(self._model, _fptr(x), C.c_void_p(y.data_ptr()),
-                                                  _fptr(cond) if cond is not None else None, _fptr(out), B), "unet_forward")
+            fwd = _lib.lib.mcvd_unet_forward_ft if float_t else _lib.lib.mcvd_unet_forward
+            _lib.check(fwd(self._model, _fptr(x), C.c_void_p(y.data_ptr()), _fptr(cond) if cond is not None else None,
+                           _fptr(out), B), "unet_forward")
         return out
 
     forward = __call__

@@ -13,6 +13,7 @@ What is pinned:
   * one UNet forward: final eps + a strided probe of every module's output  (ncsnpp_more.py:251-392, 590-718)
   * ddpm_sampler / ddim_sampler end-to-end with an injected noise sequence  (models/__init__.py:102-340)
   * upfirdn2d_native for the two FIR uses + a generic case                  (op/upfirdn2d.py:163-204)
+  * FPNDM_sampler end-to-end, every step (deterministic, no noise)          (models/__init__.py:38-99, models/pndm.py)
 """
 import os
 import sys
@@ -113,6 +114,24 @@ def gen_model_case(name, batch, steps_kinds):
     print(f"wrote {name}_b{batch}.pt  eps std {eps.std():.4f}")
 
 
+def gen_fpndm(name="tiny", batch=3, subsample=10):
+    """FPNDM_sampler of the real reference (models/__init__.py:38-99) on the synthetic tiny model: every step's x."""
+    sys.path.insert(0, REF)
+    import models as ref_models
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    net.load_state_dict(synth.make_state_dict(config, seed=123), strict=False)
+    x, cond = synth.make_inputs(config, batch, seed=0)
+    res = ref_models.FPNDM_sampler(x.clone(), net, cond=cond, final_only=False, subsample_steps=subsample, clip_before=True,
+                                   verbose=False, log=False)
+    fin = ref_models.FPNDM_sampler(x.clone(), net, cond=cond, final_only=True, subsample_steps=subsample, clip_before=False,
+                                   verbose=False, log=False)
+    torch.save(dict(config_name=name, batch=batch, subsample=subsample, all_clip=res.clone(), final_noclip=fin.clone()),
+               os.path.join(OUT, f"{name}_b{batch}_fpndm.pt"))
+    print(f"wrote {name}_b{batch}_fpndm.pt  steps {res.shape[0]}  range [{res.min():.4f}, {res.max():.4f}]  "
+          f"noclip range [{fin.min():.4f}, {fin.max():.4f}]")
+
+
 def gen_fir():
     sys.path.insert(0, REF)
     from models.better import up_or_down_sampling as uds
@@ -138,6 +157,7 @@ def main():
     gen_model_case("tiny", 3, [("ddpm", 10, {}), ("ddim", 10, {}), ("ddpm", 10, dict(t_min=0.35))])
     gen_model_case("tiny_spade", 2, [("ddpm", 10, {})])
     gen_model_case("smmnist_big5", 2, [("ddpm", 100, {})])          # BASELINE config 1 (plumbing, CPU)
+    gen_fpndm()
 
 
 if __name__ == "__main__":

@@ -5,8 +5,13 @@ Restatement of the reference's DDPM / DDIM sampling loops
 non-gamma path, with the per-step Gaussian noise supplied by a callable so CPU
 and GPU runs can consume the *same* noise sequence.
 
+`fpndm_sample` restates FPNDM_sampler (models/__init__.py:38-99) with models/pndm.py (transfer :19-33, runge_kutta :3-17,
+gen_order_4 :41-52), quirks included: the steps run UPWARDS (0, skip, 2*skip, ...) with t_next = the previous step (-1 first),
+the alpha table is the flipped `alphas` indexed by t + 1, the network label is t itself, and the Runge-Kutta midpoint label
+(t + t_next) / 2 is a float (fractional for the first step).
+
 Parity status: PINNED against the reference samplers by oracle/gen_golden.py
-(tests/golden/sampler_*.pt).
+(tests/golden/*_b*.pt, tests/golden/tiny_b3_fpndm.pt).
 """
 import numpy as np
 import torch
@@ -78,6 +83,55 @@ def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=
         if not final_only:
             images.append(x_mod.clone())
 
+    if final_only:
+        return x_mod.unsqueeze(0)
+    return torch.stack(images)
+
+
+def pndm_transfer(x, t, t_next, et, alphas_cump, clip_before):
+    """models/pndm.py:19-33 (t, t_next: [B] tensors, possibly float; the table index is t.long() + 1)."""
+    at = alphas_cump[t.long() + 1].view(-1, 1, 1, 1)
+    at_next = alphas_cump[t_next.long() + 1].view(-1, 1, 1, 1)
+    x_delta = (at_next - at) * ((1 / (at.sqrt() * (at.sqrt() + at_next.sqrt()))) * x
+                                - 1 / (at.sqrt() * (((1 - at_next) * at).sqrt() + ((1 - at) * at_next).sqrt())) * et)
+    x_next = x + x_delta
+    if clip_before:
+        x_next = x_next.clip_(-1, 1)
+    return x_next
+
+
+@torch.no_grad()
+def fpndm_sample(x_mod, scorenet, cond=None, final_only=False, subsample_steps=None, clip_before=True):
+    """FPNDM_sampler, models/__init__.py:38-99 (denoise / t_min / gamma are accepted and ignored there)."""
+    alphas = scorenet.alphas
+    alphas_old = alphas.flip(0)                                       # :57
+    skip = len(alphas) // subsample_steps                             # :60
+    steps = list(range(0, len(alphas), skip))
+    steps_next = [-1] + steps[:-1]                                    # :62
+    model = lambda x, t: scorenet(x, t, cond=cond)                    # :79
+    B = x_mod.shape[0]
+    images, ets = [], []
+    for i in range(len(steps)):
+        t = (steps[i] * torch.ones(B)).long()                         # :85
+        t_next = (steps_next[i] * torch.ones(B)).long()
+        t_list = [t, (t + t_next) / 2, t_next]                        # pndm.py:42 (true division: float labels)
+        if len(ets) > 2:                                              # pndm.py:44-47
+            noise_ = model(x_mod, t)
+            ets.append(noise_)
+            noise = (1 / 24) * (55 * ets[-1] - 59 * ets[-2] + 37 * ets[-3] - 9 * ets[-4])
+        else:                                                         # runge_kutta, pndm.py:3-17
+            e_1 = model(x_mod, t_list[0])
+            ets.append(e_1)
+            x_2 = pndm_transfer(x_mod, t_list[0], t_list[1], e_1, alphas_old, clip_before)
+            e_2 = model(x_2, t_list[1])
+            x_3 = pndm_transfer(x_mod, t_list[0], t_list[1], e_2, alphas_old, clip_before)
+            e_3 = model(x_3, t_list[1])
+            x_4 = pndm_transfer(x_mod, t_list[0], t_list[2], e_3, alphas_old, clip_before)
+            e_4 = model(x_4, t_list[2])
+            noise = (1 / 6) * (e_1 + 2 * e_2 + 2 * e_3 + e_4)
+        x_mod = pndm_transfer(x_mod, t, t_next, noise, alphas_old, clip_before)   # pndm.py:51
+        if not final_only:
+            images.append(x_mod.to("cpu"))
     if final_only:
         return x_mod.unsqueeze(0)
     return torch.stack(images)

@@ -280,6 +280,72 @@ def test_sampler_vs_reference_golden(golden_dir, fx, key, kind, sub, extra, path
     assert err <= tol, f"final frames max-abs err {err:.3e}"
 
 
+def test_fpndm_vs_reference_golden(golden_dir, ctx):
+    """F-PNDM (FPNDM_sampler + models/pndm.py): every step of the clipped run vs the reference's (fixture); float, fractional and
+    negative timesteps through mcvd_unet_forward_ft; the un-clipped run (|x| grows to ~360) at relative tolerance."""
+    from mcvd_pytorch_amd.samplers import fpndm_sampler, get_sampler
+    g = torch.load(os.path.join(golden_dir, "tiny_b3_fpndm.pt"), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    out = fpndm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=False, subsample_steps=g["subsample"], clip_before=True,
+                        verbose=False, log=False, denoise=True, config=config)
+    ref = g["all_clip"]
+    assert out.device.type == "cpu" and out.shape == ref.shape
+    err = (out - ref).abs().max().item()
+    assert err <= 2e-4, f"max-abs err over all steps {err:.3e}"          # deterministic multistep: no noise damps rounding (cf. DDIM)
+    fin = fpndm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=g["subsample"], clip_before=False)
+    assert fin.is_cuda and fin.shape == g["final_noclip"].shape
+    torch.testing.assert_close(fin.cpu(), g["final_noclip"], rtol=5e-3, atol=5e-3)
+    config.model.version = "FPNDM"
+    assert get_sampler(config).func is fpndm_sampler
+    with pytest.raises(TypeError):
+        fpndm_sampler(x.cuda(), net, cond=cond.cuda())                  # subsample_steps is mandatory, as in the reference
+
+
+def test_float_timesteps_match_integer_labels():
+    """mcvd_unet_forward_ft with integral float timesteps == mcvd_unet_forward with the int64 labels (timesteps.float())."""
+    config, sd, net = _net("tiny")
+    x, cond = synth.make_inputs(config, 3, seed=0)
+    t = torch.tensor([0, 417, 999])
+    a = net(x.cuda(), t.cuda(), cond=cond.cuda())
+    b = net(x.cuda(), t.float().cuda(), cond=cond.cuda())
+    assert torch.equal(a, b)
+    th = torch.tensor([-0.5, 416.5, 3.25])
+    c = net(x.cuda(), th.cuda(), cond=cond.cuda())
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, th, cond)
+    assert (c.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_pndm_kernels_bitwise(ctx):
+    """mcvd_lincomb / mcvd_pndm_transfer round like torch's elementwise evaluation of the reference expressions."""
+    import ctypes as C
+    from mcvd_pytorch_amd import _lib
+    from tests.hiputil import P
+    g = _g(3)
+    e = [torch.randn(4099, generator=g) for _ in range(4)]
+    x = torch.randn(4099, generator=g)
+    ec = [t.cuda() for t in e]
+    out = torch.empty(4099, device="cuda")
+    w = [55.0, -59.0, 37.0, -9.0]
+    _lib.check(_lib.lib.mcvd_lincomb(ctx.h, P(out), P(ec[0]), P(ec[1]), P(ec[2]), P(ec[3]), w[0], w[1], w[2], w[3],
+                                     float(torch.tensor(1 / 24)), 4, 4099))
+    want = (1 / 24) * (55 * e[0] - 59 * e[1] + 37 * e[2] - 9 * e[3])              # models/pndm.py:47
+    assert torch.equal(out.cpu(), want)
+    _lib.check(_lib.lib.mcvd_lincomb(ctx.h, P(out), P(ec[0]), P(ec[1]), P(ec[2]), P(ec[3]), 1.0, 2.0, 2.0, 1.0,
+                                     float(torch.tensor(1 / 6)), 4, 4099))
+    assert torch.equal(out.cpu(), (1 / 6) * (e[0] + 2 * e[1] + 2 * e[2] + e[3]))   # :15
+    at, an = torch.tensor(0.37), torch.tensor(0.52)
+    d, c1 = an - at, 1 / (at.sqrt() * (at.sqrt() + an.sqrt()))
+    c2 = 1 / (at.sqrt() * (((1 - an) * at).sqrt() + ((1 - at) * an).sqrt()))
+    for clip in (0, 1):
+        _lib.check(_lib.lib.mcvd_pndm_transfer(ctx.h, P(out), P(x.cuda()), P(ec[0]), float(d), float(c1), float(c2), clip, 4099))
+        want = x + d * (c1 * x - c2 * e[0])                                        # :27-29
+        if clip:
+            want = want.clip(-1, 1)
+        assert torch.equal(out.cpu(), want)
+
+
 def test_spade_cache_follows_cond_content():
     """SPADE gamma/beta are cached per cond tensor: changing cond in place (torch bumps ._version) must recompute."""
     config, sd, net = _net("tiny_spade")

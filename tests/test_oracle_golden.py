@@ -76,6 +76,20 @@ def test_sampler_matches_reference(golden_dir, fx, key, kind, sub, extra):
     assert (out - ref).abs().max().item() <= 1e-4
 
 
+def test_fpndm_matches_reference(golden_dir):
+    """FPNDM_sampler (models/__init__.py:38-99 + models/pndm.py): every step of the clipped run, and the un-clipped final state
+    (which grows to |x| ~ 360 on random weights: relative tolerance)."""
+    g = load(golden_dir, "tiny_b3_fpndm.pt")
+    config = synth.make_config(g["config_name"])
+    net = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123))
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    out = sampler_ref.fpndm_sample(x.clone(), net, cond=cond, final_only=False, subsample_steps=g["subsample"], clip_before=True)
+    assert out.shape == g["all_clip"].shape
+    assert (out - g["all_clip"]).abs().max().item() <= 1e-4
+    fin = sampler_ref.fpndm_sample(x.clone(), net, cond=cond, final_only=True, subsample_steps=g["subsample"], clip_before=False)
+    torch.testing.assert_close(fin, g["final_noclip"], rtol=2e-3, atol=2e-3)
+
+
 def test_fir_closed_forms(golden_dir):
     g = load(golden_dir, "fir.pt")
     torch.testing.assert_close(unet_ref.fir_up2(g["x"]), g["up"], rtol=1e-5, atol=1e-6)

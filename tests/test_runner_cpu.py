@@ -37,3 +37,12 @@ def test_data_transform_round_trip():
     assert Y.min() >= -1 and Y.max() <= 1 and torch.allclose(Y, 2 * X - 1)
     assert torch.allclose(r.inverse_data_transform(cfg, Y), X, atol=1e-6)
     assert r.inverse_data_transform(cfg, Y * 3).max() <= 1.0                    # clamp (datasets/__init__.py:261)
+
+
+def test_save_video_pred_format(tmp_path):
+    """videos_pred_<ckpt>.pt: a dict of CPU tensors with the reference's keys (ncsn_runner.py:2106-2112)."""
+    r = _runner()
+    cond, pred, real = torch.rand(2, 4, 8, 8), torch.rand(2, 6, 8, 8), torch.rand(2, 6, 8, 8)
+    p = r.save_video_pred(str(tmp_path / "videos_pred_1000.pt"), cond, pred, real)
+    d = torch.load(p, weights_only=False)
+    assert sorted(d) == ["cond", "pred", "real"] and torch.equal(d["pred"], pred) and d["cond"].device.type == "cpu"
