@@ -47,13 +47,17 @@ __device__ __forceinline__ float silu_wr(float v) { return v * __builtin_amdgcn_
 constexpr int WR_CK = 16;        // input channels per chunk (two 8-channel weight units)
 constexpr int WR_T = 32;         // tiles per workgroup (4 x 8 tiles = 8 x 16 output pixels)
 constexpr int WR_NT = 1024;
+// LDS patch row pitch (18 columns used).  24: the tile transform reads 8-byte pairs at 2*PP*ty + 2*tx floats, 16 lanes per LDS
+// cycle (ty in {0,1}, tx in 0..7): 2*PP = 48 = 16 mod 32 banks puts the two tile rows on disjoint banks (pitch 20 was a
+// 2-way conflict on half the lanes: SQ_LDS_BANK_CONFLICT 29 % of the LDS-active cycles, profiles/r01_pmc_sq_wave_states.txt).
+constexpr int WR_PP = 24;
 
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU
 template <int COT, int PRO>
 __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     constexpr int NT = WR_NT, CK = WR_CK, T = WR_T, BCO = 32 * COT;
     constexpr int VSZ = CK * 16 * T;            // floats per V chunk
-    constexpr int PP = 20;                      // LDS patch row pitch (18 columns used)
+    constexpr int PP = WR_PP;
     constexpr int PSZ = CK * 10 * PP;           // activated input patch of one chunk: [CK][10 rows][PP]
     constexpr int PBUF = PSZ + 4;               // + dump space for unused patch slots
     constexpr int PCOUNT = CK * 10 * 18;
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
 }
 
 static size_t wino_lds_bytes(int Cin) {
-    const size_t k = (size_t)(2 * WR_CK * 16 * WR_T + 2 * (WR_CK * 10 * 20 + 4) + 2 * Cin) * sizeof(float);
+    const size_t k = (size_t)(2 * WR_CK * 16 * WR_T + 2 * (WR_CK * 10 * WR_PP + 4) + 2 * Cin) * sizeof(float);
     const size_t epi = (size_t)16 * 32 * WR_T * sizeof(float);        // sM of the epilogue
     return k > epi ? k : epi;
 }

@@ -153,8 +153,9 @@ int launch_axpy_out(float* x, const float* eps, float c, int64_t n, hipStream_t 
     return 0;
 }
 
-// ---- F-PNDM pieces (models/pndm.py).  Separate roundings (__fmul_rn / __fadd_rn, no FMA contraction) in the order of the
-// reference's tensor expressions, so the multistep combination is bit-identical to torch's elementwise evaluation.
+// ---- F-PNDM pieces (models/pndm.py).  One rounding per operation, in the order of the reference's tensor expressions, so the
+// multistep combination is bit-identical to torch's elementwise evaluation: plain operators under `fp contract(off)` (the
+// __fmul_rn / __fadd_rn device functions are inlined with the translation unit's default contraction and DO get fused).
 struct LinArgs {
     const float* in[4];
     float w[4];
@@ -164,13 +165,16 @@ struct LinArgs {
 
 // out = scale * (((w0*in0 + w1*in1) + w2*in2) + w3*in3)     runge_kutta :15, gen_order_4 :47
 __global__ __launch_bounds__(256) void lincomb_kernel(float* out, LinArgs a, int64_t n) {
-#pragma clang fp contract(off)      // hipcc maps __fmul_rn / __fadd_rn to plain operators, which it would otherwise fuse
+#pragma clang fp contract(off)
     for (int64_t i = blockIdx.x * 256L + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float t = __fmul_rn(a.w[0], a.in[0][i]);
+        float t = a.w[0] * a.in[0][i];
 #pragma unroll
         for (int k = 1; k < 4; ++k)
-            if (k < a.nin) t = __fadd_rn(t, __fmul_rn(a.w[k], a.in[k][i]));
-        out[i] = __fmul_rn(a.scale, t);
+            if (k < a.nin) {
+                const float p = a.w[k] * a.in[k][i];
+                t = t + p;
+            }
+        out[i] = a.scale * t;
     }
 }
 
@@ -190,8 +194,10 @@ __global__ __launch_bounds__(256) void pndm_transfer_kernel(float* out, const fl
 #pragma clang fp contract(off)
     for (int64_t i = blockIdx.x * 256L + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float xv = x[i];
-        const float r = __fsub_rn(__fmul_rn(c1, xv), __fmul_rn(c2, e[i]));
-        float v = __fadd_rn(xv, __fmul_rn(d, r));
+        const float p = c1 * xv, q = c2 * e[i];
+        const float r = p - q;
+        const float dr = d * r;
+        float v = xv + dr;
         if (clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
         out[i] = v;
     }

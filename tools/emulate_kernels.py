@@ -253,7 +253,7 @@ def wino_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT
     B, C0, H, W = x0.shape
     C1 = 0 if x1 is None else x1.shape[1]
     Cin = C0 + C1
-    CK, T, BCO, NT, PP = 16, 32, 32 * COT, 1024, 20
+    CK, T, BCO, NT, PP = 16, 32, 32 * COT, 1024, 24
     VSZ, PSZ = CK * 16 * T, CK * 10 * PP
     assert CinP % CK == 0 and (C1 == 0 or C0 % CK == 0)
     HW = H * W

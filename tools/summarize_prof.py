@@ -77,6 +77,28 @@ def mfma():
             print(f"{k:58s} {int(d['n']):5d} {ns / 1e6:9.2f} ms  clk {gui / 8 / ns:5.2f} GHz  mfma_busy {mf / (gui / 8 * 1024):6.3f}")
 
 
+def sq():
+    """Wave-state split per kernel from the SQ counters (quad-cycle units): fractions of SQ_WAVE_CYCLES."""
+    for f in glob.glob(os.path.join(OUT, "pmc_sq", "**", "*counter_collection.csv"), recursive=True):
+        agg = defaultdict(lambda: defaultdict(float))
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "SQ_WAVE_CYCLES":
+                agg[k]["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                agg[k]["n"] += 1
+        print("== per kernel: launches, total ms | of SQ_WAVE_CYCLES: WAIT_ANY (parked: s_waitcnt / barrier), WAIT_INST_ANY (issue-stalled), "
+              "of which WAIT_INST_LDS, ACTIVE_INST_ANY (issuing) | LDS: bank-conflict cycles / LDS-active cycles")
+        for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("ns", 0))[:24]:
+            wc = d.get("SQ_WAVE_CYCLES", 0)
+            if wc <= 0:
+                continue
+            print(f"{k:58s} {int(d['n']):5d} {d['ns'] / 1e6:9.2f} ms | parked {d.get('SQ_WAIT_ANY', 0) / wc:5.3f}  issue-stall "
+                  f"{d.get('SQ_WAIT_INST_ANY', 0) / wc:5.3f} (lds {d.get('SQ_WAIT_INST_LDS', 0) / wc:5.3f})  issuing "
+                  f"{d.get('SQ_ACTIVE_INST_ANY', 0) / wc:5.3f} | lds conflict {d.get('SQ_LDS_BANK_CONFLICT', 0) / max(d.get('SQ_LDS_IDX_ACTIVE', 0), 1):5.3f}"
+                  f"  lds-active/busy {d.get('SQ_LDS_IDX_ACTIVE', 0) / max(d.get('SQ_BUSY_CYCLES', 0), 1):6.3f}")
+
+
 def traffic(out_json):
     """HBM-side bytes per launch of the dominant kernel (largest total time in the kernel stats) from the two PMC passes."""
     import json
@@ -108,6 +130,9 @@ def traffic(out_json):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sq":
+        sq()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "traffic":
         traffic(sys.argv[2])
         sys.exit(0)
