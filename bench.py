@@ -230,7 +230,7 @@ def main():
                    ms_per_step=round(1e3 * dt / args.steps, 2), higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="f32", data="synthetic",
                    config=dict(workload=f"{args.config}: ddpm_sampler subsample={args.subsample} (+1 denoise forward), "
-                                        f"64x64, 5 cond + 5 pred frames, batch {B}/GPU, random-init weights, Philox noise",
+                                        f"{config.data.image_size}x{config.data.image_size}, {config.data.num_frames_cond} cond + {nfr} pred frames, batch {B}/GPU, random-init weights, Philox noise",
                                global_batch=total, frames_per_step=total * nfr, forwards_per_step=args.subsample + 1,
                                parallelism=f"sample-sharded x{world} (1 weight broadcast + 1 final all_gather)"),
                    roofline=roofline)
