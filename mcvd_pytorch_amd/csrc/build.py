@@ -45,14 +45,23 @@ def compile_one(src, force):
 def build(force=False, jobs=None, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sources()
-    objs, rebuilt = [], 0
+    objs, rebuilt, wino_rebuilt = [], 0, False
     with cf.ThreadPoolExecutor(max_workers=jobs or os.cpu_count()) as ex:
         for obj, log in ex.map(lambda s: compile_one(s, force), srcs):
             objs.append(obj)
             if log is not None:
                 rebuilt += 1
+                wino_rebuilt |= os.path.basename(obj) == "conv_wino.o"
                 if log and verbose:
                     print(log, file=sys.stderr)
+    if wino_rebuilt:
+        # conv_wino.cpp manages its VMEM waits by hand; the generated code must keep the invariants that makes sound
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_wino_isa.py")], capture_output=True, text=True)
+        if r.returncode != 0:
+            os.remove(os.path.join(OBJ, "conv_wino.o"))
+            raise RuntimeError("conv_wino.cpp: generated code violates the asm-load invariants\n" + r.stderr)
+        if verbose:
+            print(r.stdout.strip())
     if rebuilt or not os.path.exists(LIB) or force:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -29,8 +29,9 @@
 //     the chunk, the second half is MFMAs only, so the waves reach the barrier together.
 //   * every VMEM operation of the K loop is issued through inline asm and waited for with explicit in-order vmcnt counts:
 //     the compiler's s_waitcnt insertion falls back to vmcnt(0) for loop-carried loads, which would serialise the weight
-//     prefetch behind the patch loads.  The wait points and the counts are spelled out at each use below; the destination
-//     registers are verified (ISA) not to be copied between a load and its wait.
+//     prefetch behind the patch loads.  The wait points and the counts are spelled out at each use below.  The compiler does not
+//     know these registers are pending, so the build runs tools/check_wino_isa.py on the generated code (no read/copy/spill of
+//     a destination register before a vmcnt wait, no foreign VMEM in the loop) whenever this file is recompiled.
 //   * epilogue: per 32-cout sub-tile the 16 position planes go through LDS and every thread inverse-transforms one (cout, tile).
 #include <stdlib.h>
 

@@ -1,0 +1,87 @@
+"""Static check of the invariants conv_wino.cpp's hand-managed VMEM waits rely on (run by __graft_entry__.build() and the CPU tests).
+
+The kernel's K loop issues its global loads through inline asm and waits for them with explicit, in-order `s_waitcnt vmcnt(N)`
+counts, because hipcc's own waitcnt insertion is not exact for loop-carried loads.  The compiler therefore does not know that
+the destination registers of those loads are pending.  That is only sound if, in the generated code,
+  1. nothing reads or overwrites a destination register between the load and a following `s_waitcnt vmcnt` (no copies, no
+     spills, no reuse as a temporary), following the loop's layout order and wrapping around the back edge;
+  2. the loop contains no scratch (spill) instructions: they are VMEM operations and would break the counts;
+  3. the loop's VMEM instructions are exactly the asm loads (COT weight loads twice per chunk + 3 patch loads).
+This script compiles the file to gfx950 assembly and verifies 1-3 for every instantiation of conv_wino_kernel.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc", "kernels", "conv_wino.cpp")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _regs(text):
+    r = {int(x) for x in re.findall(r"\bv(\d+)\b", text)}
+    for a, b in re.findall(r"v\[(\d+):(\d+)\]", text):
+        r |= set(range(int(a), int(b) + 1))
+    return r
+
+
+def check(asm_text):
+    problems, seen = [], 0
+    for m in re.finditer(r"^(_ZN4mcvd16conv_wino_kernelILi(\d)ELi(\d)EEEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
+        name, cot, body = m.group(1), int(m.group(2)), m.group(4)
+        seen += 1
+        lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        starts = [i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l) and "Loop" in l]
+        if not starts:
+            problems.append(f"{name}: no loop found")
+            continue
+        end = starts[-1] + 1
+        while end < len(lines) and not re.match(r"^\.LBB\d+_\d+:", lines[end]):
+            end += 1
+        loop = [l for l in lines[starts[0]:end] if not re.match(r"^\.LBB", l)]
+        vmem = [l for l in loop if re.match(r"^(global_|buffer_|scratch_|flat_)", l)]
+        if any(l.startswith("scratch_") for l in vmem):
+            problems.append(f"{name}: spill code inside the K loop")
+        loads = [l for l in vmem if re.match(r"^global_load_dword(x4)? v", l)]
+        if len(loads) != len(vmem) or len(loads) != 2 * cot + 3:
+            problems.append(f"{name}: expected {2 * cot + 3} asm loads and no other VMEM in the loop, found {len(loads)} of {len(vmem)}")
+        n = len(loop)
+        for i, l in enumerate(loop):
+            mm = re.match(r"^global_load_dword(?:x4)? (v\d+|v\[\d+:\d+\]),", l)
+            if not mm:
+                continue
+            dest = _regs(mm.group(1))
+            for k in range(1, n + 1):                                   # layout order, wrapping around the back edge
+                nxt = loop[(i + k) % n]
+                if re.match(r"^s_waitcnt.*vmcnt", nxt):
+                    break
+                ops = nxt.split(None, 1)
+                if len(ops) > 1 and _regs(ops[1]) & dest:
+                    problems.append(f"{name}: `{nxt}` touches the destination of `{l}` before any vmcnt wait")
+                    break
+    if seen != 9:
+        problems.append(f"expected 9 instantiations of conv_wino_kernel, found {seen}")
+    return problems
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "conv_wino.s")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+               SRC, "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr, file=sys.stderr)
+            return 2
+        problems = check(open(out).read())
+    for p in problems:
+        print("conv_wino ISA check:", p, file=sys.stderr)
+    if not problems:
+        print("conv_wino ISA check: ok (asm-load destinations untouched until their vmcnt wait, no spills in the K loop)")
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
