@@ -84,7 +84,7 @@ void mcvd_ctx_destroy(mcvd_ctx* ctx);
 int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
 /* options: "naive_conv", "naive_attn" (0/1: route through the simple one-thread-per-output HIP kernels, used by the
  * tests to triangulate), "conv_shape" (-1 auto; 0/1/2/3 force the 256/128/64-pixel / split-K conv tile, 4 the Winograd F(2x2,3x3) kernel where
- * it applies, 5 / 6 the all-DMA 1x1 GEMM kernel (16 / 32 channels per chunk) where it applies), "winograd" / "conv_dma1" (1: offer the Winograd / all-DMA 1x1
+ * it applies (8: with its 2-way split of the input channels), 5 / 6 the all-DMA 1x1 GEMM kernel (16 / 32 channels per chunk) where it applies), "winograd" / "conv_dma1" (1: offer the Winograd / all-DMA 1x1
  * kernel to the autotuner), "conv_cot" (with conv_shape 5: cout tile, in 32-channel units, that mcvd_op_conv2d requests), "conv_wdma" (1: weight
  * chunks by LDS-DMA, 0: register staging), "autotune" (1: time the conv tile candidates per layer shape on first use of a batch
  * size and keep the fastest), "side_stream" (1: ResBlock shortcut convs run on a second HIP stream concurrently with Conv_0; default 0, it measured slower), "profile" (0/1, see

@@ -533,7 +533,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.CinP = round_up(a.Cin, conv_chunk(ks));
     a.CoutP = round_up(Cout, 32 * a.cot);
     const size_t wfloats = (size_t)a.CinP * ks * ks * a.CoutP;
-    const bool wino = ctx->conv_shape == 4 && conv_wino_supported(ks, H, W);
+    const bool wino = (ctx->conv_shape == 4 || ctx->conv_shape == 8) && conv_wino_supported(ks, H, W);
     const size_t ufloats = wino ? (size_t)a.CinP * 16 * a.CoutP : 0;
     if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats) * sizeof(float))) return rc;
     MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP + ufloats) * sizeof(float), ctx->stream));

@@ -31,7 +31,12 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     auto fits = [&](int bpx) { return bpx % a.W == 0 && (bpx / a.W <= a.H ? a.H % (bpx / a.W) == 0 : (bpx / a.W) % a.H == 0); };
     int shape;
     // hints 4 / 5 select the specialised kernels where they apply and fall back to the tile heuristic elsewhere
-    if (a.shape_hint == 4 && conv_wino_usable(a)) return launch_conv_wino(a, s);                              // Winograd F(2x2,3x3)
+    if (a.shape_hint == 8) {                                        // Winograd with a 2-way K split (fills the CUs on 8x8 layers)
+        ConvArgs b = a;
+        b.ksplit = 2;
+        if (conv_wino_usable(b)) return launch_conv_wino(b, s);
+    }
+    if ((a.shape_hint == 4 || a.shape_hint == 8) && conv_wino_usable(a)) return launch_conv_wino(a, s);                              // Winograd F(2x2,3x3)
     if (a.shape_hint == 5 && conv1x1_dma_supported(a, 16)) return launch_conv1x1_dma(a, a.cot, 16, s);   // all-DMA 1x1 GEMM
     if (a.shape_hint == 6 && conv1x1_dma_supported(a, 32) && a.cot != 9) return launch_conv1x1_dma(a, a.cot, 32, s);
     if (a.cot < 1 || a.cot > 4 || a.CoutP % (32 * a.cot) != 0) {   // a cout tile meant for another kernel: use this one's

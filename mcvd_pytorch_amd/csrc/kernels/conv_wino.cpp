@@ -53,17 +53,23 @@ constexpr int WR_NT = 1024;
 // 2-way conflict on half the lanes: SQ_LDS_BANK_CONFLICT 29 % of the LDS-active cycles, profiles/r01_pmc_sq_wave_states.txt).
 constexpr int WR_PP = 24;
 
-// PRO: 0 raw input, 1 affine, 2 affine + SiLU
-template <int COT, int PRO>
+// PRO: 0 raw input, 1 affine, 2 affine + SiLU.
+// G8: 8x8 images -- the 32 tiles of a workgroup are TWO whole images (16 tiles each); every halo element is zero padding, so
+//     only the 2 x 64 interior pixels per channel are loaded (2 per thread and chunk) and the halo is zeroed once.
+// a.ksplit == 2 (grid.y = 2): the workgroup contracts one half of the input channels and ADDS its result into a zero-filled
+//     output with a hardware fp32 atomic (0 + p0 + p1 in either order is the same float: deterministic); used where the
+//     (region, cout tile) count alone cannot fill the 256 CUs (8x8 layers).
+template <int COT, int PRO, bool G8>
 __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     constexpr int NT = WR_NT, CK = WR_CK, T = WR_T, BCO = 32 * COT;
     constexpr int VSZ = CK * 16 * T;            // floats per V chunk
     constexpr int PP = WR_PP;
     constexpr int PSZ = CK * 10 * PP;           // activated input patch of one chunk: [CK][10 rows][PP]
     constexpr int PBUF = PSZ + 4;               // + dump space for unused patch slots
-    constexpr int PCOUNT = CK * 10 * 18;
-    constexpr int MAXP = (PCOUNT + NT - 1) / NT;
-    static_assert(MAXP == 3, "the vmcnt counts below assume 3 patch loads per thread and chunk");
+    constexpr int PCOUNT = G8 ? CK * 2 * 64 : CK * 10 * 18;     // patch elements loaded per chunk
+    constexpr int MAXP = (PCOUNT + NT - 1) / NT;                // 3 (2 for G8) loads per thread and chunk
+    constexpr int VM_P = COT;                                   // vmcnt counts of the K loop, derived where they are used
+    constexpr int VM_A = COT + MAXP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sV = smem;                           // [2][VSZ]
     float* sP = smem + 2 * VSZ;                 // [2][PBUF]
@@ -71,23 +77,25 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int H = a.H, W = a.W, HW = H * W, Cin = a.Cin;
-    const int rx_n = W >> 4, ry_n = H >> 3;
+    const int rx_n = G8 ? 1 : W >> 4, ry_n = G8 ? 1 : H >> 3;
+    const int nreg = G8 ? (a.B + 1) >> 1 : a.B * rx_n * ry_n;
     // block id -> (region, cout tile): the cout tiles of one region get ids congruent mod 8 and adjacent in dispatch order, i.e.
     // they run at the same time on the SAME XCD and share the region's input patch through that XCD's L2.
     const int nct = a.CoutP / BCO;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int reg_id = (slot / nct) * 8 + xcd;
-    if (reg_id >= a.B * rx_n * ry_n) return;
-    const int b = reg_id / (rx_n * ry_n);
-    const int rr = reg_id - b * (rx_n * ry_n);
-    const int oy0 = (rr / rx_n) * 8, ox0 = (rr % rx_n) * 16;
     const int cotile = slot - (slot / nct) * nct;
+    if (reg_id >= nreg) return;
+    const int b = G8 ? 2 * reg_id : reg_id / (rx_n * ry_n);      // (first) sample of the region
+    const int rr = G8 ? 0 : reg_id - b * (rx_n * ry_n);
+    const int oy0 = (rr / rx_n) * 8, ox0 = (rr % rx_n) * 16;
     const int co0 = cotile * BCO;
     const int grp = wave >> 2;                  // row of B^T d this wave's threads make == pipeline phase of the wave
 
     // ---- transform role: tasks (channel-in-chunk, tile) = (tid & 255) and the same + 8 channels, row = grp
     const int s_ci = (tid & 255) >> 5, s_tile = tid & 31;
-    const int s_ty = s_tile >> 3, s_tx = s_tile & 7;
+    // tile -> (row, column) of its 4x4 window's top-left corner in the LDS patch [ci][10 rows][PP]; G8: image i sits at columns 10*i
+    const int s_ty = G8 ? (s_tile >> 2) & 3 : s_tile >> 3, s_tx = G8 ? (s_tile & 3) + 5 * (s_tile >> 4) : s_tile & 7;
     // row grp of B^T d:  0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3
     const int p_rd = s_ci * 10 * PP + 2 * s_ty * PP + 2 * s_tx;     // top-left of the 4x4 window in the LDS patch
     const int p_rdA = p_rd + (grp == 0 ? 0 : 1) * PP, p_rdB = p_rd + (grp == 3 ? 3 : 2) * PP;
@@ -96,10 +104,19 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
 
     // ---- patch-load slots (chunk invariant); p_ci = channel-in-chunk, or CK + channel when the element is padding / unused
     int p_lds[MAXP], p_goff[MAXP], p_ci[MAXP];
+    int p_img[MAXP];                            // G8: second image of the region (0 / 1), clamped to the last sample
 #pragma unroll
     for (int sl = 0; sl < MAXP; ++sl) {
         const int e = sl * NT + tid;
-        if (e < PCOUNT) {
+        p_img[sl] = 0;
+        if (G8) {                               // e -> (channel, image, row, col) of an interior pixel; always < PCOUNT
+            const int ci = e >> 7, img = (e >> 6) & 1, r = (e >> 3) & 7, c = e & 7;
+            const bool valid = b + img < a.B;
+            p_lds[sl] = ci * 10 * PP + (r + 1) * PP + img * 10 + c + 1;
+            p_goff[sl] = r * 8 + c;
+            p_img[sl] = valid ? img : 0;
+            p_ci[sl] = ci + (valid ? 0 : CK);
+        } else if (e < PCOUNT) {
             const int ci = e / 180, rem = e - ci * 180;
             const int r = rem / 18, c = rem - r * 18;
             const int y = oy0 - 1 + r, x = ox0 - 1 + c;
@@ -130,9 +147,9 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
        the asm so that nothing reading it can be scheduled above the wait */                                               \
 #define WR_WAIT_A(N, S)                                                                                         \
     {                                                                                                           \
-        if (COT == 1) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(S[0]) :: "memory");                         \
-        if (COT == 2) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(S[0]), "+v"(S[1]) :: "memory");             \
-        if (COT == 3) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]) :: "memory"); \
+        if (COT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(S[0]) : "n"(N) : "memory");                     \
+        if (COT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(S[0]), "+v"(S[COT > 1 ? 1 : 0]) : "n"(N) : "memory"); \
+        if (COT == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(S[0]), "+v"(S[COT > 1 ? 1 : 0]), "+v"(S[COT > 2 ? 2 : 0]) : "n"(N) : "memory"); \
     }
     /* unconditional, clamped raw loads of the patch of chunk `ch` into pd[]; the chunk never straddles the concat seam      \
        (launch check: C0 % 16 == 0 when C1 > 0), channels past Cin re-read the last one and are zeroed at the write */         \
@@ -142,12 +159,17 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
         const int cmax = Cin - 1 - cb;                                                                          \
         const bool second = cb >= a.C0;                                                                         \
         const float* srcb = second ? a.x1 + ((long)b * a.C1 + (cb - a.C0)) * HW : a.x0 + ((long)b * a.C0 + cb) * HW; \
+        const int istride = (second ? a.C1 : a.C0) * HW;      /* G8: distance to the region's second sample */  \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
-            const unsigned off = (unsigned)(min(p_ci[sl] & (CK - 1), cmax) * HW + p_goff[sl]) * 4u;             \
+            const unsigned off = (unsigned)(min(p_ci[sl] & (CK - 1), cmax) * HW + p_goff[sl] + (G8 ? p_img[sl] * istride : 0)) * 4u; \
             asm volatile("global_load_dword %0, %1, %2" : "=v"(D[sl]) : "v"(off), "s"(srcb) : "memory");        \
         }                                                                                                       \
     }
-#define WR_WAIT_P(N, D) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]) :: "memory");
+#define WR_WAIT_P(N, D)                                                                                         \
+    {                                                                                                           \
+        if (MAXP == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(D[0]), "+v"(D[1]) : "n"(N) : "memory");        \
+        if (MAXP == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(D[0]), "+v"(D[1]), "+v"(D[MAXP > 2 ? 2 : 0]) : "n"(N) : "memory"); \
+    }
     /* activate once per pixel (coefficients from the LDS table) and park the patch in LDS; zero padding applies AFTER     \
        the activation */                                                                                           \
 #define WR_WRITE_P(ch, D)                                                                                        \
@@ -157,7 +179,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
             float v = D[sl];                                                                                    \
             if (PRO >= 1) {                                                                                     \
-                const int cch = min((ch) * CK + (p_ci[sl] & (CK - 1)), Cin - 1);                                \
+                const int cch = min((ch) * CK + (p_ci[sl] & (CK - 1)), Cin - 1) + (G8 ? p_img[sl] * Cin : 0);   \
                 const f32x2 cf = *reinterpret_cast<const f32x2*>(sCo + cch * 2);                                \
                 v = v * cf.x + cf.y;                                                                            \
             }                                                                                                   \
@@ -207,51 +229,61 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
         tprev = now;                                                                                            \
     }
 
+    // ---- chunk range of this workgroup (a.ksplit == 2: blockIdx.y picks one half of the input channels)
+    const int nch_all = a.CinP / CK;
+    const int ksp = a.ksplit == 2 ? 2 : 1, kh = ksp == 2 ? (int)blockIdx.y : 0;
+    const int c_begin = kh * (nch_all / ksp), c_end = c_begin + nch_all / ksp;
+
     // ---- prologue: every global load of the first chunks + the coefficient table is issued before anything waits
-    const int nchunks = a.CinP / CK;
     f32x4 A0[COT], A1[COT];                // A operands of the even / odd weight unit (first / second half of a chunk)
     float pd[MAXP];                        // raw patch registers, loaded one chunk ahead of their activation
     {
-        float q0[MAXP], q1[MAXP];          // patches of chunks 0 and 1: prologue only
+        float q0[MAXP], q1[MAXP];          // patches of the first two chunks: prologue only
         f32x2 cfl = {1.0f, 0.0f};
-        WR_LOAD_A(0, A0)
-        WR_LOAD_A(1, A1)
-        WR_LOAD_P(0, q0)
-        WR_LOAD_P(1, q1)
-        WR_LOAD_P(2, pd)
+        WR_LOAD_A(2 * c_begin, A0)
+        WR_LOAD_A(2 * c_begin + 1, A1)
+        WR_LOAD_P(c_begin, q0)
+        WR_LOAD_P(c_begin + 1, q1)
+        WR_LOAD_P(c_begin + 2, pd)
         if (PRO && a.coef && tid < Cin) cfl = *reinterpret_cast<const f32x2*>(a.coef + ((long)b * Cin + tid) * 2);
         if (PRO && tid < Cin) *reinterpret_cast<f32x2*>(sCo + tid * 2) = cfl;
+        if (G8) {                          // the halo of both patch buffers is zero padding for the whole kernel
+            for (int i = tid; i < 2 * PBUF; i += NT) sP[i] = 0.0f;
+            if (PRO && a.coef && tid < Cin && b + 1 < a.B)     // second sample's coefficients: table rows Cin .. 2*Cin-1
+                cfl = *reinterpret_cast<const f32x2*>(a.coef + ((long)(b + 1) * Cin + tid) * 2);
+            if (PRO && tid < Cin) *reinterpret_cast<f32x2*>(sCo + (Cin + tid) * 2) = cfl;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ONE memory latency for everything above (the asm loads are
         WR_WAIT_A(0, A0)                                     // not tracked by the compiler: the waits are threaded through
         WR_WAIT_A(0, A1)                                     // the destination registers)
         WR_WAIT_P(0, q0)
         WR_WAIT_P(0, q1)
         WR_WAIT_P(0, pd)
-        if (PRO) __syncthreads();          // coefficient table visible
-        WR_WRITE_P(0, q0)
-        WR_WRITE_P(1, q1)
+        if (PRO || G8) __syncthreads();    // coefficient table (and the zeroed halo) visible
+        WR_WRITE_P(c_begin, q0)
+        WR_WRITE_P(c_begin + 1, q1)
     }
-    __syncthreads();                       // patch(0), patch(1) visible
-    WR_WRITE_V(0)
-    __syncthreads();                       // V(0) visible
+    __syncthreads();                       // the first two patches visible
+    WR_WRITE_V(c_begin)
+    __syncthreads();                       // V of the first chunk visible
     WR_STAMP(0)
 
     // ---- K loop.  VMEM issue order of a wave in chunk c (in-order vmcnt counter; nothing else is outstanding):
-    //   top:  A1 <- unit 2c+1 (COT loads), patch(c+3) (3 loads)      mid (after group 3):  A0 <- unit 2c+2 (COT loads)
-    // wait points:  patch(c+2) write at the top, before the new loads: everything but the COT loads of `mid` of chunk c-1
-    //               first use of A1 (group 4): issued at the top, younger = 3 patch + COT mid loads
-    //               first use of A0 (group 0 of the next chunk): issued at mid, younger = COT + 3 loads of that chunk's top
+    //   top:  A1 <- unit 2c+1 (COT loads), patch(c+3) (MAXP loads)   mid (after group 3):  A0 <- unit 2c+2 (COT loads)
+    // wait points:  patch(c+2) write at the top, before the new loads: all but the COT loads of `mid` of chunk c-1  (VM_P = COT)
+    //               first use of A1 (group 4): issued at the top, younger = MAXP patch + COT mid loads            (VM_A)
+    //               first use of A0 (group 0 of the next chunk): issued at mid, younger = COT + MAXP loads of that chunk's top
     float xb = 0.0f, yb = 0.0f;            // B operands; yb = 0: the first "deferred" group multiplies zeros
-    for (int c = 0; c + 1 < nchunks; ++c) {
+    for (int c = c_begin; c + 1 < c_end; ++c) {
         const float* sVc = sV + ((c & 1) ? VSZ : 0);
         WR_DO_MFMA(3, yb, A1)              // group 7 of the previous chunk (operands were read before the barrier)
         WR_LOAD_B(0, xb)
-        if (COT == 1) { WR_WAIT_P(1, pd) } else if (COT == 2) { WR_WAIT_P(2, pd) } else { WR_WAIT_P(3, pd) }
+        WR_WAIT_P(VM_P, pd)
         WR_WRITE_P(c + 2, pd)
         WR_LOAD_A(2 * c + 1, A1)
         WR_LOAD_P(c + 3, pd)
         if (grp == 3) WR_WRITE_V(c + 1)    // slot T
-        if (COT == 1) { WR_WAIT_A(4, A0) } else if (COT == 2) { WR_WAIT_A(5, A0) } else { WR_WAIT_A(6, A0) }
+        WR_WAIT_A(VM_A, A0)
         WR_DO_MFMA(0, xb, A0)              // g0
         WR_LOAD_B(1, yb)
         if (grp == 2) WR_WRITE_V(c + 1)
@@ -264,7 +296,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
         WR_DO_MFMA(3, yb, A0)              // g3
         WR_LOAD_B(4, xb)
         WR_LOAD_A(2 * c + 2, A0)           // mid: first unit of the next chunk
-        if (COT == 1) { WR_WAIT_A(4, A1) } else if (COT == 2) { WR_WAIT_A(5, A1) } else { WR_WAIT_A(6, A1) }
+        WR_WAIT_A(VM_A, A1)
         WR_DO_MFMA(0, xb, A1)              // g4
         WR_LOAD_B(5, yb)
         WR_DO_MFMA(1, yb, A1)              // g5
@@ -275,12 +307,12 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     {
-        const int c = nchunks - 1;
+        const int c = c_end - 1;
         const float* sVc = sV + ((c & 1) ? VSZ : 0);
         WR_DO_MFMA(3, yb, A1)
         WR_LOAD_A(2 * c + 1, A1)
         WR_LOAD_B(0, xb)
-        if (COT == 1) { WR_WAIT_A(1, A0) } else if (COT == 2) { WR_WAIT_A(2, A0) } else { WR_WAIT_A(3, A0) }
+        WR_WAIT_A(VM_P, A0)
         WR_DO_MFMA(0, xb, A0)
         WR_LOAD_B(1, yb)
         WR_DO_MFMA(1, yb, A0)
@@ -305,12 +337,15 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     // a round ahead and stay in flight across them.
     float* sM = smem;                      // [16 positions][32 couts][32 tiles] = 64 KiB
     const int e_tile = tid & 31, e_col = tid >> 5;
-    const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
+    const int e_ty = G8 ? (e_tile >> 2) & 3 : e_tile >> 3, e_tx = G8 ? e_tile & 3 : e_tile & 7;
+    const int e_b = min(b + (G8 ? e_tile >> 4 : 0), a.B - 1);          // G8: the tile's sample (clamped for the loads)
+    const bool e_valid = !G8 || b + (e_tile >> 4) < a.B;
     const long pix = (long)(oy0 + 2 * e_ty) * W + ox0 + 2 * e_tx;
+    const bool lead = kh == 0;                 // the K-split partner that contributes bias and residual
     f32x2 rn0 = {0.0f, 0.0f}, rn1 = {0.0f, 0.0f};
 #define WR_LOAD_RES(ct)                                                                                         \
-    if (a.res) {                                                                                                \
-        const long o = ((long)b * a.Cout + min(co0 + (ct) * 32 + e_col, a.Cout - 1)) * HW + pix;                \
+    if (a.res && lead) {                                                                                        \
+        const long o = ((long)e_b * a.Cout + min(co0 + (ct) * 32 + e_col, a.Cout - 1)) * HW + pix;              \
         rn0 = *reinterpret_cast<const f32x2*>(a.res + o);                                                       \
         rn1 = *reinterpret_cast<const f32x2*>(a.res + o + W);                                                   \
     }
@@ -340,12 +375,18 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
             }
             float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
             float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
-            const float bvv = a.bias[co];                       // zero-padded to CoutP
-            if (co < a.Cout) {
-                const long o = ((long)b * a.Cout + co) * HW + pix;
-                y00 += bvv + r0.x; y01 += bvv + r0.y; y10 += bvv + r1.x; y11 += bvv + r1.y;
-                *reinterpret_cast<float2*>(a.y + o) = make_float2(y00 * a.out_scale, y01 * a.out_scale);
-                *reinterpret_cast<float2*>(a.y + o + W) = make_float2(y10 * a.out_scale, y11 * a.out_scale);
+            const float bvv = lead ? a.bias[co] : 0.0f;         // zero-padded to CoutP
+            if (co < a.Cout && e_valid) {
+                const long o = ((long)e_b * a.Cout + co) * HW + pix;
+                y00 = (y00 + bvv + r0.x) * a.out_scale; y01 = (y01 + bvv + r0.y) * a.out_scale;
+                y10 = (y10 + bvv + r1.x) * a.out_scale; y11 = (y11 + bvv + r1.y) * a.out_scale;
+                if (ksp == 2) {                                 // add into the zero-filled output (see the kernel's header)
+                    unsafeAtomicAdd(a.y + o, y00); unsafeAtomicAdd(a.y + o + 1, y01);
+                    unsafeAtomicAdd(a.y + o + W, y10); unsafeAtomicAdd(a.y + o + W + 1, y11);
+                } else {
+                    *reinterpret_cast<float2*>(a.y + o) = make_float2(y00, y01);
+                    *reinterpret_cast<float2*>(a.y + o + W) = make_float2(y10, y11);
+                }
             }
         }
         if (ct + 1 < COT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -354,10 +395,10 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     if (rec) {
         const unsigned long long now = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
-            unsigned long long* d = a.dbg + (long)blockIdx.x * 8;
+            unsigned long long* d = a.dbg + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
             d[0] = dt[0]; d[1] = dt[1]; d[2] = 0; d[3] = 0; d[4] = 0;      // prologue, K loop
             d[5] = now - tprev;            // epilogue
-            d[6] = (unsigned long long)nchunks;
+            d[6] = (unsigned long long)(c_end - c_begin);
             d[7] = now - tk0;
         }
     }
@@ -372,32 +413,40 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
 #undef WR_DO_MFMA
 }
 
-static size_t wino_lds_bytes(int Cin) {
-    const size_t k = (size_t)(2 * WR_CK * 16 * WR_T + 2 * (WR_CK * 10 * WR_PP + 4) + 2 * Cin) * sizeof(float);
+static size_t wino_lds_bytes(int Cin, bool g8) {
+    const size_t k = (size_t)(2 * WR_CK * 16 * WR_T + 2 * (WR_CK * 10 * WR_PP + 4) + (g8 ? 4 : 2) * Cin) * sizeof(float);
     const size_t epi = (size_t)16 * 32 * WR_T * sizeof(float);        // sM of the epilogue
     return k > epi ? k : epi;
 }
 
-template <int COT, int PRO>
-static int wino_launch2(const ConvArgs& a, hipStream_t s) {
+template <int COT, int PRO, bool G8>
+static int wino_launch3(const ConvArgs& a, hipStream_t s) {
     constexpr int BCO = 32 * COT;
-    const size_t lds = wino_lds_bytes(a.Cin);
+    const size_t lds = wino_lds_bytes(a.Cin, G8);
     static bool raised = false;
     if (!raised) {
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<COT, PRO>),
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<COT, PRO, G8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    const int nreg = a.B * (a.H / 8) * (a.W / 16);
-    dim3 grid(((nreg + 7) / 8) * 8 * (a.CoutP / BCO));
+    const int nreg = G8 ? (a.B + 1) / 2 : a.B * (a.H / 8) * (a.W / 16);
+    const int ksp = a.ksplit == 2 ? 2 : 1;
+    dim3 grid(((nreg + 7) / 8) * 8 * (a.CoutP / BCO), ksp);
     ConvArgs k = a;
     if (k.dbg) {
         const char* w = getenv("MCVD_DBG_WAVE");       // which wave records its phase times (diagnostics)
         k.wdma = w ? atoi(w) : 0;
     }
-    hipLaunchKernelGGL((conv_wino_kernel<COT, PRO>), grid, dim3(WR_NT), lds, s, k);
+    if (ksp == 2)                                      // the two K halves ADD into the output
+        MCVD_HIP_CHECK(hipMemsetAsync(a.y, 0, (size_t)a.B * a.Cout * a.H * a.W * sizeof(float), s));
+    hipLaunchKernelGGL((conv_wino_kernel<COT, PRO, G8>), grid, dim3(WR_NT), lds, s, k);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+template <int COT, int PRO>
+static int wino_launch2(const ConvArgs& a, hipStream_t s) {
+    return (a.H == 8 && a.W == 8) ? wino_launch3<COT, PRO, true>(a, s) : wino_launch3<COT, PRO, false>(a, s);
 }
 
 template <int COT>
@@ -407,7 +456,8 @@ static int wino_launch(const ConvArgs& a, hipStream_t s) {
     return wino_launch2<COT, 2>(a, s);
 }
 
-bool conv_wino_supported(int ks, int H, int W) { return ks == 3 && H % 8 == 0 && W % 16 == 0 && H >= 8 && W >= 16; }
+// Geometry the kernel serves: regions of 8 x 16 output pixels, or whole 8 x 8 images in pairs.
+bool conv_wino_supported(int ks, int H, int W) { return ks == 3 && ((H % 8 == 0 && W % 16 == 0 && H >= 8 && W >= 16) || (H == 8 && W == 8)); }
 
 int conv_wino_cout_tile(int Cout) {
     if (Cout % 96 == 0) return 3;
@@ -415,18 +465,19 @@ int conv_wino_cout_tile(int Cout) {
     return 1;
 }
 
-// Shape id 4 applies to this launch: geometry, channel layout, packed weights present.
+// Shape ids 4 / 8 apply to this launch: geometry, channel layout, packed weights present (8: and an even chunk count).
 bool conv_wino_usable(const ConvArgs& a) {
     return conv_wino_supported(a.ks, a.H, a.W) && a.wpw && a.Cin <= 1024 && a.CinP % WR_CK == 0 &&
            (a.C1 == 0 || a.C0 % WR_CK == 0) &&                                       // a chunk never straddles the concat seam
            (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) &&      // 32-bit byte offsets of the patch loads
-           wino_lds_bytes(a.Cin) <= 160 * 1024;
+           wino_lds_bytes(a.Cin, a.H == 8 && a.W == 8) <= 160 * 1024 &&
+           (a.ksplit != 2 || ((a.CinP / WR_CK) % 2 == 0 && a.CinP / WR_CK >= 4 && a.y != a.res));
 }
 
 // a.wpw must hold the operand-major layout (launch_pack_wino_weight) packed for conv_wino_cout_tile(Cout).
 int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
-    MCVD_REQUIRE(conv_wino_usable(a), "winograd conv: unsupported (ks=%d H=%d W=%d Cin=%d C0=%d, packed weights %s)", a.ks, a.H, a.W,
-                 a.Cin, a.C0, a.wpw ? "present" : "missing");
+    MCVD_REQUIRE(conv_wino_usable(a), "winograd conv: unsupported (ks=%d H=%d W=%d Cin=%d C0=%d ksplit=%d, packed weights %s)", a.ks,
+                 a.H, a.W, a.Cin, a.C0, a.ksplit, a.wpw ? "present" : "missing");
     const int cot = conv_wino_cout_tile(a.Cout);
     MCVD_REQUIRE(a.CoutP % (32 * cot) == 0, "winograd conv: CoutP=%d vs tile %d", a.CoutP, 32 * cot);
     switch (cot) {

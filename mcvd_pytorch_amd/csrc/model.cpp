@@ -691,6 +691,12 @@ int mcvd_model::autotune(int B) {
                 }
             }
             a.cot = op.cot;
+            if (op.ks == 3 && ctx->winograd) {             // 8 = Winograd with a 2-way K split (more workgroups: 8x8 layers)
+                ConvArgs b = a;
+                b.ksplit = 2;
+                if (conv_wino_usable(b))
+                    if (int rc = time_candidate(8, op.cot)) return rc;
+            }
             if (op.ks == 1 && ctx->conv_dma1) {        // 5 / 6 = all-DMA 1x1 GEMM (16 / 32 channels per chunk), cout tiles of its own
                 static const int g1_cots[] = {9, 6, 4, 3, 2, 1};
                 for (int ck = 16; ck <= 32; ck += 16) {

@@ -59,6 +59,11 @@ CONV_CASES = [
     (3, 64, 0, 128, 16, 3, True, 1, True, 4),       # Winograd: 64-channel cout tile
     (2, 96, 0, 5, 64, 3, True, 1, False, 4),        # Winograd: final conv, Cout=5
     (1, 32, 0, 32, 128, 3, True, 1, True, 4),       # Winograd: 128x128
+    (5, 48, 16, 96, 8, 3, True, 1, True, 4),        # Winograd on 8x8 images: two samples per region, B odd, concat
+    (4, 288, 0, 288, 8, 3, True, 1, True, 8),       # ... with the 2-way K split (atomic add into the zeroed output)
+    (3, 96, 0, 96, 8, 3, False, 0, False, 8),
+    (2, 96, 0, 96, 64, 3, True, 1, True, 8),        # K split at 64x64
+    (3, 32, 0, 64, 8, 3, True, 1, False, 8),        # too few chunks to split: runs unsplit
     (2, 96, 0, 192, 32, 1, False, 0, False, -1),    # 1x1 shortcut
     (2, 96, 96, 192, 32, 1, False, 0, False, 0),    # 1x1 shortcut over a concat
     (2, 192, 0, 576, 32, 1, True, 0, False, 1),     # fused q|k|v projection with GN affine prologue (no SiLU)

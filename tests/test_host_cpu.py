@@ -98,7 +98,7 @@ def test_winograd_isa_checker_flags_violations():
     """tools/check_wino_isa.py (run by the build whenever conv_wino.cpp is recompiled): a register written by an in-flight
     asm load must not be touched before a vmcnt wait; spills or foreign VMEM in the K loop are rejected."""
     from tools import check_wino_isa as c
-    head = "_ZN4mcvd16conv_wino_kernelILi1ELi0EEEvNS_8ConvArgsE: ; @x\n"
+    head = "_ZN4mcvd16conv_wino_kernelILi1ELi0ELb0EEEvNS_8ConvArgsE: ; @x\n"
     loop_ok = (".LBB0_1: ; =>This Inner Loop Header: Depth=1\n"
                "\tv_mfma_f32_32x32x2_f32 v[0:15], v20, v21, v[0:15]\n"
                "\ts_waitcnt vmcnt(1)\n"
@@ -109,10 +109,10 @@ def test_winograd_isa_checker_flags_violations():
                "\ts_waitcnt vmcnt(4)\n"
                "\tv_mfma_f32_32x32x2_f32 v[0:15], v24, v21, v[0:15]\n"
                "\ts_cbranch_scc1 .LBB0_1\n.LBB0_2:\n\ts_endpgm\n.Lfunc_end0:\n")
-    others = "".join(f"_ZN4mcvd16conv_wino_kernelILi{a}ELi{b}EEEvNS_8ConvArgsE: ; @x\n" + loop_ok.replace("LBB0", f"LBB{a}{b}")
+    others = "".join(f"_ZN4mcvd16conv_wino_kernelILi{a}ELi{b}ELb0EEEvNS_8ConvArgsE: ; @x\n" + loop_ok.replace("LBB0", f"LBB{a}{b}")
                      for a, b in [(1, 1), (1, 2)])
     def problems(loop):
-        return [p for p in c.check(head + loop + others) if "ILi1ELi0" in p]
+        return [p for p in c.check(head + loop + others) if "ILi1ELi0ELb0" in p]
     assert problems(loop_ok) == []
     bad_copy = loop_ok.replace("\tv_add_u32_e32 v50, v51, v52\n", "\tv_mov_b32_e32 v50, v25\n")
     assert any("touches the destination" in p for p in problems(bad_copy))

@@ -54,7 +54,8 @@ def test_attention_index_maps(B, C, heads, S):
     np.testing.assert_allclose(got, want.numpy(), rtol=1e-8, atol=1e-8)
 
 
-@pytest.mark.parametrize("B,C0,C1,Cout,H,W,COT", [(1, 16, 5, 40, 16, 16, 2), (2, 8, 0, 96, 8, 32, 3), (1, 16, 8, 32, 16, 32, 1), (1, 10, 0, 32, 8, 16, 1), (3, 16, 20, 40, 8, 16, 2)])
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W,COT", [(1, 16, 5, 40, 16, 16, 2), (2, 8, 0, 96, 8, 32, 3), (1, 16, 8, 32, 16, 32, 1), (1, 10, 0, 32, 8, 16, 1), (3, 16, 20, 40, 8, 16, 2),
+                                                    (3, 16, 16, 40, 8, 8, 2), (2, 10, 0, 96, 8, 8, 3)])
 def test_winograd_index_maps(B, C0, C1, Cout, H, W, COT):
     """conv_wino.cpp: patch slots, transform tasks, V layout, operand-major weights, MFMA lane maps, block id -> (region, cout
     tile), the LDS exchange and the 2x2 inverse transform."""

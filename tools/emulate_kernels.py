@@ -262,15 +262,17 @@ def wino_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT
     coef_f = None if coef is None else coef.reshape(-1)
     y = np.full((B, Cout, H, W), np.nan)
     silu = lambda v: v / (1 + np.exp(-v))
-    rx_n, ry_n = W // 16, H // 8
-    nreg, nct, nunits = B * rx_n * ry_n, CoutP // BCO, CinP // 8
+    G8 = H == 8 and W == 8                     # two whole 8x8 images per region, halo = zero padding, only interiors loaded
+    rx_n, ry_n = (1, 1) if G8 else (W // 16, H // 8)
+    nreg, nct, nunits = ((B + 1) // 2 if G8 else B * rx_n * ry_n), CoutP // BCO, CinP // 8
+    PCOUNT = CK * 2 * 64 if G8 else CK * 180
     for bid in range(((nreg + 7) // 8) * 8 * nct):
         xcd, slot = bid & 7, bid >> 3
         reg_id = (slot // nct) * 8 + xcd
         if reg_id >= nreg:
             continue
-        b = reg_id // (rx_n * ry_n)
-        rr = reg_id - b * (rx_n * ry_n)
+        b = 2 * reg_id if G8 else reg_id // (rx_n * ry_n)
+        rr = 0 if G8 else reg_id - b * (rx_n * ry_n)
         oy0, ox0 = (rr // rx_n) * 8, (rr % rx_n) * 16
         cotile = slot - (slot // nct) * nct
         co0 = cotile * BCO
@@ -278,34 +280,45 @@ def wino_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT
         for ch in range(CinP // CK):
             sV = np.full(VSZ, np.nan)
             sP = np.full(PSZ + 4, np.nan)
+            if G8:
+                sP[:] = 0.0                                           # halo zeroed once in the prologue
             for tid in range(NT):
-                for sl in range((CK * 180 + NT - 1) // NT):
+                for sl in range((PCOUNT + NT - 1) // NT):
                     e = sl * NT + tid
-                    if e >= CK * 180:
+                    p_img = 0
+                    if G8:
+                        ci, img, r, cc_ = e >> 7, (e >> 6) & 1, (e >> 3) & 7, e & 7
+                        valid = b + img < B
+                        p_lds = ci * 10 * PP + (r + 1) * PP + img * 10 + cc_ + 1
+                        goff, p_img, p_ci = r * 8 + cc_, (img if valid else 0), ci + (0 if valid else CK)
+                    elif e >= PCOUNT:
                         sP[PSZ] = 0.0
                         continue
-                    ci, rem = e // 180, e % 180
-                    r, cc_ = rem // 18, rem % 18
-                    yy, xx = oy0 - 1 + r, ox0 - 1 + cc_
-                    inside = 0 <= yy < H and 0 <= xx < W
-                    p_ci = ci + (0 if inside else CK)
-                    goff = min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)
+                    else:
+                        ci, rem = e // 180, e % 180
+                        r, cc_ = rem // 18, rem % 18
+                        yy, xx = oy0 - 1 + r, ox0 - 1 + cc_
+                        inside = 0 <= yy < H and 0 <= xx < W
+                        p_ci = ci + (0 if inside else CK)
+                        goff = min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)
+                        p_lds = ci * 10 * PP + r * PP + cc_
                     cb = min(ch * CK, Cin - 1)
                     cmax = Cin - 1 - cb
                     second = cb >= C0
                     srcb = (x1f, (b * C1 + (cb - C0)) * HW) if second else (x0f, (b * C0 + cb) * HW)
+                    istride = (C1 if second else C0) * HW
                     cl = min(p_ci & (CK - 1), cmax)
-                    v = srcb[0][srcb[1] + cl * HW + goff]
+                    v = srcb[0][srcb[1] + cl * HW + goff + p_img * istride]
                     if coef is not None:
                         cch = min(ch * CK + (p_ci & (CK - 1)), Cin - 1)
-                        v = v * coef_f[(b * Cin + cch) * 2] + coef_f[(b * Cin + cch) * 2 + 1]
+                        v = v * coef_f[((b + p_img) * Cin + cch) * 2] + coef_f[((b + p_img) * Cin + cch) * 2 + 1]
                     if act:
                         v = silu(v)
                     nvalid = Cin - ch * CK
-                    sP[ci * 10 * PP + r * PP + cc_] = v if p_ci < min(nvalid, CK) else 0.0
+                    sP[p_lds] = v if p_ci < min(nvalid, CK) else 0.0
             for tid in range(NT):
                 s_ci, s_tile, grp = (tid & 255) >> 5, tid & 31, tid >> 8
-                s_ty, s_tx = s_tile >> 3, s_tile & 7
+                s_ty, s_tx = ((s_tile >> 2) & 3, (s_tile & 3) + 5 * (s_tile >> 4)) if G8 else (s_tile >> 3, s_tile & 7)
                 p_rd = s_ci * 10 * PP + 2 * s_ty * PP + 2 * s_tx
                 p_rdA, p_rdB = p_rd + (0 if grp == 0 else 1) * PP, p_rd + (3 if grp == 3 else 2) * PP
                 v_fa, v_fb = (-1.0 if grp == 2 else 1.0), (1.0 if grp in (1, 2) else -1.0)
@@ -336,21 +349,22 @@ def wino_emulate(x0, x1, up, bias, coef, act, res, scale, Cout, CoutP, CinP, COT
                         sM[(wave * 32 + col) * T + (lane & 31)] = acc[wave, ct, r, lane]
             for tid in range(NT):
                 e_tile, col = tid & 31, tid >> 5
-                e_ty, e_tx = e_tile >> 3, e_tile & 7
+                e_ty, e_tx = ((e_tile >> 2) & 3, e_tile & 3) if G8 else (e_tile >> 3, e_tile & 7)
+                e_b = b + (e_tile >> 4 if G8 else 0)
                 co = co0 + ct * 32 + col
                 mm = np.array([sM[(xi * 32 + col) * T + e_tile] for xi in range(16)])
                 t0 = [mm[0 + l] + mm[4 + l] + mm[8 + l] for l in range(4)]
                 t1 = [mm[4 + l] - mm[8 + l] - mm[12 + l] for l in range(4)]
                 ys = [[t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]], [t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]]]
-                if co < Cout:
+                if co < Cout and e_b < B:
                     for r in range(2):
                         for cc in range(2):
                             yy, xx = oy0 + 2 * e_ty + r, ox0 + 2 * e_tx + cc
                             v = ys[r][cc] + bias[co]
                             if res is not None:
-                                v += res[b, co, yy, xx]
-                            assert np.isnan(y[b, co, yy, xx])
-                            y[b, co, yy, xx] = v * scale
+                                v += res[e_b, co, yy, xx]
+                            assert np.isnan(y[e_b, co, yy, xx])
+                            y[e_b, co, yy, xx] = v * scale
     assert not np.isnan(y).any()
     return y
 
