@@ -20,10 +20,6 @@
 #pragma once
 #include "../common.h"
 
-#ifndef MCVD_CONV_PIPE2
-#define MCVD_CONV_PIPE2 0
-#endif
-
 namespace mcvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -68,15 +64,11 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
     using Cfg = ConvCfg<KS, CK, COT, PXT, SPLIT>;
     constexpr int KK = Cfg::KK, HALO = Cfg::HALO, BCO = Cfg::BCO, MAXA = Cfg::MAXA, MAXW = Cfg::MAXW;
     constexpr bool WDB = WDMA && (Cfg::WDB || WDBF);      // WDBF: double-buffer even a large weight chunk (one block per CU)
-    // PIPE2 (3x3, pixel-split tiles, double-buffered DMA weights): the activation patch is double-buffered too, so the
-    // prologue transform + LDS write of chunk i+1 is interleaved with the MFMAs of chunk i (separate pipes) and each chunk
-    // needs ONE barrier.  The serialised staging phase is 10-13 % of a block's time in isolation, but with two
-    // workgroups per CU the partner block already fills it: measured on MI355X this variant is 0-5 % SLOWER (profiles/
-    // r01_conv_phase_breakdown.txt), so it is compiled out (MCVD_CONV_PIPE2=1 re-enables it).
-    constexpr bool PIPE2 = MCVD_CONV_PIPE2 && (KS == 3) && !SPLIT && WDB;
+    // (A variant that double-buffered the activation patch as well, one barrier per chunk, measured 0-5 % slower with two
+    // workgroups per CU -- profiles/r01_conv_phase_breakdown_pipe2.txt -- and was removed.)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
-    float* sW = smem + (PIPE2 ? 2 : 1) * CK * g.PS;
+    float* sW = smem + CK * g.PS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -127,7 +119,7 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
     }
 
     // zero the activation patch once: halo columns (and unused pad) stay zero for the whole kernel
-    for (int i = tid; i < (PIPE2 ? 2 : 1) * CK * g.PS; i += 256) sA[i] = 0.0f;
+    for (int i = tid; i < CK * g.PS; i += 256) sA[i] = 0.0f;
 
     f32x4 ra[MAXA];      // native vector types: plain load/store, no struct memcpy (keeps them in VGPRs)
     f32x2 rc[MAXA];
@@ -135,61 +127,6 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
 
     // Loads are unconditional (invalid slots read a safe in-bounds address and are discarded at write time) so the
     // staging registers are always defined; plain macros (not lambdas) keep them out of scratch.
-#define MCVD_LOAD_A(ch)                                                                                              \
-    {                                                                                                                \
-        const int cbase = (ch) * CK;                                                                                 \
-        _Pragma("unroll") for (int s = 0; s < MAXA; ++s) {                                                           \
-            const int c = cbase + (a_cb[s] >> 16);                                                                   \
-            const int b = b0 + ((a_cb[s] >> 1) & 0x7fff);                                                            \
-            const bool ok = (a_cb[s] >= 0) && (a_cb[s] & 1) && (c < Cin);                                            \
-            const float* src = a.x0;                                                                                 \
-            const float* csrc = a.coef ? a.coef : a.bias;                                                            \
-            if (ok) {                                                                                                \
-                src = ((c < a.C0) ? a.x0 + ((long)b * a.C0 + c) * HW                                                 \
-                                  : a.x1 + ((long)b * a.C1 + (c - a.C0)) * HW) + a_goff[s];                          \
-                if (a.coef) csrc = a.coef + ((long)b * Cin + c) * 2;                                                 \
-            }                                                                                                        \
-            ra[s] = *reinterpret_cast<const f32x4*>(src);                                                            \
-            rc[s] = *reinterpret_cast<const f32x2*>(csrc);                                                           \
-        }                                                                                                            \
-    }
-#define MCVD_DMA_W(ch)                                                                                               \
-    {                                                                                                                \
-        const float* wsrc = a.wp + (long)(ch) * CK * KK * a.CoutP;                                                   \
-        float* wdst = sW + (((ch) & 1) ? Cfg::WSZ : 0);                                                              \
-        _Pragma("unroll") for (int s = 0; s < MAXW; ++s) {                                                           \
-            if (w_goff[s] >= 0)                                                                                      \
-                __builtin_amdgcn_global_load_lds(                                                                    \
-                    (const __attribute__((address_space(1))) void*)(wsrc + w_goff[s]),                               \
-                    (__attribute__((address_space(3))) void*)(wdst + (s * 256 + wave * 64) * 4), 16, 0, 0);          \
-        }                                                                                                            \
-    }
-// (issuing the DMA pieces one by one between MFMA groups instead of in a burst measured neutral: it costs registers)
-#define MCVD_DMA_W_SLOT(ch, s)                                                                                       \
-    {                                                                                                                \
-        if (w_goff[s] >= 0)                                                                                          \
-            __builtin_amdgcn_global_load_lds(                                                                        \
-                (const __attribute__((address_space(1))) void*)(a.wp + (long)(ch) * CK * KK * a.CoutP + w_goff[s]),  \
-                (__attribute__((address_space(3))) void*)(sW + (((ch) & 1) ? Cfg::WSZ : 0) + (s * 256 + wave * 64) * 4), \
-                16, 0, 0);                                                                                           \
-    }
-#define MCVD_WRITE_A_SLOT(ch, s, dstbase)                                                                            \
-    {                                                                                                                \
-        if (a_cb[s] >= 0) {                                                                                          \
-            f32x4 v = ra[s];                                                                                         \
-            const bool live = (a_cb[s] & 1) && ((ch) * CK + (a_cb[s] >> 16) < Cin);                                  \
-            if (live) {                                                                                              \
-                if (a.coef) {                                                                                        \
-                    v.x = v.x * rc[s].x + rc[s].y; v.y = v.y * rc[s].x + rc[s].y;                                    \
-                    v.z = v.z * rc[s].x + rc[s].y; v.w = v.w * rc[s].x + rc[s].y;                                    \
-                }                                                                                                    \
-                if (a.act) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }           \
-            } else {                                                                                                 \
-                v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                       \
-            }                                                                                                        \
-            *reinterpret_cast<f32x4*>((dstbase) + a_lds[s]) = v;                                                     \
-        }                                                                                                            \
-    }
 #define MCVD_LOAD_CHUNK(ch)                                                                                          \
     {                                                                                                                \
         const int cbase = (ch) * CK;                                                                                 \
@@ -353,47 +290,6 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
     }
 
     const int nchunks = a.CinP / CK;
-    if (PIPE2) {
-        // ---- software pipeline over channel chunks: one barrier per chunk
-        MCVD_LOAD_A(0);
-        MCVD_DMA_W(0);
-        __syncthreads();              // zero fill done (and chunk-0 loads landed)
-#pragma unroll
-        for (int s = 0; s < MAXA; ++s) MCVD_WRITE_A_SLOT(0, s, sA);
-        if (nchunks > 1) MCVD_LOAD_A(1);
-        __syncthreads();
-        MCVD_STAMP(0)
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const bool more = ch + 1 < nchunks;
-            if (more) MCVD_DMA_W(ch + 1);                       // into the weight buffer chunk ch-1 just released
-            const float* sAc = sA + ((ch & 1) ? CK * g.PS : 0);
-            float* sAn = sA + ((ch & 1) ? 0 : CK * g.PS);
-            const float* sWc = sW + ((ch & 1) ? Cfg::WSZ : 0);
-#pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-                const int tapoff = ((tap / 3) - 1) * g.P + ((tap % 3) - 1);
-#pragma unroll
-                for (int kp = 0; kp < CK / 2; ++kp) {
-                    float aw[COT], bx[PXT];
-#pragma unroll
-                    for (int ct = 0; ct < COT; ++ct) aw[ct] = sWc[(2 * kp * KK + tap) * BCO + ct * 32 + woff];
-#pragma unroll
-                    for (int pt = 0; pt < PXT; ++pt) bx[pt] = sAc[2 * kp * g.PS + pixoff[pt] + tapoff];
-#pragma unroll
-                    for (int ct = 0; ct < COT; ++ct)
-#pragma unroll
-                        for (int pt = 0; pt < PXT; ++pt)
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ct], bx[pt], acc[ct][pt], 0, 0, 0);
-                }
-                // staging work for the NEXT chunk rides between the MFMAs of this one (VALU/LDS-write vs matrix pipe)
-                if (more && tap >= 1 && tap <= MAXA) MCVD_WRITE_A_SLOT(ch + 1, tap - 1, sAn);
-                if (tap == MAXA + 1 && ch + 2 < nchunks) MCVD_LOAD_A(ch + 2);
-            }
-            MCVD_STAMP(1)
-            __syncthreads();          // chunk ch consumed by all waves; chunk ch+1 patch visible; its weight DMA landed
-            MCVD_STAMP(2)
-        }
-    } else {
     MCVD_LOAD_CHUNK(0);
     __syncthreads();              // zero fill done
     MCVD_WRITE_CHUNK(0);
@@ -432,7 +328,6 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
             __syncthreads();
             MCVD_STAMP(4)
         }
-    }
     }
     unsigned long long t_loop_end = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -498,6 +393,8 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
         d[5] = t_red_end - t_loop_end; d[6] = te - t_red_end; d[7] = te - tk0;
     }
 #undef MCVD_STAMP
+#undef MCVD_LOAD_CHUNK
+#undef MCVD_WRITE_CHUNK
 }
 
 // Host-side geometry + launch for one instantiation.
@@ -528,8 +425,7 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     MCVD_REQUIRE(a.CinP % CK == 0 && a.CoutP % Cfg::BCO == 0, "conv: packed dims (%d,%d) vs chunk %d tile %d",
                  a.CinP, a.CoutP, CK, Cfg::BCO);
     constexpr bool WDB = WDMA && (Cfg::WDB || WDBF);
-    constexpr bool PIPE2 = MCVD_CONV_PIPE2 && (KS == 3) && !SPLIT && WDB;
-    size_t lds = (size_t)((PIPE2 ? 2 : 1) * CK * g.PS + (WDB ? 2 : 1) * Cfg::WSZ) * sizeof(float);
+    size_t lds = (size_t)(CK * g.PS + (WDB ? 2 : 1) * Cfg::WSZ) * sizeof(float);
     if (SPLIT && lds < 3 * 1024 * sizeof(float)) lds = 3 * 1024 * sizeof(float);
     MCVD_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu > 160KiB", lds);
     if (lds > 64 * 1024) {      // above the default dynamic-LDS limit: opt in once per instantiation
