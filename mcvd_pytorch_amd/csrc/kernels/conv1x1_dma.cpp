@@ -24,7 +24,8 @@ constexpr int G1_MAXIMG = 4;     // images a pixel tile may span (HW >= 32)
 
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU;  CK: input channels per chunk (16 or 32)
 template <int COT, int PRO, int CK>
-__global__ __launch_bounds__(256) void conv1x1_dma_kernel(ConvArgs a, int ptiles, int nct) {
+// second launch bound: 4 waves/SIMD (128 registers) up to cout tile 3, where accumulators + staging fit without spills
+__global__ __launch_bounds__(256, COT <= 3 ? 4 : 1) void conv1x1_dma_kernel(ConvArgs a, int ptiles, int nct) {
     constexpr int PT = G1_PT, BCO = 32 * COT;
     constexpr int WSZ = CK * BCO, XSZ = CK * PT;
     constexpr int WPIECES = WSZ / 4, XPIECES = XSZ / 4;          // 16-byte pieces per chunk
