@@ -169,6 +169,7 @@ void mcvd_model_destroy(mcvd_model* m) {
     if (m->arena) (void)hipFree(m->arena);
     if (m->labels) (void)hipFree(m->labels);
     if (m->eps_buf) (void)hipFree(m->eps_buf);
+    if (m->ksplit_buf) (void)hipFree(m->ksplit_buf);
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     delete m;
 }
@@ -535,11 +536,13 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     const size_t wfloats = (size_t)a.CinP * ks * ks * a.CoutP;
     const bool wino = (ctx->conv_shape == 4 || ctx->conv_shape == 8) && conv_wino_supported(ks, H, W);
     const size_t ufloats = wino ? (size_t)a.CinP * 16 * a.CoutP : 0;
-    if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats) * sizeof(float))) return rc;
+    const size_t pfloats = (wino && ctx->conv_shape == 8) ? (size_t)2 * B * Cout * H * W : 0;     // K-split partial results
+    if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats + pfloats) * sizeof(float))) return rc;
     MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP + ufloats) * sizeof(float), ctx->stream));
     if (wino) {
         if (int rc = launch_pack_wino_weight(w, ctx->scratch + wfloats + a.CoutP, Cout, a.Cin, a.CinP, a.CoutP, ctx->stream)) return rc;
         a.wpw = ctx->scratch + wfloats + a.CoutP;
+        if (pfloats) a.part = ctx->scratch + wfloats + a.CoutP + ufloats;
     }
     if (int rc = launch_pack_conv_weight(w, ctx->scratch, Cout, a.Cin, ks, a.CinP, a.CoutP, 0, 0, ctx->stream)) return rc;
     MCVD_HIP_CHECK(hipMemcpyAsync(ctx->scratch + wfloats, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));

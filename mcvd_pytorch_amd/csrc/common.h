@@ -48,8 +48,9 @@ struct ConvArgs {
     int ks;               // 1 or 3
     int cot;              // cout tile in units of 32 channels (1..4); CoutP % (32*cot) == 0
     int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile, 3 split-K+WDB, 4 Winograd (8: with a 2-way K split), 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels per chunk)
-    int ksplit;           // Winograd kernel only: 2 = two workgroups per tile contract half the input channels each and add
-                          // into the (zero-filled) output; 0/1 = off
+    int ksplit;           // Winograd kernel only: 2 = two workgroups per tile contract half the input channels each into
+                          // `part`, a second pass sums the halves; 0/1 = off
+    float* part;          // ksplit == 2: scratch for the two partial results, 2 * B*Cout*H*W floats
     int wdma;             // 1: stage weight chunks by LDS-DMA (default), 0: through registers
     unsigned long long* dbg;   // optional: per-block phase cycle counters [n_blocks][8] (diagnostics), else null
 };

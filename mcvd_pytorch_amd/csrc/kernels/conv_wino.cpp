@@ -56,9 +56,11 @@ constexpr int WR_PP = 24;
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU.
 // G8: 8x8 images -- the 32 tiles of a workgroup are TWO whole images (16 tiles each); every halo element is zero padding, so
 //     only the 2 x 64 interior pixels per channel are loaded (2 per thread and chunk) and the halo is zeroed once.
-// a.ksplit == 2 (grid.y = 2): the workgroup contracts one half of the input channels and ADDS its result into a zero-filled
-//     output with a hardware fp32 atomic (0 + p0 + p1 in either order is the same float: deterministic); used where the
-//     (region, cout tile) count alone cannot fill the 256 CUs (8x8 layers).
+// a.ksplit == 2 (grid.y = 2): the workgroup contracts one half of the input channels and stores its raw partial result to
+//     a.part[half]; wino_ksplit_reduce_kernel then forms y = s * (p0 + p1 + bias + res) in that fixed order (deterministic).
+//     Used where the (region, cout tile) count alone cannot fill the 256 CUs (8x8 and some 16x16 layers).  An earlier
+//     version added the halves into a zero-filled output with fp32 atomics: the memset + 3 M scalar atomics per launch cost
+//     what the split gained.
 template <int COT, int PRO, bool G8>
 __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     constexpr int NT = WR_NT, CK = WR_CK, T = WR_T, BCO = 32 * COT;
@@ -341,10 +343,11 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     const int e_b = min(b + (G8 ? e_tile >> 4 : 0), a.B - 1);          // G8: the tile's sample (clamped for the loads)
     const bool e_valid = !G8 || b + (e_tile >> 4) < a.B;
     const long pix = (long)(oy0 + 2 * e_ty) * W + ox0 + 2 * e_tx;
-    const bool lead = kh == 0;                 // the K-split partner that contributes bias and residual
+    const bool fin = ksp == 1;                 // K split: bias, residual and scale are applied by the reduce kernel
+    float* const ydst = fin ? a.y : a.part + (long)kh * a.B * a.Cout * HW;
     f32x2 rn0 = {0.0f, 0.0f}, rn1 = {0.0f, 0.0f};
 #define WR_LOAD_RES(ct)                                                                                         \
-    if (a.res && lead) {                                                                                        \
+    if (a.res && fin) {                                                                                        \
         const long o = ((long)e_b * a.Cout + min(co0 + (ct) * 32 + e_col, a.Cout - 1)) * HW + pix;              \
         rn0 = *reinterpret_cast<const f32x2*>(a.res + o);                                                       \
         rn1 = *reinterpret_cast<const f32x2*>(a.res + o + W);                                                   \
@@ -375,18 +378,12 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
             }
             float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
             float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
-            const float bvv = lead ? a.bias[co] : 0.0f;         // zero-padded to CoutP
+            const float bvv = fin ? a.bias[co] : 0.0f;          // zero-padded to CoutP
+            const float osc = fin ? a.out_scale : 1.0f;
             if (co < a.Cout && e_valid) {
                 const long o = ((long)e_b * a.Cout + co) * HW + pix;
-                y00 = (y00 + bvv + r0.x) * a.out_scale; y01 = (y01 + bvv + r0.y) * a.out_scale;
-                y10 = (y10 + bvv + r1.x) * a.out_scale; y11 = (y11 + bvv + r1.y) * a.out_scale;
-                if (ksp == 2) {                                 // add into the zero-filled output (see the kernel's header)
-                    unsafeAtomicAdd(a.y + o, y00); unsafeAtomicAdd(a.y + o + 1, y01);
-                    unsafeAtomicAdd(a.y + o + W, y10); unsafeAtomicAdd(a.y + o + W + 1, y11);
-                } else {
-                    *reinterpret_cast<float2*>(a.y + o) = make_float2(y00, y01);
-                    *reinterpret_cast<float2*>(a.y + o + W) = make_float2(y10, y11);
-                }
+                *reinterpret_cast<float2*>(ydst + o) = make_float2((y00 + bvv + r0.x) * osc, (y01 + bvv + r0.y) * osc);
+                *reinterpret_cast<float2*>(ydst + o + W) = make_float2((y10 + bvv + r1.x) * osc, (y11 + bvv + r1.y) * osc);
             }
         }
         if (ct + 1 < COT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -413,6 +410,19 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
 #undef WR_DO_MFMA
 }
 
+// y = s * (p0 + p1 + bias[c] + res): the second pass of the 2-way K split, 4 pixels per thread
+__global__ __launch_bounds__(256) void wino_ksplit_reduce_kernel(const float* part, const float* bias, const float* res, float scale,
+                                                                 float* y, long n4, long half_stride, int Cout, int HW4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 p0 = reinterpret_cast<const f32x4*>(part)[i];
+        const f32x4 p1 = reinterpret_cast<const f32x4*>(part + half_stride)[i];
+        const float bv = bias[(i / HW4) % Cout];
+        f32x4 v = p0 + p1 + bv;
+        if (res) v = v + reinterpret_cast<const f32x4*>(res)[i];
+        reinterpret_cast<f32x4*>(y)[i] = v * scale;
+    }
+}
+
 static size_t wino_lds_bytes(int Cin, bool g8) {
     const size_t k = (size_t)(2 * WR_CK * 16 * WR_T + 2 * (WR_CK * 10 * WR_PP + 4) + (g8 ? 4 : 2) * Cin) * sizeof(float);
     const size_t epi = (size_t)16 * 32 * WR_T * sizeof(float);        // sM of the epilogue
@@ -437,10 +447,15 @@ static int wino_launch3(const ConvArgs& a, hipStream_t s) {
         const char* w = getenv("MCVD_DBG_WAVE");       // which wave records its phase times (diagnostics)
         k.wdma = w ? atoi(w) : 0;
     }
-    if (ksp == 2)                                      // the two K halves ADD into the output
-        MCVD_HIP_CHECK(hipMemsetAsync(a.y, 0, (size_t)a.B * a.Cout * a.H * a.W * sizeof(float), s));
     hipLaunchKernelGGL((conv_wino_kernel<COT, PRO, G8>), grid, dim3(WR_NT), lds, s, k);
     MCVD_HIP_CHECK(hipGetLastError());
+    if (ksp == 2) {                                    // second pass: p0 + p1 + bias + res, scaled
+        const long n = (long)a.B * a.Cout * a.H * a.W, n4 = n / 4;
+        const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+        hipLaunchKernelGGL(wino_ksplit_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale, a.y, n4, n,
+                           a.Cout, a.H * a.W / 4);
+        MCVD_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -471,7 +486,7 @@ bool conv_wino_usable(const ConvArgs& a) {
            (a.C1 == 0 || a.C0 % WR_CK == 0) &&                                       // a chunk never straddles the concat seam
            (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) &&      // 32-bit byte offsets of the patch loads
            wino_lds_bytes(a.Cin, a.H == 8 && a.W == 8) <= 160 * 1024 &&
-           (a.ksplit != 2 || ((a.CinP / WR_CK) % 2 == 0 && a.CinP / WR_CK >= 4 && a.y != a.res));
+           (a.ksplit != 2 || ((a.CinP / WR_CK) % 2 == 0 && a.CinP / WR_CK >= 4 && a.part != nullptr));
 }
 
 // a.wpw must hold the operand-major layout (launch_pack_wino_weight) packed for conv_wino_cout_tile(Cout).

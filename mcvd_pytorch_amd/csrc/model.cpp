@@ -506,11 +506,17 @@ int mcvd_model::ensure_workspace(int B) {
     if (arena) MCVD_HIP_CHECK(hipFree(arena));
     if (labels) MCVD_HIP_CHECK(hipFree(labels));
     if (eps_buf) MCVD_HIP_CHECK(hipFree(eps_buf));
-    arena = nullptr; labels = nullptr; eps_buf = nullptr; arena_B = 0;
+    if (ksplit_buf) MCVD_HIP_CHECK(hipFree(ksplit_buf));
+    arena = nullptr; labels = nullptr; eps_buf = nullptr; ksplit_buf = nullptr; arena_B = 0;
     const size_t per = (size_t)d.channels * d.num_frames * d.image_size * d.image_size;
     MCVD_HIP_CHECK(hipMalloc((void**)&arena, (size_t)arena_per_sample * B * sizeof(float)));
     MCVD_HIP_CHECK(hipMalloc((void**)&labels, (size_t)B * sizeof(int64_t)));
     MCVD_HIP_CHECK(hipMalloc((void**)&eps_buf, per * B * sizeof(float)));
+    size_t kfl = 0;                               // K-split Winograd candidates: 3x3 layers at 8x8 / 16x16
+    for (const Op& op : ops)
+        if (op.kind == OP_CONV && op.ks == 3 && op.wpw >= 0 && op.H * op.W <= 256)
+            kfl = std::max(kfl, (size_t)2 * B * op.Cout * op.H * op.W);
+    if (kfl) MCVD_HIP_CHECK(hipMalloc((void**)&ksplit_buf, kfl * sizeof(float)));
     arena_B = B;
     cond_cache_valid = false;
     tuned_B = 0;
@@ -588,6 +594,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.cot = op.cot;
             a.shape_hint = ctx->conv_shape;
             a.wdma = ctx->conv_wdma;
+            a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
             const size_t oi = (size_t)(&op - ops.data());
             if (ctx->conv_shape < 0 && tuned_B == B && oi < tuned_shape.size() && tuned_shape[oi] >= 0) {
                 a.shape_hint = tuned_shape[oi];
@@ -663,6 +670,7 @@ int mcvd_model::autotune(int B) {
             a.y = resolve(op.dst, scratch_io, scratch_io, scratch_io, B);
             a.B = B; a.Cin = cin; a.CinP = op.CinP; a.Cout = op.Cout; a.CoutP = op.CoutP; a.H = op.H; a.W = op.W; a.ks = op.ks;
             a.wdma = ctx->conv_wdma;
+            a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
             float best_ms = 1e30f;
             std::pair<int, int> choice{-1, op.cot};
             auto time_candidate = [&](int shape, int cot) -> int {

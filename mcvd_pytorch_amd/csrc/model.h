@@ -121,6 +121,7 @@ struct mcvd_model {
     int arena_B = 0;
     int64_t* labels = nullptr;        // [arena_B] (sampler-owned labels)
     float* eps_buf = nullptr;         // [arena_B * C*nf*S*S] (sampler-owned eps)
+    float* ksplit_buf = nullptr;      // two partial outputs of the K-split Winograd layers (H*W <= 256), sized for arena_B
 
     std::vector<float> betas, alphas, alphas_prev, freqs;
 
