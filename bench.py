@@ -187,14 +187,14 @@ def main():
                          tflops=round(a["flops"] / a["ms"] / 1e9, 2), gbs=round(a["bytes"] / a["ms"] / 1e6, 1))
                  for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     # ---- dominant kernel: the 3x3 convs.  Which implementation each layer runs is the autotuner's choice (op_info):
-    # shape 4 = Winograd F(2x2,3x3) (conv_wino_kernel), else the direct implicit GEMM (conv_mfma_kernel).
+    # shape 4 / 8 = Winograd F(2x2,3x3) (conv_wino_kernel; 8: + its K-split reduce pass), else the direct implicit GEMM.
     info = (C.c_int * 8)()
     wino = dict(launches=0, ms=0.0, flops=0.0, bytes=0.0)
     for i in range(n):
         if kinds[i] != 3 or kss[i] != 3 or ms[i] == 0.0:
             continue
         _lib.check(_lib.lib.mcvd_model_op_info(net._model, i, info), "op_info")
-        if (info[6] >> 12) and ((info[6] >> 4) & 15) == 4:
+        if (info[6] >> 12) and ((info[6] >> 4) & 15) in (4, 8):         # 8 = the same kernel with the 2-way K split
             wino["launches"] += 1; wino["ms"] += ms[i]; wino["flops"] += fl[i]; wino["bytes"] += by[i]
     c3 = agg["conv3x3"]
     dom, dom_name = c3, "conv_mfma_kernel<3x3> (direct implicit GEMM, v_mfma_f32_32x32x2_f32)"
