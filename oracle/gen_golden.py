@@ -14,6 +14,7 @@ What is pinned:
   * ddpm_sampler / ddim_sampler end-to-end with an injected noise sequence  (models/__init__.py:102-340)
   * upfirdn2d_native for the two FIR uses + a generic case                  (op/upfirdn2d.py:163-204)
   * FPNDM_sampler end-to-end, every step (deterministic, no noise)          (models/__init__.py:38-99, models/pndm.py)
+  * one forward at BASELINE configs 3-5 (probes of eps and of every module)  (ncsnpp_more.py:251-392, layerspp.py:101-173)
 """
 import os
 import sys
@@ -114,6 +115,27 @@ def gen_model_case(name, batch, steps_kinds):
     print(f"wrote {name}_b{batch}.pt  eps std {eps.std():.4f}")
 
 
+def gen_forward_only(name, batch):
+    """One forward of the REAL reference at a full-width BASELINE config (ngf=128 / SPADE / 128x128 five-level): the final
+    eps as a strided probe + moments, and a probe of every module output.  Small file, pins the oracle at those widths."""
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    check_names(net, config)
+    net.load_state_dict(synth.make_state_dict(config, seed=123), strict=False)
+    x, cond = synth.make_inputs(config, batch, seed=0)
+    taps, hooks = {}, []
+    for i, m in enumerate(net.unet.all_modules):
+        hooks.append(m.register_forward_hook(lambda mod, inp, o, i=i: taps.__setitem__(i, probe(o, 41))))
+    t = torch.tensor([(311 * (b + 1)) % 1000 for b in range(batch)]).long()
+    with torch.no_grad():
+        eps = net(x, t, cond=cond)
+    for h in hooks:
+        h.remove()
+    torch.save(dict(config_name=name, batch=batch, fwd_t=t, fwd_eps_probe=probe(eps, 4001), fwd_taps=taps),
+               os.path.join(OUT, f"{name}_b{batch}_fwd.pt"))
+    print(f"wrote {name}_b{batch}_fwd.pt  eps std {eps.std():.4f}")
+
+
 def gen_fpndm(name="tiny", batch=3, subsample=10):
     """FPNDM_sampler of the real reference (models/__init__.py:38-99) on the synthetic tiny model: every step's x."""
     sys.path.insert(0, REF)
@@ -158,6 +180,8 @@ def main():
     gen_model_case("tiny_spade", 2, [("ddpm", 10, {})])
     gen_model_case("smmnist_big5", 2, [("ddpm", 100, {})])          # BASELINE config 1 (plumbing, CPU)
     gen_fpndm()
+    for name, batch in (("kth64_big_ngf128", 2), ("bair_big_spade", 2), ("cityscapes_big", 1)):     # BASELINE configs 3-5
+        gen_forward_only(name, batch)
 
 
 if __name__ == "__main__":

@@ -370,8 +370,9 @@ def test_spade_cache_follows_cond_content():
 
 
 @pytest.mark.parametrize("name,B", [("kth64_big_ngf128", 2), ("bair_big_spade", 2), ("cityscapes_big", 1)])
-def test_other_baseline_configs_forward(name, B):
-    """BASELINE configs 3-5 (ngf=128 / SPADE at full width / 128x128 five-level): one forward vs the CPU oracle."""
+def test_other_baseline_configs_forward(name, B, golden_dir):
+    """BASELINE configs 3-5 (ngf=128 / SPADE at full width / 128x128 five-level): one forward vs the CPU oracle and vs the REAL
+    reference's output on the same inputs (strided probe fixture, oracle/gen_golden.py:gen_forward_only)."""
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     config, sd, net = _net(name)
     x, cond = synth.make_inputs(config, B, seed=0)
@@ -381,6 +382,11 @@ def test_other_baseline_configs_forward(name, B):
         ref = unet_ref.unet_forward(sd, config, x, t, cond)
     err = (eps - ref).abs().max().item()
     assert err <= 1e-4 * ref.abs().max().item(), f"{name}: {err:.3e} vs scale {ref.abs().max().item():.3e}"
+    g = torch.load(os.path.join(golden_dir, f"{name}_b{B}_fwd.pt"), weights_only=False)
+    assert torch.equal(g["fwd_t"], t)
+    p = g["fwd_eps_probe"]
+    got = eps.reshape(-1).double()[p["idx"]].float()
+    assert (got - p["sample"]).abs().max().item() <= 1e-4 * p["sample"].abs().max().item()
 
 
 def test_video_gen_autoregressive_and_checkpoint_format(tmp_path):

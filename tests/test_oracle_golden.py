@@ -76,6 +76,28 @@ def test_sampler_matches_reference(golden_dir, fx, key, kind, sub, extra):
     assert (out - ref).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("fx", ["kth64_big_ngf128_b2_fwd.pt", "bair_big_spade_b2_fwd.pt", "cityscapes_big_b1_fwd.pt"])
+def test_forward_matches_reference_full_width(golden_dir, fx):
+    """BASELINE configs 3-5 (ngf=128 / SPADE at full width / 128x128 five-level): the oracle vs the REAL reference's forward,
+    module by module (strided probes) and on the final eps."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    g = load(golden_dir, fx)
+    config = synth.make_config(g["config_name"])
+    sd = synth.make_state_dict(config, seed=123)
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    taps = {}
+    with torch.no_grad():
+        eps = unet_ref.unet_forward(sd, config, x, g["fwd_t"], cond, taps=taps)
+    for i, p in g["fwd_taps"].items():
+        if i == 0 or i not in taps:
+            continue
+        got = taps[i].reshape(-1).double()[p["idx"]].float()
+        torch.testing.assert_close(got, p["sample"], rtol=1e-4, atol=3e-5, msg=f"module {i}")
+    p = g["fwd_eps_probe"]
+    assert list(eps.shape) == p["shape"]
+    torch.testing.assert_close(eps.reshape(-1).double()[p["idx"]].float(), p["sample"], rtol=1e-4, atol=3e-5)
+
+
 def test_fpndm_matches_reference(golden_dir):
     """FPNDM_sampler (models/__init__.py:38-99 + models/pndm.py): every step of the clipped run, and the un-clipped final state
     (which grows to |x| ~ 360 on random weights: relative tolerance)."""
