@@ -118,3 +118,24 @@ def test_winograd_isa_checker_flags_violations():
     assert any("touches the destination" in p for p in problems(bad_copy))
     bad_spill = loop_ok.replace("\tv_add_u32_e32 v50, v51, v52\n", "\tscratch_store_dword off, v50, off\n")
     assert any("spill" in p for p in problems(bad_spill))
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under mcvd_pytorch_amd/ (Python or native sources) may import, open or link it,
+    and outside the package only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do."""
+    import re
+    pkg = os.path.join(ROOT, "mcvd_pytorch_amd")
+    offenders = []
+    for d, _, files in os.walk(pkg):
+        if os.sep + "build" in d or "__pycache__" in d:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                if re.search(r"\boracle\b", txt):
+                    offenders.append(os.path.relpath(os.path.join(d, f), ROOT))
+    assert not offenders, offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle|import oracle", bench)]
+    assert uses and all(bench.rfind("def ", 0, u) == bench.rfind("def cpu_baseline", 0, u) for u in uses), \
+        "bench.py may use the oracle only inside cpu_baseline()"
