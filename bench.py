@@ -1,21 +1,25 @@
 #!/usr/bin/env python
 """Headline benchmark: sampled frames/s (whole job) of the DDPM sampling hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config NAME]
 
-A "step" is ONE full sampler call over one batch: `ddpm_sampler` with subsample=100 (100 UNet forwards + fused updates
-+ the denoise forward = 101 forwards) on BASELINE.json configs[1]: smmnist_DDPM_big5 with ngf=96, 64x64, 5 cond + 5
-predicted frames, batch 64 per GPU, synthetic random weights / inputs, on-device Philox noise.  Frames = B * 5 per
-step per GPU; `value` = frames of all ranks / max-over-ranks wall time (weak scaling: per-GPU batch fixed).
-Inputs are resident in HBM before the timed region.  One JSON line on stdout (rank 0).
+A "step" is ONE full sampling job over one batch per GPU.  Default workload = BASELINE.json configs[1]: `ddpm_sampler` with
+subsample=100 (100 UNet forwards + fused updates + the denoise forward = 101 forwards) on smmnist_DDPM_big5 with ngf=96, 64x64,
+5 cond + 5 predicted frames, batch 64 per GPU, synthetic random weights / inputs, on-device Philox noise.  Frames = B * 5 per
+step per GPU.  For the autoregressive config (`--config cityscapes_big`: num_frames_pred=28 > num_frames=5) a step is the whole
+`video_gen` block loop (6 sampler calls, cond shift on the device) and frames = B * 28 KEPT frames.
+`value` = frames of all ranks / max-over-ranks wall time (weak scaling: per-GPU batch fixed).  Inputs are resident in HBM before
+the timed region.  One JSON line on stdout (rank 0).
+
+`--gpus N` with N > 1 and no launcher (WORLD_SIZE unset) re-executes itself under `python -m torch.distributed.run` with one
+rank per GPU (RCCL); under the driver's own torchrun launch it just reads RANK / LOCAL_RANK / WORLD_SIZE.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -24,9 +28,35 @@ if ROOT not in sys.path:
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
 
+# per-config defaults: (per-GPU batch, subsample, metric label) -- BASELINE.json configs[1..4] at their per-GPU batch
+DEFAULTS = {
+    "smmnist_big5_ngf96": (64, 100, "SMMNIST 64x64 DDPM 100-step"),
+    "smmnist_big5": (64, 100, "SMMNIST 64x64 (ngf=64) DDPM 100-step"),
+    "kth64_big_ngf128": (32, 100, "KTH 64x64 (ngf=128) DDPM 100-step"),
+    "bair_big_spade": (16, 1000, "BAIR 64x64 SPADE DDPM 1000-step"),
+    "cityscapes_big": (8, 100, "Cityscapes 128x128 autoregressive 28 frames, DDPM 100-step per block"),
+    "cityscapes_big_variant": (8, 100, "Cityscapes 128x128 ch_mult=[1,2,3,4,4] attn@16, autoregressive 28 frames"),
+}
+
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def plan_launch(gpus, env, argv=None):
+    """None: run in this process (N == 1, or already one rank of a launcher).  Otherwise the command that starts `gpus` ranks of
+    this script on this node, one per GPU, over RCCL.  A launcher whose WORLD_SIZE disagrees with --gpus is refused (a run that
+    silently benchmarks another N reads as 'no scaling')."""
+    world = env.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but the launcher set WORLD_SIZE={world}; refusing to run an ambiguous job")
+        return None
+    if gpus <= 1:
+        return None
+    port = env.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", port, os.path.join(ROOT, "bench.py")] + list(argv if argv is not None else sys.argv[1:])
 
 
 def make_config(name):
@@ -36,6 +66,7 @@ def make_config(name):
     model = dict(version="DDPM", arch="unetmore", type="v1", time_conditional=True, dropout=0.1, sigma_dist="linear",
                  sigma_begin=0.02, sigma_end=0.0001, num_classes=1000, ngf=96, ch_mult=[1, 2, 3, 4], num_res_blocks=2,
                  attn_resolutions=[8, 16, 32], n_head_channels=96, spade=False, spade_dim=128)
+    sampling = dict(subsample=100, denoise=True, clip_before=True, num_frames_pred=5, init_prev_t=-1.0)
     if name == "smmnist_big5_ngf96":
         pass
     elif name == "smmnist_big5":
@@ -49,35 +80,53 @@ def make_config(name):
     elif name == "cityscapes_big":
         data.update(image_size=128, channels=3, num_frames_cond=2)
         model.update(ngf=128, n_head_channels=128, ch_mult=[1, 1, 2, 3, 4])
+        sampling.update(num_frames_pred=28)
+    elif name == "cityscapes_big_variant":
+        data.update(image_size=128, channels=3, num_frames_cond=2)
+        model.update(ngf=128, n_head_channels=128, ch_mult=[1, 2, 3, 4, 4], attn_resolutions=[16])
+        sampling.update(num_frames_pred=28)
     else:
         raise KeyError(name)
-    return dict2namespace(dict(data=data, model=model, sampling=dict(subsample=100, denoise=True, clip_before=True)))
+    return dict2namespace(dict(data=data, model=model, sampling=sampling))
 
 
-def cpu_baseline(config, state_dict, subsample, budget_s=20.0):
-    """The CPU port of the reference sampler (oracle/, torch CPU fp32, all host cores) timed on a bounded sample of the
-    same workload: B=4, as many sampler steps as fit the budget (each step = one identical UNet forward + update),
-    extrapolated linearly to the 101 forwards of a full call.  kind="port": the Python reference cannot travel."""
+def cpu_baseline(config, state_dict, subsample, budget_s=24.0, kept_fraction=1.0):
+    """The CPU port of the reference sampler (oracle/, torch CPU fp32) timed on the GPU box's host cores on a bounded sample of
+    the same workload: B=8 rows of the same synthetic inputs.  First a thread-count sweep (1 warm-up + 2 timed forwards at 16 /
+    32 / 64 / 128 threads, capped at the box's count), then the sampler itself at the best count for the rest of the budget (each
+    step = one UNet forward + update), extrapolated linearly to the subsample + 1 forwards of a full call.
+    kind="port": the Python reference cannot travel to the GPU box."""
+    import torch
     from oracle import sampler_ref, unet_ref
     from mcvd_pytorch_amd import synthetic
-    # oneDNN/MKL stop scaling (and collapse through oversubscription) far below the 256 hardware threads of the GPU
-    # box: 16 threads is what the survey container's 8-thread figure extrapolates to sensibly; `cores` reports it.
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    B = 4
+    ncpu = os.cpu_count() or 1
+    B = 8
     net = unet_ref.OracleScoreNet(config, {k: v.float().cpu() for k, v in state_dict.items()})
     x, cond = synthetic.random_inputs(config, 0, B)
     t = torch.full((B,), 500).long()
-    with torch.no_grad():
-        net(x, t, cond=cond)                                    # warm-up
+    sweep = {}
+    t_begin = time.perf_counter()
+    for th in [c for c in (16, 32, 64, 128) if c <= ncpu] or [ncpu]:
+        torch.set_num_threads(th)
+        with torch.no_grad():
+            net(x, t, cond=cond)                                    # warm-up at this thread count
+            t0 = time.perf_counter()
+            for _ in range(2):
+                net(x, t, cond=cond)
+        sweep[th] = (time.perf_counter() - t0) / 2
+        if time.perf_counter() - t_begin > 0.6 * budget_s:
+            break
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
     n_steps, t0 = 0, time.perf_counter()
+    remaining = max(budget_s - (t0 - t_begin), 3.0)
 
     class Stop(Exception):
         pass
 
     def counting(xx, yy, cond=None):
         nonlocal n_steps
-        if time.perf_counter() - t0 > budget_s and n_steps >= 3:
+        if time.perf_counter() - t0 > remaining and n_steps >= 3:
             raise Stop()
         n_steps += 1
         return net(xx, yy, cond=cond)
@@ -88,10 +137,11 @@ def cpu_baseline(config, state_dict, subsample, budget_s=20.0):
         pass
     dt = time.perf_counter() - t0
     per_fwd = dt / max(n_steps, 1)
-    fps = B * config.data.num_frames / (per_fwd * (subsample + 1))
-    return dict(value=round(fps, 4), unit="frames/s", cores=cores, kind="port",
-                sample=f"oracle ddpm_sampler, B={B}, {n_steps} of {subsample + 1} forwards timed ({dt:.1f}s), "
-                       f"extrapolated linearly; torch {torch.__version__} CPU, {cores} threads")
+    fps = kept_fraction * B * config.data.num_frames / (per_fwd * (subsample + 1))      # autoregressive: kept / generated frames
+    return dict(value=round(fps, 4), unit="frames/s", cores=cores, kind="port", host_threads_available=ncpu,
+                thread_sweep_s_per_forward={str(k): round(v, 4) for k, v in sweep.items()},
+                sample=f"oracle ddpm_sampler, B={B}, {n_steps} of {subsample + 1} forwards timed ({dt:.1f}s) at the best of the "
+                       f"swept thread counts ({cores} of {ncpu} hardware threads), extrapolated linearly; torch {torch.__version__} CPU")
 
 
 def main():
@@ -99,17 +149,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="smmnist_big5_ngf96")
-    ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
-    ap.add_argument("--subsample", type=int, default=100)
+    ap.add_argument("--config", default="smmnist_big5_ngf96", choices=sorted(DEFAULTS))
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the config's per-GPU batch)")
+    ap.add_argument("--subsample", type=int, default=None)
+    ap.add_argument("--frames-pred", type=int, default=None, help="autoregressive configs: frames to keep (default 28)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("MCVD_GRAPH", "1")), help="hipGraph replay of the forwards")
+    ap.add_argument("--tune-cache", default=None, help="JSON file: load the kernel-selection table if it exists, else save it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    cmd = plan_launch(args.gpus, os.environ)
+    if cmd is not None:                                       # self-launch: N ranks, one per GPU; rank 0 prints the line
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     import torch.distributed as dist
     backend = os.environ.get("MCVD_DIST_BACKEND", "nccl")     # "gloo": N>1 plumbing check on a box with fewer GPUs than ranks
     local = local % max(torch.cuda.device_count(), 1)
@@ -121,10 +179,19 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    from mcvd_pytorch_amd import HipScoreNet, ddpm_sampler, synthetic
+    from mcvd_pytorch_amd import HipScoreNet, ddpm_sampler, synthetic, video_gen
     from mcvd_pytorch_amd.dist import broadcast_weights, gather_rows, shard_rows
 
+    dB, dS, label = DEFAULTS[args.config]
+    B = args.batch or dB
+    subsample = args.subsample or dS
     config = make_config(args.config)
+    config.sampling.subsample = subsample
+    if args.frames_pred:
+        config.sampling.num_frames_pred = args.frames_pred
+    nfr, nfp = config.data.num_frames, config.sampling.num_frames_pred
+    autoreg = nfp > nfr
+    n_blocks = -(-nfp // nfr)
     config.device = f"cuda:{local}"
     net = HipScoreNet(config)
     sd = None
@@ -133,18 +200,26 @@ def main():
         net.load_state_dict(sd, strict=True)
     broadcast_weights(net, src=0)                    # ONE RCCL broadcast of the packed blob (no-op at N=1)
     net.set_option("profile", 1)
+    net.set_option("graph", args.graph)
+    tuned_from_cache = False
+    if args.tune_cache and os.path.exists(args.tune_cache):
+        net.load_tuning(args.tune_cache)
+        tuned_from_cache = True
 
-    B = args.batch
     total = B * world
     b0, b1 = shard_rows(total, rank, world)
     x, cond = synthetic.random_inputs(config, b0, b1 - b0)
     x, cond = x.cuda(), cond.cuda()
-    nfr = config.data.num_frames
 
     def one_step(i):
-        out = ddpm_sampler(x, net, cond=cond, final_only=True, denoise=True, subsample_steps=args.subsample,
-                           clip_before=True, verbose=False, log=False, seed=1000 + i, sample_offset=b0)
-        return gather_rows(out[0], total)            # final gather of the generated frames
+        if autoreg:            # the whole autoregressive job: n_blocks sampler calls, cond shifted on the device, crop to nfp frames
+            g = torch.Generator(device="cuda").manual_seed(1000 + i)
+            out = video_gen(config, net, cond, num_frames_pred=nfp, seed=1000 + i, sample_offset=b0,
+                            init_noise_fn=lambda k, shp, dev: torch.randn(shp, device=dev, generator=g))
+        else:
+            out = ddpm_sampler(x, net, cond=cond, final_only=True, denoise=True, subsample_steps=subsample,
+                               clip_before=True, verbose=False, log=False, seed=1000 + i, sample_offset=b0)[0]
+        return gather_rows(out, total)               # final gather of the generated frames
 
     def fence():
         torch.cuda.synchronize()
@@ -154,20 +229,26 @@ def main():
 
     for i in range(args.warmup):
         one_step(-1 - i)
+    if args.tune_cache and not tuned_from_cache and rank == 0:
+        net.save_tuning(args.tune_cache, [b1 - b0])
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         frames = one_step(i)
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt, per_rank = dt_local, [round(dt_local, 4)]
     if world > 1:
-        tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
-    assert torch.isfinite(frames).all() and frames.shape[0] == total
-    value = args.steps * total * nfr / dt
+        tt = torch.tensor([dt_local], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [round(v.item(), 4) for v in allt]
+        dt = max(per_rank)
+    assert torch.isfinite(frames).all() and frames.shape[0] == total and frames.shape[1] == config.data.channels * nfp
+    value = args.steps * total * nfp / dt
 
-    # ---- per-op HIP-event timings of one forward inside the timed region (first forward of the last step)
+    # ---- per-op HIP-event timings of one forward inside the timed region (first forward of the last sampler call; that
+    # forward runs op by op with events around each launch, so the sum is an UPPER bound of a back-to-back forward: event gaps)
     import ctypes as C
     from mcvd_pytorch_amd import _lib
     n = _lib.lib.mcvd_model_profile_read(net._model, None, None, None, None, None, 0)
@@ -179,7 +260,7 @@ def main():
     for i in range(n):
         if ms[i] == 0.0:          # cond-only (SPADE prep) ops are not part of the per-step forward
             continue
-        key = names[kinds[i]] + (f"{kss[i]}x{kss[i]}" if kinds[i] == 3 else "")
+        key = names.get(kinds[i], f"op{kinds[i]}") + (f"{kss[i]}x{kss[i]}" if kinds[i] == 3 else "")
         a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
         a["launches"] += 1; a["ms"] += ms[i]; a["flops"] += fl[i]; a["bytes"] += by[i]
     fwd_ms = sum(a["ms"] for a in agg.values())
@@ -202,41 +283,52 @@ def main():
     if wino["ms"] > 0.5 * c3["ms"]:
         dom, dom_name = wino, "conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)"
         mult_ratio = 16.0 / 36.0          # multiplies executed per output tile: 16 (Winograd) vs 36 (direct form)
-    achieved = dom["flops"] / dom["ms"] / 1e9
-    traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/, tools/gpu_check.sh prof)
+    algorithmic = dom["flops"] / dom["ms"] / 1e9
+    executed = algorithmic * mult_ratio
+    traffic, traffic_src = None, None     # HBM-side bytes per launch from the committed PMC passes over the SAME launch population
     try:
-        tr = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("conv3x3_traffic.json"))
-        if tr:
-            traffic = round(json.load(open(os.path.join(ROOT, "profiles", tr[-1])))["traffic_bytes_per_launch"])
+        tr = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("conv_wino_traffic.json"))
+        if tr and args.config == "smmnist_big5_ngf96" and B == 64:
+            tj = json.load(open(os.path.join(ROOT, "profiles", tr[-1])))
+            traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/" + tr[-1]
     except Exception:
         traffic = None
     roofline = dict(bound="mfma", kernel=dom_name,
-                    achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                    note=("achieved = ALGORITHMIC flops (direct-form 2*Cin*Cout*9 per output pixel) / HIP-event time of the kernel's "
-                          "launches in one forward of the timed region; the Winograd kernel executes 16/36 of those multiplies on "
-                          "the matrix pipe, so frac may exceed 1 -- executed_frac is the matrix-pipe utilisation"),
-                    executed_mfma_tflops=round(achieved * mult_ratio, 2),
-                    executed_frac=round(achieved * mult_ratio / FP32_MFMA_PEAK_TFLOPS, 4),
+                    achieved=round(executed, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(executed / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
+                    note=("achieved / frac = flops the kernel EXECUTES on the fp32 matrix pipe (Winograd F(2x2,3x3): 16/36 of the "
+                          "direct-form multiplies) / HIP-event time of its launches in one forward of the timed region / MFMA peak, "
+                          "i.e. the matrix-pipe utilisation (agrees with PMC SQ_VALU_MFMA_BUSY_CYCLES, profiles/); "
+                          "algorithmic_* applies the contract's direct-form count 2*B*HW*Cout*Cin*9 and may exceed 1"),
+                    algorithmic_achieved=round(algorithmic, 2), algorithmic_frac=round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
                     algorithmic_bytes_per_launch=round(dom["bytes"] / dom["launches"]),
                     launches=dom["launches"], avg_launch_us=round(1e3 * dom["ms"] / dom["launches"], 1),
                     flops_per_launch_avg=dom["flops"] / dom["launches"],
                     all_conv3x3=dict(launches=c3["launches"], ms=round(c3["ms"], 3), tflops=round(c3["flops"] / c3["ms"] / 1e9, 2)),
-                    forward_ms_events=round(fwd_ms, 3), breakdown=breakdown)
+                    forward_ms_events=round(fwd_ms, 3),
+                    forward_ms_events_note="sum of per-op event intervals of ONE instrumented forward: upper bound (event gaps, ~3 %)",
+                    breakdown=breakdown)
 
     if rank == 0:
-        res = dict(metric="sampled frames/sec (whole node), SMMNIST 64x64 DDPM 100-step", value=round(value, 3),
+        cap, rep = C.c_int64(), C.c_int64()
+        _lib.lib.mcvd_model_graph_stats(net._model, C.byref(cap), C.byref(rep))
+        fwd_per_step = (subsample + 1) * (n_blocks if autoreg else 1)
+        res = dict(metric=f"sampled frames/sec (whole node), {label}", value=round(value, 3),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(1e3 * dt / args.steps, 2), higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="f32", data="synthetic",
-                   config=dict(workload=f"{args.config}: ddpm_sampler subsample={args.subsample} (+1 denoise forward), "
-                                        f"{config.data.image_size}x{config.data.image_size}, {config.data.num_frames_cond} cond + {nfr} pred frames, batch {B}/GPU, random-init weights, Philox noise",
-                               global_batch=total, frames_per_step=total * nfr, forwards_per_step=args.subsample + 1,
-                               parallelism=f"sample-sharded x{world} (1 weight broadcast + 1 final all_gather)"),
-                   roofline=roofline)
+                   config=dict(workload=f"{args.config}: " + (f"video_gen, {n_blocks} autoregressive blocks of " if autoreg else "")
+                               + f"ddpm_sampler subsample={subsample} (+1 denoise forward), "
+                               f"{config.data.image_size}x{config.data.image_size}, {config.data.num_frames_cond} cond + {nfr} pred frames"
+                               + (f" per block, {nfp} kept frames" if autoreg else "")
+                               + f", batch {B}/GPU, random-init weights, Philox noise",
+                               global_batch=total, frames_per_step=total * nfp, forwards_per_step=fwd_per_step,
+                               parallelism=f"sample-sharded x{world} (1 weight broadcast + 1 final all_gather)",
+                               hip_graph=dict(enabled=bool(args.graph), captures=cap.value, replays=rep.value)),
+                   per_rank_s=per_rank, roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(config, sd, args.subsample)
+                res["cpu_baseline"] = cpu_baseline(config, sd, subsample, kept_fraction=nfp / (n_blocks * nfr) if autoreg else 1.0)
                 res["cpu_baseline"]["speedup"] = round(value / res["cpu_baseline"]["value"], 1)
             except Exception as e:      # the baseline is reporting only; never lose the GPU line
                 res["cpu_baseline"] = dict(value=None, unit="frames/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e}")

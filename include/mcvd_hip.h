@@ -88,7 +88,10 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  * kernel to the autotuner), "conv_cot" (with conv_shape 5: cout tile, in 32-channel units, that mcvd_op_conv2d requests), "conv_wdma" (1: weight
  * chunks by LDS-DMA, 0: register staging), "autotune" (1: time the conv tile candidates per layer shape on first use of a batch
  * size and keep the fastest), "side_stream" (1: ResBlock shortcut convs run on a second HIP stream concurrently with Conv_0; default 0, it measured slower), "profile" (0/1, see
- * mcvd_model_profile_read), "graph" (0/1: hipGraph replay of the forward). */
+ * mcvd_model_profile_read), "graph" (0/1: replay each UNet forward as ONE hipGraph launch instead of ~190 kernel launches -- a forward is
+ * run eagerly the first time a (x, labels, cond, eps, B) pointer set is seen, captured on a private stream the second time and
+ * replayed afterwards; mcvd_sampler_run presents the same set on every step.  Any option change, re-tune, workspace growth or
+ * mcvd_model_finalize drops the captured graph.  Also MCVD_GRAPH=1 in the environment at mcvd_ctx_create). */
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value);
 /* Diagnostics: when set (device pointer to [n_blocks][8] uint64, or NULL to disable), mcvd_op_conv2d's MFMA kernel records per
  * block the shader cycles wave 0 spent in {prologue, MFMA phases, barrier after MFMA, staging writes, second barrier, split-K
@@ -136,6 +139,14 @@ int mcvd_unet_forward_ft(mcvd_model* m, const float* x, const float* t, const fl
  * (cond, B) was not prepared computes the maps itself, every call.  mcvd_sampler_run prepares once per call.  No-ops for concat models. */
 int mcvd_model_prepare_cond(mcvd_model* m, const float* cond, int B);
 int mcvd_model_invalidate_cond(mcvd_model* m);
+/* Kernel selection table of batch size B (filled by the autotuner on the first forward at B; one (tile shape id, cout tile) pair
+ * per plan op, -1 / 0 for non-conv ops).  Exporting it after a warm-up and importing it into a later process pins the kernel
+ * choice: no timing launches, and bit-identical results from run to run (the choice only changes fp32 summation order, but the
+ * tuner's decision is timing dependent).  get: shapes == NULL returns the entry count; returns the count or a negative error. */
+int mcvd_model_get_tuning(mcvd_model* m, int B, int* shapes, int* cots, int cap);
+int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* cots, int n);
+/* hipGraph replay counters of this model (option "graph"): graphs instantiated / forwards served by a graph launch. */
+int mcvd_model_graph_stats(mcvd_model* m, int64_t* captures, int64_t* replays);
 /* Number of kernels one forward enqueues at this batch size (for tests / DESIGN.md). */
 int mcvd_model_num_launches(mcvd_model* m, int B);
 
@@ -188,6 +199,10 @@ int mcvd_upfirdn2d(mcvd_ctx* ctx, const float* in, const float* kernel_host, int
 int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
                    int Cout, int ks, const float* coef, int act, const float* res, float out_scale, float* y, int B, int H,
                    int W);
+/* Which kernel family the calling thread's last conv launch (mcvd_op_conv2d or a model forward) was dispatched to: 0..3 direct
+ * implicit-GEMM tile shapes, 4 Winograd F(2x2,3x3), 8 Winograd with the 2-way K split, 5 / 6 all-DMA 1x1 GEMM; -1 none yet.  A forced
+ * "conv_shape" that does not apply to a launch falls back to the direct kernel -- tests use this to assert what really ran. */
+int mcvd_last_conv_kernel(void);
 /* GroupNorm statistics folded to per-(b,c) affine coefficients: y = A*x + B.
  * mode 0: plain (A=rstd, B=-mean*rstd); mode 1: temb scale/shift, emb:[B, emb_stride] with scale at emb_off+c and shift at
  * emb_off+C+c (layerspp.py:521-535); mode 2: affine weight/bias:[C] (torch GroupNorm affine=True). */

@@ -45,6 +45,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     if (const char* t = getenv("MCVD_SIDE_STREAM")) c->side_stream = atoi(t);
     if (const char* t = getenv("MCVD_WINOGRAD")) c->winograd = atoi(t);
     if (const char* t = getenv("MCVD_CONV_DMA1")) c->conv_dma1 = atoi(t);
+    if (const char* t = getenv("MCVD_GRAPH")) c->graph = atoi(t);
     const char* e = getenv("MCVD_NAIVE");
     if (e) {
         const int v = atoi(e);
@@ -60,6 +61,7 @@ void mcvd_ctx_destroy(mcvd_ctx* ctx) {
     if (!ctx) return;
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->cap) (void)hipStreamDestroy(ctx->cap);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
@@ -79,6 +81,7 @@ int mcvd_ctx_set_debug_buffer(mcvd_ctx* ctx, void* device_u64) {
 
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     MCVD_REQUIRE(ctx && key, "ctx/key is NULL");
+    ++ctx->epoch;                  // captured graphs embed the kernels the options select
     if (!strcmp(key, "naive_conv")) ctx->naive_conv = value;
     else if (!strcmp(key, "naive_attn")) ctx->naive_attn = value;
     else if (!strcmp(key, "graph")) ctx->graph = value;
@@ -164,6 +167,7 @@ int mcvd_model_create(mcvd_ctx* ctx, const mcvd_unet_desc* desc, mcvd_model** ou
 void mcvd_model_destroy(mcvd_model* m) {
     if (!m) return;
     if (m->ctx) (void)hipStreamSynchronize(m->ctx->stream);
+    m->drop_graph();
     if (m->blob) (void)hipFree(m->blob);
     if (m->packed) (void)hipFree(m->packed);
     if (m->arena) (void)hipFree(m->arena);
@@ -260,6 +264,7 @@ int mcvd_model_finalize(mcvd_model* m) {
                                   hipMemcpyHostToDevice, s));
     MCVD_HIP_CHECK(hipStreamSynchronize(s));
     m->finalized = true;
+    ++m->epoch;
     return 0;
     API_CATCH
 }
@@ -328,6 +333,35 @@ int mcvd_model_num_launches(mcvd_model* m, int) {
     int n = 0;
     for (const Op& op : m->ops) n += op.prep ? 0 : 1;
     return n;
+}
+
+int mcvd_model_get_tuning(mcvd_model* m, int B, int* shapes, int* cots, int cap) {
+    MCVD_REQUIRE(m && B > 0, "get_tuning: bad arguments");
+    auto it = m->tuned_cache.find(B);
+    MCVD_REQUIRE(it != m->tuned_cache.end(), "get_tuning: batch size %d has not been tuned", B);
+    const int n = (int)it->second.first.size();
+    if (!shapes) return n;
+    MCVD_REQUIRE(cots && cap >= n, "get_tuning: capacity %d < %d ops", cap, n);
+    for (int i = 0; i < n; ++i) {
+        shapes[i] = it->second.first[i];
+        cots[i] = it->second.second[i];
+    }
+    return n;
+}
+
+int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* cots, int n) {
+    API_TRY
+    MCVD_REQUIRE(m && shapes && cots && B > 0, "set_tuning: bad arguments");
+    MCVD_REQUIRE(n == (int)m->ops.size(), "set_tuning: %d entries for a plan of %d ops (tuning of another model?)", n, (int)m->ops.size());
+    for (int i = 0; i < n; ++i) {
+        const bool conv = m->ops[i].kind == OP_CONV;
+        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 8 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
+                     "set_tuning: entry %d (shape %d, cout tile %d) does not fit op kind %d", i, shapes[i], cots[i], (int)m->ops[i].kind);
+    }
+    m->tuned_cache[B] = {std::vector<int>(shapes, shapes + n), std::vector<int>(cots, cots + n)};
+    if (m->tuned_B == B) m->tuned_B = 0;              // re-read on the next forward
+    return 0;
+    API_CATCH
 }
 
 int mcvd_model_prepare_cond(mcvd_model* m, const float* cond, int B) {
@@ -554,6 +588,15 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.dbg = ctx->dbg;
     return ctx->naive_conv ? launch_conv_naive(a, ctx->stream) : launch_conv_mfma(a, ctx->stream);
     API_CATCH
+}
+
+int mcvd_last_conv_kernel(void) { return last_conv_kernel(); }
+
+int mcvd_model_graph_stats(mcvd_model* m, int64_t* captures, int64_t* replays) {
+    MCVD_REQUIRE(m, "graph_stats: NULL model");
+    if (captures) *captures = m->graph_captures;
+    if (replays) *replays = m->graph_replays;
+    return 0;
 }
 
 int mcvd_op_gn_coef(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int C1, int groups, float eps, int mode,

@@ -18,7 +18,8 @@ LIB = os.path.join(PKG, "libmcvd_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include")]
-HOST_ONLY_FLAGS = {"model.cpp": ["-ffp-contract=off"], "api.cpp": ["-ffp-contract=off"]}
+HOST_ONLY_FLAGS = {"model.cpp": ["-ffp-contract=off"], "api.cpp": ["-ffp-contract=off"],
+                   "sampler.cpp": ["-ffp-contract=off"]}      # sampler update kernels: one rounding per operation
 
 
 def sources():

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 namespace mcvd {
@@ -25,6 +26,25 @@ const char* get_error();
             return -1;                     \
         }                                  \
     } while (0)
+
+// hipFuncSetAttribute (dynamic-LDS opt-in) is a per-DEVICE property of a kernel: each launcher keeps one of these per
+// instantiation and raises the limit the first time it launches on a device.  Lock-free: ctxs of different devices may be
+// driven from different threads (include/mcvd_hip.h threading contract).
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    // true exactly once per device (the caller then sets the attribute; a racing second caller on the same device may
+    // also see true -- setting the attribute twice is harmless)
+    bool first_use() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        const unsigned long long bit = 1ull << dev;
+        return (mask.load(std::memory_order_acquire) & bit) == 0;
+    }
+    void done() {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release);
+    }
+};
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
@@ -58,6 +78,7 @@ int conv_cout_tile(int Cout);                 // 32-channel units per block alon
 int conv_chunk(int ks);                       // input-channel chunk the MFMA kernel consumes per stage
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 int launch_conv_naive(const ConvArgs& a, hipStream_t s);
+int last_conv_kernel();                       // kernel family of this thread's last launch_conv_mfma (see conv.cpp)
 // Winograd F(2x2,3x3) kernel (conv_wino.cpp): tile shape id 4 of the dispatcher
 bool conv_wino_supported(int ks, int H, int W);      // geometry only (decides whether transformed weights are packed at all)
 int conv_wino_cout_tile(int Cout);

@@ -20,6 +20,11 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+// which kernel family the last launch_conv_mfma of this thread dispatched to (tests assert a forced shape did not fall back
+// silently): 0..3 direct implicit GEMM tile shapes, 4 Winograd, 8 Winograd + K split, 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels)
+static thread_local int g_last_conv_kernel = -1;
+int last_conv_kernel() { return g_last_conv_kernel; }
+
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     MCVD_REQUIRE(a.ks == 1 || a.ks == 3, "conv: kernel size %d unsupported", a.ks);
     MCVD_REQUIRE(a.W >= 8 && (a.W & (a.W - 1)) == 0 && a.W <= 256, "conv: W=%d must be a power of two in [8,256]", a.W);
@@ -34,11 +39,11 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if (a.shape_hint == 8) {                                        // Winograd with a 2-way K split (fills the CUs on 8x8 layers)
         ConvArgs b = a;
         b.ksplit = 2;
-        if (conv_wino_usable(b)) return launch_conv_wino(b, s);
+        if (conv_wino_usable(b)) { g_last_conv_kernel = 8; return launch_conv_wino(b, s); }
     }
-    if ((a.shape_hint == 4 || a.shape_hint == 8) && conv_wino_usable(a)) return launch_conv_wino(a, s);                              // Winograd F(2x2,3x3)
-    if (a.shape_hint == 5 && conv1x1_dma_supported(a, 16)) return launch_conv1x1_dma(a, a.cot, 16, s);   // all-DMA 1x1 GEMM
-    if (a.shape_hint == 6 && conv1x1_dma_supported(a, 32) && a.cot != 9) return launch_conv1x1_dma(a, a.cot, 32, s);
+    if ((a.shape_hint == 4 || a.shape_hint == 8) && conv_wino_usable(a)) { g_last_conv_kernel = 4; return launch_conv_wino(a, s); }   // Winograd F(2x2,3x3)
+    if (a.shape_hint == 5 && conv1x1_dma_supported(a, 16)) { g_last_conv_kernel = 5; return launch_conv1x1_dma(a, a.cot, 16, s); }   // all-DMA 1x1 GEMM
+    if (a.shape_hint == 6 && conv1x1_dma_supported(a, 32) && a.cot != 9) { g_last_conv_kernel = 6; return launch_conv1x1_dma(a, a.cot, 32, s); }
     if (a.cot < 1 || a.cot > 4 || a.CoutP % (32 * a.cot) != 0) {   // a cout tile meant for another kernel: use this one's
         ConvArgs b = a;
         b.cot = conv_cout_tile(a.Cout);
@@ -55,6 +60,7 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     typedef int (*fn_t)(const ConvArgs&, int, hipStream_t);
     static const fn_t tab3[4] = {conv3_cot1, conv3_cot2, conv3_cot3, conv3_cot4};
     static const fn_t tab1[4] = {conv1_cot1, conv1_cot2, conv1_cot3, conv1_cot4};
+    g_last_conv_kernel = shape;
     return (a.ks == 3 ? tab3 : tab1)[a.cot - 1](a, shape, s);
 }
 

@@ -184,15 +184,15 @@ static int g1_launch(const ConvArgs& a, hipStream_t s) {
     const int nct = a.CoutP / (32 * COT);
     const size_t lds = (size_t)(2 * G1_CK * 32 * COT + 2 * G1_CK * G1_PT + 2 * G1_MAXIMG * G1_CK * 2) * sizeof(float);
     const dim3 grid(((ptiles + 7) / 8) * 8 * nct);
-    static bool raised = false;
-    if (!raised && lds > 48 * 1024) {
+    static PerDeviceOnce raised;
+    if (lds > 48 * 1024 && raised.first_use()) {
         MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 0, G1_CK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 1, G1_CK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 2, G1_CK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised = true;
+        raised.done();
     }
     if (!a.coef)
         hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 0, G1_CK>), grid, dim3(256), lds, s, a, ptiles, nct);

@@ -429,11 +429,11 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     if (SPLIT && lds < 3 * 1024 * sizeof(float)) lds = 3 * 1024 * sizeof(float);
     MCVD_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu > 160KiB", lds);
     if (lds > 64 * 1024) {      // above the default dynamic-LDS limit: opt in once per instantiation
-        static bool raised = false;
-        if (!raised) {
+        static PerDeviceOnce raised;
+        if (raised.first_use()) {
             MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, CK, COT, PXT, SPLIT, WDMA, WDBF>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
+            raised.done();
         }
     }
     dim3 grid(g.n_ptiles, a.CoutP / Cfg::BCO);

@@ -433,11 +433,11 @@ template <int COT, int PRO, bool G8>
 static int wino_launch3(const ConvArgs& a, hipStream_t s) {
     constexpr int BCO = 32 * COT;
     const size_t lds = wino_lds_bytes(a.Cin, G8);
-    static bool raised = false;
-    if (!raised) {
+    static PerDeviceOnce raised;
+    if (raised.first_use()) {
         MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<COT, PRO, G8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised = true;
+        raised.done();
     }
     const int nreg = G8 ? (a.B + 1) / 2 : a.B * (a.H / 8) * (a.W / 16);
     const int ksp = a.ksplit == 2 ? 2 : 1;

@@ -1,8 +1,9 @@
 // Sampler elementwise kernels: label fill, the fused DDPM/DDIM update (models/__init__.py:287-290, :165-168,
 // :324-328), the t_min re-noise (:279), the final denoise (:333), and a counter-based Philox4x32-10 + Box-Muller
 // normal generator keyed by (seed, GLOBAL sample index, draw, element) so the stream does not depend on how the
-// batch is sharded over GPUs.  The arithmetic keeps the reference's operation order with explicit non-fused
-// multiplies/adds (CPU torch does not contract to FMA).
+// batch is sharded over GPUs.  The arithmetic keeps the reference's operation order with one rounding per multiply / add
+// (CPU torch does not contract to FMA): this translation unit is compiled with -ffp-contract=off (csrc/build.py) -- the
+// __fmul_rn / __fadd_rn device functions alone do not prevent contraction, they are inlined under the unit's default.
 #include "../common.h"
 
 namespace mcvd {

@@ -520,6 +520,7 @@ int mcvd_model::ensure_workspace(int B) {
     arena_B = B;
     cond_cache_valid = false;
     tuned_B = 0;
+    ++epoch;
     return 0;
 }
 
@@ -725,13 +726,23 @@ int mcvd_model::autotune(int B) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     tuned_B = B;
+    ++epoch;
     return 0;
 }
 
 int mcvd_model::prepare_B(int B) {
     if (int rc = ensure_workspace(B)) return rc;
     if (ctx->autotune && !ctx->naive_conv && tuned_B != B) {
+        auto it = tuned_cache.find(B);
+        if (it != tuned_cache.end() && it->second.first.size() == ops.size()) {     // tuned (or imported) before: no timing launches
+            tuned_shape = it->second.first;
+            tuned_cot = it->second.second;
+            tuned_B = B;
+            ++epoch;
+            return 0;
+        }
         if (int rc = autotune(B)) return rc;
+        tuned_cache[B] = {tuned_shape, tuned_cot};
         cond_cache_valid = false;                 // the tuner scribbles over the workspace
     }
     return 0;
@@ -779,6 +790,63 @@ int mcvd_model::forward(const float* x, const void* lab, const float* cond, floa
         }
         return 0;
     }
+    if (ctx->graph) {
+        // Replay policy: a pointer set is run eagerly the first time it is seen (kernel attributes get set, nothing unusual
+        // happens inside a capture), captured + instantiated the second time, replayed from then on.  The sampler loop
+        // presents the same (x, labels, eps, cond, B) for every step of a call.
+        GraphKey k;
+        k.x = x; k.lab = lab; k.cond = cond; k.out = out; k.B = B; k.labels_f32 = labels_f32; k.epoch = epoch; k.ctx_epoch = ctx->epoch;
+        if (graph_exec && k == graph_key) {
+            MCVD_HIP_CHECK(hipGraphLaunch(graph_exec, ctx->stream));
+            ++graph_replays;
+            return 0;
+        }
+        if (k == graph_seen) {
+            drop_graph();
+            if (!ctx->cap) MCVD_HIP_CHECK(hipStreamCreateWithFlags(&ctx->cap, hipStreamNonBlocking));
+            MCVD_HIP_CHECK(hipStreamBeginCapture(ctx->cap, hipStreamCaptureModeThreadLocal));
+            op_stream = ctx->cap;
+            int rc = 0;
+            for (const Op& op : ops) {
+                if (op.prep) continue;
+                if ((rc = launch_op(op, x, lab, cond, out, B))) break;
+            }
+            op_stream = nullptr;
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(ctx->cap, &g);
+            if (rc) {
+                if (g) (void)hipGraphDestroy(g);
+                return rc;
+            }
+            if (e != hipSuccess) {
+                set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+                return -2;
+            }
+            const hipError_t ei = hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ei != hipSuccess) {
+                graph_exec = nullptr;
+                set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+                return -2;
+            }
+            graph_key = k;
+            ++graph_captures;
+            MCVD_HIP_CHECK(hipGraphLaunch(graph_exec, ctx->stream));
+            ++graph_replays;
+            return 0;
+        }
+        graph_seen = k;
+    }
+    return forward_ops(x, lab, cond, out, B);
+}
+
+void mcvd_model::drop_graph() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    graph_exec = nullptr;
+    graph_key = GraphKey{};
+}
+
+int mcvd_model::forward_ops(const float* x, const void* lab, const float* cond, float* out, int B) {
     const bool use_side = ctx->side_stream && !ctx->naive_conv;
     if (use_side && !ctx->side) {
         MCVD_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));

@@ -12,7 +12,11 @@ struct mcvd_ctx {
     hipStream_t stream = nullptr;
     int naive_conv = 0;
     int naive_attn = 0;
-    int graph = 0;
+    int graph = 0;                 // 1: replay each forward as a hipGraph (captured on the second use of the same
+                                   //    (x, labels, cond, out, B) pointer set; the sampler loop reuses one set for all steps)
+    hipStream_t cap = nullptr;     // private capture stream (the caller's stream may be the legacy default stream, which
+                                   //    cannot be captured)
+    unsigned epoch = 0;            // bumped by every option change: invalidates captured graphs
     int conv_shape = -1;           // -1 auto, 0/1/2 force a conv tile shape (tests)
     int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
     int conv_cot = 0;              // > 0 with conv_shape 5: cout tile (32-channel units) mcvd_op_conv2d requests (tests)
@@ -128,6 +132,8 @@ struct mcvd_model {
     // conv tile choice per op for the batch size it was tuned at: (shape, cot); filled by autotune()
     std::vector<int> tuned_shape, tuned_cot;
     int tuned_B = 0;
+    // every batch size tuned (or imported through mcvd_model_set_tuning) so far: alternating batch sizes do not re-tune
+    std::map<int, std::pair<std::vector<int>, std::vector<int>>> tuned_cache;
     int autotune(int B);
 
     // per-op HIP event timing (bench.py roofline): events are recorded on the ctx stream around each op of ONE forward
@@ -143,6 +149,22 @@ struct mcvd_model {
     int prepare_B(int B);                                   // workspace + autotune for a batch size
     int run_prep(const float* cond, int B);                 // the cond-only ops
     int prepare_cond(const float* cond, int B);             // run_prep + mark the cache valid
+
+    // hipGraph replay of one forward (ctx option "graph")
+    struct GraphKey {
+        const float* x = nullptr; const void* lab = nullptr; const float* cond = nullptr; float* out = nullptr;
+        int B = 0, labels_f32 = 0; unsigned epoch = 0, ctx_epoch = 0;
+        bool operator==(const GraphKey& o) const {
+            return x == o.x && lab == o.lab && cond == o.cond && out == o.out && B == o.B && labels_f32 == o.labels_f32 &&
+                   epoch == o.epoch && ctx_epoch == o.ctx_epoch;
+        }
+    };
+    GraphKey graph_key, graph_seen;        // key of the instantiated graph / of the last eager forward
+    hipGraphExec_t graph_exec = nullptr;
+    unsigned epoch = 0;                    // bumped when the workspace, the tile choice or the packed weights change
+    long graph_replays = 0, graph_captures = 0;
+    void drop_graph();
+    int forward_ops(const float* x, const void* labels, const float* cond, float* out, int B);   // the plain launch sequence
 
     hipStream_t op_stream = nullptr;                        // overrides ctx->stream for the op being launched (side stream)
     int build_plan();

@@ -74,36 +74,76 @@ def inverse_data_transform(config, X):
 
 
 @torch.no_grad()
-def video_gen(config, scorenet, cond, num_frames_pred=None, init_noise_fn=None, sampler=None, **sampler_kwargs):
-    """Autoregressive block loop of NCSNRunner.video_gen (runners/ncsn_runner.py:1504-1569, future == 0 path):
-    generate ceil(num_frames_pred / num_frames) blocks, sliding the conditioning window on the device, and return
-    [B, C*num_frames_pred, S, S].  `init_noise_fn(block_index, shape, device)` supplies z for each block
-    (default torch.randn on the device, like :1476/:1551)."""
+def video_gen(config, scorenet, cond, num_frames_pred=None, init_noise_fn=None, sampler=None, data_init=None, verbose=False,
+              log=False, **sampler_kwargs):
+    """Autoregressive block loop of NCSNRunner.video_gen (runners/ncsn_runner.py:1476-1569, prediction path: future == 0), kept on
+    the device between blocks (the reference moves every block to the CPU and back, :1521-1539).  Returns [B, C*num_frames_pred, S, S].
+
+      * blocks: ceil(num_frames_pred / num_frames), or num_frames_pred when `sampling.one_frame_at_a_time` (:1501-1504);
+      * block input: fresh z for every block (:1476, :1551) unless `sampling.init_prev_t` > 0, where block i > 0 restarts from the
+        previous block's output and the sampler re-noises it (:1513, models/__init__.py:269-280);
+      * cond update (:1528-1539): `cond is None` (unconditional bootstrap) -> cond = gen; one_frame_at_a_time -> drop the oldest
+        cond frame, append the first generated frame; else drop the oldest num_frames cond frames, append the newest
+        min(num_frames, num_frames_cond) generated frames;
+      * `data_init` (sampling.data_init, :1479-1498, :1553-1565): frames `real_init` already in network range, flattened to
+        channels as the reference does; block input = sqrt(alpha_0) * real_init1 + sqrt(1 - alpha_0) * z.  The later-block slices
+        follow the reference's expressions literally (they index dim 0 there);
+      * result: cat(blocks, dim=1)[:, :C*num_frames_pred] (:1569).
+
+    `init_noise_fn(block_index, shape, device)` supplies z (default torch.randn on the device).  A `seed=` kwarg (on-device Philox
+    step noise) is advanced by one per block, so blocks never share a noise stream."""
     d, s = config.data, config.sampling
     C, nf, nc, S = d.channels, d.num_frames, d.num_frames_cond, d.image_size
     nfp = int(num_frames_pred if num_frames_pred is not None else s.num_frames_pred)
-    if getattr(s, "one_frame_at_a_time", False):
-        raise NotImplementedError("sampling.one_frame_at_a_time")
+    one_at_a_time = bool(getattr(s, "one_frame_at_a_time", False))
     sampler = sampler or get_sampler(config)
     dev = scorenet.device
-    cond = cond.to(dev).float().contiguous()
-    B = cond.shape[0]
+    if cond is not None:
+        cond = cond.to(dev).float().contiguous()
+        B = cond.shape[0]
+    else:
+        B = int(sampler_kwargs.pop("batch_size", getattr(s, "batch_size", 1)))
     shape = (B, C * nf, S, S)
     init_noise_fn = init_noise_fn or (lambda i, shp, dv: torch.randn(shp, device=dv))
     t_min = getattr(s, "init_prev_t", -1)
-    n_iter = ceil(nfp / nf)
+    n_iter = nfp if one_at_a_time else ceil(nfp / nf)                                  # :1501-1504
+    seed = sampler_kwargs.pop("seed", None)
+    real_init = None
+    if data_init is not None:
+        real_init = data_init.to(dev).float().reshape(len(data_init), -1, S, S)        # conditioning_fn(..., conditional=False) :109-110
+        alpha0 = scorenet.alphas[0]
+
+    def init_for(i, real_init1):
+        z = init_noise_fn(i, shape, dev)
+        if real_init is None:
+            return z
+        return alpha0.sqrt() * real_init1 + (1 - alpha0).sqrt() * z                   # :1495-1496, :1563-1564
+
+    init = init_for(0, real_init[:, :C * nf] if real_init is not None else None)       # :1488
     preds, gen = [], None
     for i in range(n_iter):
-        init = init_noise_fn(i, shape, dev) if (i == 0 or t_min <= 0) else gen          # :1513
-        out = sampler(init, scorenet, cond=cond, cond_mask=None, final_only=True, denoise=getattr(s, "denoise", True),
+        x0 = init if (i == 0 or t_min <= 0) else gen                                    # :1513
+        kw = dict(sampler_kwargs)
+        if seed is not None:
+            kw["seed"] = int(seed) + i
+        out = sampler(x0, scorenet, cond=cond, cond_mask=None, final_only=True, denoise=getattr(s, "denoise", True),
                       subsample_steps=getattr(s, "subsample", None), clip_before=getattr(s, "clip_before", True),
-                      t_min=t_min, verbose=False, log=False, **sampler_kwargs)
+                      t_min=t_min, verbose=verbose, log=log, **kw)
         gen = out[-1].reshape(B, C * nf, S, S)                                          # :1521-1522
         preds.append(gen)
         if i == n_iter - 1:
             continue
-        # cond <- [cond[:, C*nf:], gen[:, C*max(0, nf - nc):]]                            :1537-1539
-        cond = torch.cat([cond[:, C * nf:], gen[:, C * max(0, nf - nc):]], dim=1).contiguous()
+        if cond is None:                                                                # :1528-1529
+            cond = gen
+        elif one_at_a_time:                                                             # :1530-1531
+            cond = torch.cat([cond[:, C:], gen[:, :C]], dim=1).contiguous()
+        else:                                                                           # :1532-1535
+            cond = torch.cat([cond[:, C * nf:], gen[:, C * max(0, nf - nc):]], dim=1).contiguous()
+        real_init1 = None
+        if real_init is not None:                                                       # :1553-1557 (dim-0 slices, sic)
+            real_init1 = real_init[C * (i + 1):C * (i + 1 + nf)] if one_at_a_time else \
+                real_init[(i + 1) * C * nf:(i + 2) * C * nf]
+        init = init_for(i + 1, real_init1)
     return torch.cat(preds, dim=1)[:, :C * nfp]                                         # :1569
 
 

@@ -72,7 +72,30 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
     per = x[0].numel()
     if noise is not None:
         noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+    if noise_val is not None:
+        noise_val = noise_val.to(device=dev, dtype=torch.float32).contiguous()
     name = "DDPM" if kind == _lib.SAMPLER_DDPM else "DDIM"
+    # The device loop hands raw pointers to the library, which sizes everything from the model description: check every
+    # shape here (the same conditions HipScoreNet.__call__ enforces per forward), so a wrong-shaped tensor raises instead of
+    # being read / written out of bounds.
+    d = net._desc
+    want = (d.channels * d.num_frames, d.image_size, d.image_size)
+    if x.dim() != 4 or tuple(x.shape[1:]) != want:
+        raise RuntimeError(f"x_mod has shape {tuple(x.shape)}, the model expects [B, {want[0]}, {want[1]}, {want[2]}]")
+    if d.num_frames_cond > 0:
+        cwant = (B, d.channels * d.num_frames_cond, d.image_size, d.image_size)
+        if cond is None or tuple(cond.shape) != cwant:
+            raise RuntimeError(f"cond missing or mis-shaped: got {None if cond is None else tuple(cond.shape)}, expected {cwant}")
+    elif cond is not None:
+        raise RuntimeError("this model takes no conditioning frames (num_frames_cond == 0) but cond was passed")
+    L_all = d.num_classes if (subsample_steps is None or subsample_steps >= d.num_classes) else \
+        len(range(0, d.num_classes, d.num_classes // int(subsample_steps)))
+    if noise is not None:
+        need = (L_all - 1 if kind == _lib.SAMPLER_DDPM else 0) + (1 if t_min > 0 else 0)
+        if noise.dim() != 5 or tuple(noise.shape[1:]) != tuple(x.shape) or noise.shape[0] < need:
+            raise RuntimeError(f"injected noise has shape {tuple(noise.shape)}; need at least [{need}, {', '.join(map(str, x.shape))}]")
+    if noise_val is not None and tuple(noise_val.shape) != tuple(x.shape):
+        raise RuntimeError(f"noise_val has shape {tuple(noise_val.shape)}, expected {tuple(x.shape)}")
 
     fast = final_only and not verbose and not log and not same_noise and noise_val is None and frac_steps is None
     if fast:

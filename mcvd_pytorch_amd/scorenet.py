@@ -55,25 +55,34 @@ def _fptr(t):
 
 
 class HipScoreNet:
-    def __init__(self, config, device=None):
-        if not torch.cuda.is_available():
-            raise RuntimeError("HipScoreNet needs a ROCm GPU (MI355X); there is no CPU fallback")
+    def __init__(self, config, device=None, plan_only=False):
+        """`plan_only=True` builds the parameter table / schedule without a GPU (host-side protocol tests: state_dict names,
+        `EMAHelper` round trip); such an object cannot compute -- every forward / upload raises."""
         self.config = config
-        dev = torch.device(device if device is not None else getattr(config, "device", "cuda:0"))
-        if dev.type != "cuda":
-            raise RuntimeError(f"HipScoreNet cannot run on device {dev}")
-        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.plan_only = bool(plan_only)
         self.version = getattr(config.model, "version", "DDPM").upper()
         self.type = getattr(config.model, "type", None) if isinstance(getattr(config.model, "type", None), str) else None
         self.training = False
         self._desc = desc_from_config(config)
         self._ctx = C.c_void_p()
         self._model = C.c_void_p()
-        with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            _lib.check(_lib.lib.mcvd_ctx_create(self.device.index, C.c_void_p(stream), C.byref(self._ctx)), "ctx_create")
-            _lib.check(_lib.lib.mcvd_model_create(self._ctx, C.byref(self._desc), C.byref(self._model)), "model_create")
-        # python-visible parameters (torch storage; uploaded to the library's blob by sync_parameters)
+        if self.plan_only:
+            self.device = torch.device("cpu")
+            _lib.check(_lib.lib.mcvd_model_create(None, C.byref(self._desc), C.byref(self._model)), "model_create")
+        else:
+            if not torch.cuda.is_available():
+                raise RuntimeError("HipScoreNet needs a ROCm GPU (MI355X); there is no CPU fallback")
+            dev = torch.device(device if device is not None else getattr(config, "device", "cuda:0"))
+            if dev.type != "cuda":
+                raise RuntimeError(f"HipScoreNet cannot run on device {dev}")
+            self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+            with torch.cuda.device(self.device):
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                _lib.check(_lib.lib.mcvd_ctx_create(self.device.index, C.c_void_p(stream), C.byref(self._ctx)), "ctx_create")
+                _lib.check(_lib.lib.mcvd_model_create(self._ctx, C.byref(self._desc), C.byref(self._model)), "model_create")
+        # python-visible parameters (torch storage; uploaded to the library's blob by sync_parameters).  requires_grad=True
+        # although no autograd ever runs: the reference's EMAHelper.register / .ema only touch parameters that require grad
+        # (models/ema.py:12-13, 26-28), and the documented drop-in path goes through it (runners/ncsn_runner.py:928-932).
         self._params = OrderedDict()
         n = _lib.lib.mcvd_model_num_params(self._model)
         name, shape, ndim, off = C.c_char_p(), (C.c_int64 * 4)(), C.c_int(), C.c_int64()
@@ -81,7 +90,7 @@ class HipScoreNet:
             _lib.check(_lib.lib.mcvd_model_param_info(self._model, i, C.byref(name), shape, C.byref(ndim), C.byref(off)))
             shp = tuple(shape[k] for k in range(ndim.value))
             self._params[name.value.decode()] = torch.nn.Parameter(
-                torch.zeros(shp, dtype=torch.float32, device=self.device), requires_grad=False)
+                torch.zeros(shp, dtype=torch.float32, device=self.device), requires_grad=True)
         self._loaded = False
         self._dirty = True
         self._cond_key = None          # (data_ptr, _version, B) of the cond whose SPADE maps are cached in the library
@@ -92,6 +101,7 @@ class HipScoreNet:
         emb = math.log(10000) / (half - 1)                                   # layers.py:505-510
         freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -emb).contiguous()
         _lib.check(_lib.lib.mcvd_model_set_temb_freqs(self._model, _fptr(freqs), half), "set_temb_freqs")
+
 
     # ---------------------------------------------------------------- nn.Module-ish surface
     def _set_schedule(self, betas, alphas, alphas_prev):
@@ -124,7 +134,8 @@ class HipScoreNet:
                 p = self._params[key]
                 if tuple(v.shape) != tuple(p.shape):
                     raise RuntimeError(f"size mismatch for {key}: {tuple(v.shape)} vs {tuple(p.shape)}")
-                p.data.copy_(v.detach().to(dtype=torch.float32))
+                with torch.no_grad():
+                    p.data.copy_(v.detach().to(dtype=torch.float32))
                 seen.add(key)
             elif key in _BUFFER_KEYS:
                 sched[key] = v
@@ -149,6 +160,8 @@ class HipScoreNet:
         this (forced) at the start of every sampling call, because in-place edits through `.data` cannot be observed."""
         if not (self._dirty or force):
             return
+        if self.plan_only:
+            raise RuntimeError("HipScoreNet(plan_only=True) has no device: it cannot upload parameters or compute")
         if not self._loaded:
             raise RuntimeError("HipScoreNet: parameters were never loaded (load_state_dict first)")
         with torch.cuda.device(self.device):
@@ -174,7 +187,7 @@ class HipScoreNet:
         return self
 
     def to(self, device=None, *args, **kwargs):
-        if device is not None and torch.device(device).type == "cuda":
+        if device is not None and torch.device(device).type == "cuda" and not self.plan_only:
             d = torch.device(device)
             if d.index is None or d.index == self.device.index:
                 return self
@@ -182,6 +195,33 @@ class HipScoreNet:
 
     def set_option(self, key, value):
         _lib.check(_lib.lib.mcvd_ctx_set_option(self._ctx, key.encode(), int(value)), f"set_option({key})")
+
+    # ---------------------------------------------------------------- kernel-selection table (autotuner output)
+    def get_tuning(self, B):
+        """[(shape id, cout tile)] per plan op for batch size B (after a forward at B)."""
+        n = _lib.lib.mcvd_model_get_tuning(self._model, int(B), None, None, 0)
+        if n < 0:
+            raise RuntimeError(f"get_tuning: {_lib.last_error()}")
+        sh, ct = (C.c_int * n)(), (C.c_int * n)()
+        if _lib.lib.mcvd_model_get_tuning(self._model, int(B), sh, ct, n) != n:
+            raise RuntimeError(f"get_tuning: {_lib.last_error()}")
+        return [(sh[i], ct[i]) for i in range(n)]
+
+    def set_tuning(self, B, table):
+        n = len(table)
+        sh, ct = (C.c_int * n)(*[int(t[0]) for t in table]), (C.c_int * n)(*[int(t[1]) for t in table])
+        _lib.check(_lib.lib.mcvd_model_set_tuning(self._model, int(B), sh, ct, n), "set_tuning")
+
+    def save_tuning(self, path, batch_sizes):
+        import json
+        with open(path, "w") as f:
+            json.dump({str(int(b)): self.get_tuning(b) for b in batch_sizes}, f)
+
+    def load_tuning(self, path):
+        import json
+        with open(path) as f:
+            for b, table in json.load(f).items():
+                self.set_tuning(int(b), table)
 
     # ---------------------------------------------------------------- blob (one-shot weight broadcast)
     def blob_numel(self):
@@ -223,6 +263,8 @@ class HipScoreNet:
     @torch.no_grad()
     def __call__(self, x, y, cond=None, cond_mask=None):
         """eps = UNet(x, y, cond)   (reference: UNetMore_DDPM.forward, ncsnpp_more.py:753-770)."""
+        if self.plan_only:
+            raise RuntimeError("HipScoreNet(plan_only=True) cannot compute (no GPU context)")
         self.sync_parameters()
         x = self._prep(x, "x")
         cond = self._prep(cond, "cond")
@@ -233,6 +275,8 @@ class HipScoreNet:
         if d.num_frames_cond > 0:
             if cond is None or tuple(cond.shape) != (B, d.channels * d.num_frames_cond, d.image_size, d.image_size):
                 raise RuntimeError("cond missing or mis-shaped")
+        elif cond is not None:      # the reference concatenates whatever it is given and fails in the stem conv (ncsnpp_more.py:256-257)
+            raise RuntimeError("this model takes no conditioning frames (num_frames_cond == 0) but cond was passed")
         # integer labels as the DDPM/DDIM samplers pass them; float (possibly fractional) timesteps for F-PNDM's midpoints:
         # the reference's embedding takes timesteps.float() either way (layers.py:504-518)
         float_t = y.is_floating_point()

@@ -154,6 +154,65 @@ def gen_fpndm(name="tiny", batch=3, subsample=10):
           f"noclip range [{fin.min():.4f}, {fin.max():.4f}]")
 
 
+def gen_sampler_only(name, batch, subsample, kind="ddpm"):
+    """Full `ddpm_sampler` of the REAL reference at a full-width BASELINE config with the injected noise sequence: the final
+    frames (full tensor, small) -- pins the oracle and the HIP path end-to-end at configs 3 / 4."""
+    import models as ref_models
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    net.load_state_dict(synth.make_state_dict(config, seed=123), strict=False)
+    x, cond = synth.make_inputs(config, batch, seed=0)
+    noise = synth.make_noise(config, batch, subsample + 1, seed=2)
+    inj = NoiseInjector(noise)
+    orig = torch.randn_like
+    torch.randn_like = inj
+    try:
+        res = dict(ddpm=ref_models.ddpm_sampler, ddim=ref_models.ddim_sampler)[kind](
+            x.clone(), net, cond=cond, final_only=True, denoise=True, subsample_steps=subsample, clip_before=True,
+            verbose=False, log=False)
+    finally:
+        torch.randn_like = orig
+    torch.save(dict(config_name=name, batch=batch, subsample=subsample, kind=kind, result=res.clone(), n_noise=inj.k),
+               os.path.join(OUT, f"{name}_b{batch}_{kind}{subsample}.pt"))
+    print(f"wrote {name}_b{batch}_{kind}{subsample}.pt  range [{res.min():.4f}, {res.max():.4f}]  draws {inj.k}")
+
+
+def gen_autoregressive(name, batch, nfp, subsample):
+    """The autoregressive block loop of NCSNRunner.video_gen (runners/ncsn_runner.py:1504-1569, future == 0, no data_init,
+    init_prev_t <= 0) restated around the REAL reference `ddpm_sampler` + `UNetMore_DDPM` (the runner module itself does not
+    import here: cv2 / imageio / torchvision are absent).  Per block: fresh init z (seed 50 + block), injected step noise
+    (seed 60 + block); cond <- cat(cond[:, C*nf:], gen[:, C*max(0, nf - nc):]) (:1537-1539); result = cat(blocks)[:, :C*nfp] (:1569)."""
+    import models as ref_models
+    from math import ceil
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    net.load_state_dict(synth.make_state_dict(config, seed=123), strict=False)
+    C, nf, nc, S = config.data.channels, config.data.num_frames, config.data.num_frames_cond, config.data.image_size
+    _, cond = synth.make_inputs(config, batch, seed=0)
+    n_iter = ceil(nfp / nf)
+    preds = []
+    for i in range(n_iter):
+        init = torch.randn(batch, C * nf, S, S, generator=torch.Generator().manual_seed(50 + i))
+        inj = NoiseInjector(synth.make_noise(config, batch, subsample + 1, seed=60 + i))
+        orig = torch.randn_like
+        torch.randn_like = inj
+        try:
+            gen = ref_models.ddpm_sampler(init, net, cond=cond, cond_mask=None, n_steps_each=0, step_lr=0.0, verbose=False,
+                                          final_only=True, denoise=True, subsample_steps=subsample, clip_before=True,
+                                          t_min=-1, log=False, gamma=False)
+        finally:
+            torch.randn_like = orig
+        gen = gen[-1].reshape(batch, C * nf, S, S)                                    # :1521-1522
+        preds.append(gen)
+        if i == n_iter - 1:
+            continue
+        cond = torch.cat([cond[:, C * nf:], gen[:, C * max(0, nf - nc):]], dim=1)     # :1537-1539
+    pred = torch.cat(preds, dim=1)[:, :C * nfp]                                       # :1569
+    torch.save(dict(config_name=name, batch=batch, nfp=nfp, subsample=subsample, pred=pred.clone()),
+               os.path.join(OUT, f"{name}_b{batch}_ar{nfp}.pt"))
+    print(f"wrote {name}_b{batch}_ar{nfp}.pt  blocks {n_iter}  range [{pred.min():.4f}, {pred.max():.4f}]")
+
+
 def gen_fir():
     sys.path.insert(0, REF)
     from models.better import up_or_down_sampling as uds
@@ -184,5 +243,29 @@ def main():
         gen_forward_only(name, batch)
 
 
+def main_round2():
+    """Fixtures added in round 2 (VERDICT r01 'next round' item 1): the headline config end-to-end, configs 3 / 4 full samplers,
+    the autoregressive driver at config 5 width, the BASELINE.json ch_mult variant, the cosine schedule."""
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    sys.path.insert(0, REF)
+    which = sys.argv[2:] or ["cosine", "cfg2", "variant", "cfg3", "cfg4", "cfg5"]
+    if "cosine" in which:
+        gen_model_case("tiny_cosine", 2, [("ddpm", 10, {}), ("ddim", 10, {})])
+    if "cfg2" in which:
+        gen_model_case("smmnist_big5_ngf96", 2, [("ddpm", 100, {})])                  # BASELINE config 2 (the bench workload)
+    if "variant" in which:
+        gen_forward_only("cityscapes_big_variant", 1)
+    if "cfg3" in which:
+        gen_sampler_only("kth64_big_ngf128", 2, 100)
+    if "cfg4" in which:
+        gen_sampler_only("bair_big_spade", 2, 100)
+    if "cfg5" in which:
+        gen_autoregressive("cityscapes_big", 1, 8, 100)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        main_round2()
+    else:
+        main()

@@ -58,6 +58,11 @@ def make_config(name):
         data.update(image_size=32, num_frames=2, num_frames_cond=2)
         model.update(ngf=32, n_head_channels=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8, 16])
         sampling.update(subsample=10)
+    elif name == "tiny_cosine":              # `tiny` with the cosine alpha-bar schedule (models/__init__.py:28-32)
+        data.update(image_size=32, num_frames=2, num_frames_cond=2)
+        model.update(ngf=32, n_head_channels=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8, 16],
+                     sigma_dist="cosine")
+        sampling.update(subsample=10)
     elif name == "tiny_spade":
         data.update(image_size=32, channels=3, num_frames=2, num_frames_cond=1, num_frames_future=1)
         model.update(ngf=32, n_head_channels=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8, 16],

@@ -64,6 +64,8 @@ CONV_CASES = [
     (3, 96, 0, 96, 8, 3, False, 0, False, 8),
     (2, 96, 0, 96, 64, 3, True, 1, True, 8),        # K split at 64x64
     (3, 32, 0, 64, 8, 3, True, 1, False, 8),        # too few chunks to split: runs unsplit
+    (2, 288, 0, 288, 16, 3, True, 1, True, 8),      # K split on the 16x16 288-channel layers (the ones the bench splits)
+    (2, 384, 288, 288, 16, 3, True, 1, True, 8),    # ... up-path concat 672 -> 288 @16
     (2, 96, 0, 192, 32, 1, False, 0, False, -1),    # 1x1 shortcut
     (2, 96, 96, 192, 32, 1, False, 0, False, 0),    # 1x1 shortcut over a concat
     (2, 192, 0, 576, 32, 1, True, 0, False, 1),     # fused q|k|v projection with GN affine prologue (no SiLU)
@@ -82,6 +84,25 @@ CONV_CASES = [
     (2, 96, 96, 192, 32, 1, False, 0, False, 6 + 16 * 6),  # ... over a concat, cout tile 6 (82 KiB of LDS)
     (3, 288, 0, 288, 8, 1, True, 1, True, 6 + 16 * 1),     # ... two images per pixel tile, affine + SiLU, residual
 ]
+
+
+def _expected_kernel(case):
+    """Kernel family a forced conv_shape must REALLY run (mcvd_last_conv_kernel), None where the hint legitimately does not apply."""
+    B, C0, C1, Cout, H, ks, use_coef, act, use_res, shape = case
+    if shape < 0:
+        return None
+    fam = shape & 15
+    Cin = C0 + C1
+    if fam in (0, 1, 2, 3):
+        return None                                  # tile shapes fall back among themselves by geometry
+    if fam == 8:
+        chunks = -(-Cin // 16)
+        return 8 if (chunks % 2 == 0 and chunks >= 4) else 4      # conv_wino_usable: an even chunk count >= 4 splits
+    if fam == 4:
+        return 4
+    if fam in (5, 6):
+        return fam if Cin % (16 if fam == 5 else 32) == 0 else "direct"
+    return None
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "B{}_c{}+{}_o{}_H{}_k{}_s{}".format(c[0], c[1], c[2], c[3], c[4], c[5], c[9]))
@@ -111,6 +132,13 @@ def test_conv2d(ctx, case, naive):
     ctx.opt("conv_cot", shape >> 4 if shape >= 0 else 0)
     dev = lambda t: t.cuda().contiguous() if t is not None else None
     got = ctx.conv2d(dev(x0), dev(w), dev(bias), x1=dev(x1), coef=dev(coef), act=act, res=dev(res), scale=scale)
+    if not naive:                                    # a forced kernel must not have fallen back silently
+        from mcvd_pytorch_amd import _lib
+        ran, exp = _lib.lib.mcvd_last_conv_kernel(), _expected_kernel(case)
+        if exp == "direct":
+            assert ran in (0, 1, 2, 3), f"conv {case}: expected the direct kernel, kernel family {ran} ran"
+        elif exp is not None:
+            assert ran == exp, f"conv {case}: kernel family {ran} ran, expected {exp}"
     ctx.opt("naive_conv", 0)
     ctx.opt("conv_shape", -1)
     ctx.opt("conv_cot", 0)
@@ -213,7 +241,8 @@ def _net(name):
     return config, sd, net.eval()
 
 
-@pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt"])
+@pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt", "tiny_cosine_b2.pt",
+                                "smmnist_big5_ngf96_b2.pt"])
 @pytest.mark.parametrize("naive", [0, 3], ids=["mfma", "naive"])
 def test_forward_vs_reference_golden(golden_dir, fx, naive):
     """One UNet forward vs the REAL reference's output (fixture) and, module by module, vs the oracle."""
@@ -257,6 +286,9 @@ def test_forward_vs_reference_golden(golden_dir, fx, naive):
     ("tiny_b3.pt", "ddpm_10_t_min0.35", "ddpm", 10, dict(t_min=0.35)),
     ("tiny_spade_b2.pt", "ddpm_10", "ddpm", 10, {}),              # SPADE conditioning, gamma/beta cached per call
     ("smmnist_big5_b2.pt", "ddpm_100", "ddpm", 100, {}),          # BASELINE config 1: 100 steps + denoise
+    ("smmnist_big5_ngf96_b2.pt", "ddpm_100", "ddpm", 100, {}),    # BASELINE config 2 (the bench workload): 100 steps + denoise
+    ("tiny_cosine_b2.pt", "ddpm_10", "ddpm", 10, {}),             # sigma_dist: cosine
+    ("tiny_cosine_b2.pt", "ddim_10", "ddim", 10, {}),
 ])
 @pytest.mark.parametrize("path", ["device_loop", "host_loop"])
 def test_sampler_vs_reference_golden(golden_dir, fx, key, kind, sub, extra, path):
@@ -369,7 +401,8 @@ def test_spade_cache_follows_cond_content():
     assert (e2 - e1).abs().max().item() > 1e-3
 
 
-@pytest.mark.parametrize("name,B", [("kth64_big_ngf128", 2), ("bair_big_spade", 2), ("cityscapes_big", 1)])
+@pytest.mark.parametrize("name,B", [("kth64_big_ngf128", 2), ("bair_big_spade", 2), ("cityscapes_big", 1),
+                                    ("cityscapes_big_variant", 1)])
 def test_other_baseline_configs_forward(name, B, golden_dir):
     """BASELINE configs 3-5 (ngf=128 / SPADE at full width / 128x128 five-level): one forward vs the CPU oracle and vs the REAL
     reference's output on the same inputs (strided probe fixture, oracle/gen_golden.py:gen_forward_only)."""
@@ -468,3 +501,176 @@ def test_config2_shapes_mfma_vs_naive_and_properties():
     net.set_option("autotune", 1)
     assert (full[0, 4:] - part[0]).abs().max().item() <= 2e-5
     assert full.abs().max().item() < 4.0
+
+
+# ------------------------------------------------------------------------------------------------ round 2: BASELINE configs end to end
+@pytest.mark.parametrize("fx", ["kth64_big_ngf128_b2_ddpm100.pt", "bair_big_spade_b2_ddpm100.pt"])
+@pytest.mark.parametrize("path", ["device_loop", "host_loop", "graph"])
+def test_full_width_sampler_vs_reference_golden(golden_dir, fx, path):
+    """BASELINE configs 3 (ngf=128) and 4 (SPADE, gamma/beta cached across 101 forwards): the whole 100-step ddpm_sampler +
+    denoise vs the REAL reference's output with the same injected noise (oracle/gen_golden.py:gen_sampler_only)."""
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    g = torch.load(os.path.join(golden_dir, fx), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    noise = synth.make_noise(config, g["batch"], g["subsample"] + 1, seed=2)
+    if path == "graph":
+        net.set_option("graph", 1)
+    out = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), denoise=True, subsample_steps=g["subsample"], clip_before=True,
+                       verbose=False, log=False, noise=noise.cuda(), final_only=(path != "host_loop"))
+    if path == "graph":
+        import ctypes as C
+        from mcvd_pytorch_amd import _lib
+        cap, rep = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib.mcvd_model_graph_stats(net._model, C.byref(cap), C.byref(rep)))
+        assert cap.value >= 1 and rep.value >= g["subsample"] - 1, (cap.value, rep.value)      # the graph really served the loop
+    out = out[-1:].cpu()
+    assert out.shape == g["result"].shape
+    err = (out - g["result"]).abs().max().item()
+    assert err <= 1e-4, f"{fx} [{path}]: final frames max-abs err {err:.3e}"
+
+
+def test_video_gen_config5_vs_reference_golden(golden_dir):
+    """BASELINE config 5 (cityscapes 128x128, nc=2 < nf=5): `runner.video_gen` -- two autoregressive blocks, cond shift of
+    runners/ncsn_runner.py:1537-1539, crop to 8 frames (:1569) -- vs the same loop driven by the REAL reference sampler
+    (oracle/gen_golden.py:gen_autoregressive).  Two chained 100-step blocks: 2e-4."""
+    from mcvd_pytorch_amd import video_gen
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    g = torch.load(os.path.join(golden_dir, "cityscapes_big_b1_ar8.pt"), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    B, nfp, sub = g["batch"], g["nfp"], g["subsample"]
+    d = config.data
+    _, cond = synth.make_inputs(config, B, seed=0)
+    blk = [0]
+
+    def sampler(x, scorenet, cond=None, **kw):
+        i = blk[0]
+        blk[0] += 1
+        kw.pop("subsample_steps", None)
+        return ddpm_sampler(x, scorenet, cond=cond, subsample_steps=sub, noise=synth.make_noise(config, B, sub + 1, seed=60 + i).cuda(), **kw)
+    init = lambda i, shp, dev: torch.randn(B, d.channels * d.num_frames, d.image_size, d.image_size,
+                                           generator=_g(50 + i)).to(dev)
+    got = video_gen(config, net, cond.cuda(), num_frames_pred=nfp, sampler=sampler, init_noise_fn=init).cpu()
+    assert blk[0] == 2 and got.shape == g["pred"].shape == (B, d.channels * nfp, d.image_size, d.image_size)
+    err = (got - g["pred"]).abs().max().item()
+    assert err <= 2e-4, f"autoregressive config 5: max-abs err {err:.3e}"
+
+
+def test_graph_replay_is_bit_identical():
+    """Option "graph": the replayed forward launches the same kernels in the same order -> identical bits, for the plain forward
+    and for a whole sampler call; option changes drop the captured graph."""
+    import ctypes as C
+    from mcvd_pytorch_amd import _lib
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    config, sd, net = _net("tiny_spade")
+    B = 2
+    x, cond = synth.make_inputs(config, B, seed=0)
+    xc, cc = x.cuda(), cond.cuda()
+    t = torch.tensor([700, 20]).cuda()
+    ref = net(xc, t, cond=cc).clone()
+    want = ddpm_sampler(xc, net, cond=cc, final_only=True, subsample_steps=10, seed=5).clone()
+    net.set_option("graph", 1)
+    outs = [ddpm_sampler(xc, net, cond=cc, final_only=True, subsample_steps=10, seed=5) for _ in range(2)]
+    cap, rep = C.c_int64(), C.c_int64()
+    _lib.check(_lib.lib.mcvd_model_graph_stats(net._model, C.byref(cap), C.byref(rep)))
+    assert cap.value >= 1 and rep.value >= 9
+    assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
+    net.set_option("naive_attn", 1)                   # option change: the captured graph must not be replayed
+    o2 = ddpm_sampler(xc, net, cond=cc, final_only=True, subsample_steps=10, seed=5)
+    net.set_option("naive_attn", 0)
+    assert (o2 - want).abs().max().item() <= 1e-4
+    net.set_option("graph", 0)
+    assert torch.equal(net(xc, t, cond=cc), ref)
+
+
+def test_reference_ema_helper_round_trip():
+    """The documented drop-in path keeps runners/ncsn_runner.py:926-932 unchanged: load_state_dict(states[0]) then
+    EMAHelper.register / load_state_dict(states[-1]) / ema(scorenet).  The helper (restated in oracle/ema_ref.py from models/ema.py:4-29)
+    only touches parameters with requires_grad: the EMA shadow must reach the device blob and the forward must use it."""
+    from oracle.ema_ref import EMAHelper
+    config = synth.make_config("tiny")
+    config.device = "cuda:0"
+    from mcvd_pytorch_amd.scorenet import HipScoreNet
+    sd = synth.make_state_dict(config, seed=123)                 # the EMA weights (what sampling must use)
+    raw = {"module." + k: v + 0.05 * torch.randn(v.shape, generator=_g(1)) for k, v in sd.items()}      # states[0]: non-EMA weights
+    net = HipScoreNet(config)
+    net.load_state_dict(raw, strict=False)
+    helper = EMAHelper(mu=0.999)
+    helper.register(net)
+    assert len(helper.shadow) == len(sd)                          # every parameter was registered (requires_grad)
+    helper.load_state_dict(dict(sd))
+    helper.ema(net)
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    t = torch.tensor([990, 130])
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    noise = synth.make_noise(config, 2, 11, seed=2)
+    out = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10, noise=noise.cuda()).cpu()
+    blob = net.export_blob().cpu()
+    import ctypes as C
+    from mcvd_pytorch_amd import _lib
+    name, shape, ndim, off = C.c_char_p(), (C.c_int64 * 4)(), C.c_int(), C.c_int64()
+    for i, (k, p) in enumerate(net.named_parameters()):
+        _lib.check(_lib.lib.mcvd_model_param_info(net._model, i, C.byref(name), shape, C.byref(ndim), C.byref(off)))
+        assert torch.equal(blob[off.value:off.value + p.numel()].view_as(p), sd[k]), k
+    fn_k = [0]
+
+    def fn(i, like):
+        fn_k[0] += 1
+        return noise[fn_k[0] - 1]
+    want = sampler_ref.sample(x.clone(), unet_ref.OracleScoreNet(config, sd), cond=cond, kind="ddpm", final_only=True,
+                              denoise=True, subsample_steps=10, noise_fn=fn)
+    assert (out - want).abs().max().item() <= 1e-4
+    eps = net(x.cuda(), t.cuda(), cond=cond.cuda()).cpu()
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t, cond)
+    assert (eps - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_two_contexts_large_lds_kernels():
+    """Two mcvd_ctx in one process (include/mcvd_hip.h threading contract): the >64 KiB dynamic-LDS opt-in of the Winograd / 1x1
+    kernels is tracked per device, not per process; both contexts must launch them, also from two threads at once."""
+    import threading
+    from tests.hiputil import Ctx
+    a, b = Ctx(), Ctx()
+    g = _g(3)
+    x = torch.randn(2, 96, 32, 32, generator=g).cuda()
+    w3 = (torch.randn(96, 96, 3, 3, generator=g) / 30).cuda()
+    w1 = (torch.randn(192, 96, 1, 1, generator=g) / 10).cuda()
+    bias3, bias1 = torch.zeros(96).cuda(), torch.zeros(192).cuda()
+    want3 = F.conv2d(x.cpu(), w3.cpu(), padding=1)
+    want1 = F.conv2d(x.cpu(), w1.cpu())
+    res = {}
+
+    def work(name, c):
+        c.opt("conv_shape", 4)
+        y3 = c.conv2d(x, w3, bias3)
+        c.opt("conv_shape", 6)
+        c.opt("conv_cot", 6)
+        y1 = c.conv2d(x, w1, bias1)
+        torch.cuda.synchronize()
+        res[name] = (y3.cpu(), y1.cpu())
+    th = [threading.Thread(target=work, args=(n, c)) for n, c in (("a", a), ("b", b))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for n in ("a", "b"):
+        _close(res[n][0], want3, what=f"ctx {n} winograd")
+        _close(res[n][1], want1, what=f"ctx {n} 1x1 dma")
+
+
+def test_sampler_rejects_bad_shapes():
+    """The device loop hands raw pointers to the library: wrong-shaped x / cond / too-short injected noise must raise, not read
+    out of bounds."""
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    config, sd, net = _net("tiny")
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    with pytest.raises(RuntimeError):
+        ddpm_sampler(x[:, :1].cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10)
+    with pytest.raises(RuntimeError):
+        ddpm_sampler(x.cuda(), net, cond=cond[:1].cuda(), final_only=True, subsample_steps=10)
+    with pytest.raises(RuntimeError):
+        ddpm_sampler(x.cuda(), net, cond=None, final_only=True, subsample_steps=10)
+    with pytest.raises(RuntimeError):
+        ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10,
+                     noise=synth.make_noise(config, 2, 4, seed=2).cuda())

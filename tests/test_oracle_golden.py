@@ -12,7 +12,7 @@ def load(golden_dir, name):
     return torch.load(os.path.join(golden_dir, name), weights_only=False)
 
 
-@pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt"])
+@pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt", "tiny_cosine_b2.pt"])
 def test_schedule_bit_exact(golden_dir, fx):
     g = load(golden_dir, fx)
     c = unet_ref.hot_cfg(synth.make_config(g["config_name"]))
@@ -22,7 +22,8 @@ def test_schedule_bit_exact(golden_dir, fx):
     assert torch.equal(alphas_prev, g["alphas_prev"])
 
 
-@pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt"])
+@pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt", "tiny_cosine_b2.pt",
+                                "smmnist_big5_ngf96_b2.pt"])
 def test_forward_matches_reference(golden_dir, fx):
     g = load(golden_dir, fx)
     config = synth.make_config(g["config_name"])
@@ -60,6 +61,9 @@ def _injector(noise):
     ("tiny_b3.pt", "ddpm_10_t_min0.35", "ddpm", 10, dict(t_min=0.35)),
     ("tiny_spade_b2.pt", "ddpm_10", "ddpm", 10, {}),
     ("smmnist_big5_b2.pt", "ddpm_100", "ddpm", 100, {}),      # BASELINE config 1, full 101 forwards
+    ("smmnist_big5_ngf96_b2.pt", "ddpm_100", "ddpm", 100, {}),   # BASELINE config 2 (the bench workload), full 101 forwards
+    ("tiny_cosine_b2.pt", "ddpm_10", "ddpm", 10, {}),         # sigma_dist: cosine (models/__init__.py:28-32)
+    ("tiny_cosine_b2.pt", "ddim_10", "ddim", 10, {}),
 ])
 def test_sampler_matches_reference(golden_dir, fx, key, kind, sub, extra):
     g = load(golden_dir, fx)
@@ -76,7 +80,8 @@ def test_sampler_matches_reference(golden_dir, fx, key, kind, sub, extra):
     assert (out - ref).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("fx", ["kth64_big_ngf128_b2_fwd.pt", "bair_big_spade_b2_fwd.pt", "cityscapes_big_b1_fwd.pt"])
+@pytest.mark.parametrize("fx", ["kth64_big_ngf128_b2_fwd.pt", "bair_big_spade_b2_fwd.pt", "cityscapes_big_b1_fwd.pt",
+                                "cityscapes_big_variant_b1_fwd.pt"])
 def test_forward_matches_reference_full_width(golden_dir, fx):
     """BASELINE configs 3-5 (ngf=128 / SPADE at full width / 128x128 five-level): the oracle vs the REAL reference's forward,
     module by module (strided probes) and on the final eps."""
@@ -96,6 +101,52 @@ def test_forward_matches_reference_full_width(golden_dir, fx):
     p = g["fwd_eps_probe"]
     assert list(eps.shape) == p["shape"]
     torch.testing.assert_close(eps.reshape(-1).double()[p["idx"]].float(), p["sample"], rtol=1e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize("fx", ["kth64_big_ngf128_b2_ddpm100.pt", "bair_big_spade_b2_ddpm100.pt"])
+def test_full_width_sampler_matches_reference(golden_dir, fx):
+    """BASELINE configs 3 / 4 (ngf=128; SPADE) end to end: 100-step ddpm_sampler + denoise of the REAL reference with the injected
+    noise sequence vs the oracle (final frames, 1e-4)."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    g = load(golden_dir, fx)
+    config = synth.make_config(g["config_name"])
+    net = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123))
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    fn, k = _injector(synth.make_noise(config, g["batch"], g["subsample"] + 1, seed=2))
+    out = sampler_ref.sample(x.clone(), net, cond=cond, kind=g["kind"], final_only=True, denoise=True,
+                             subsample_steps=g["subsample"], clip_before=True, noise_fn=fn)
+    assert k[0] == g["n_noise"] and out.shape == g["result"].shape
+    assert (out - g["result"]).abs().max().item() <= 1e-4
+
+
+def ar_oracle(config, sd, batch, nfp, subsample):
+    """The autoregressive block loop (runners/ncsn_runner.py:1504-1569) over the oracle sampler, with the inputs of
+    oracle/gen_golden.py:gen_autoregressive (init seed 50 + block, step noise seed 60 + block)."""
+    from math import ceil
+    net = unet_ref.OracleScoreNet(config, sd)
+    C, nf, nc, S = config.data.channels, config.data.num_frames, config.data.num_frames_cond, config.data.image_size
+    _, cond = synth.make_inputs(config, batch, seed=0)
+    preds = []
+    n_iter = ceil(nfp / nf)
+    for i in range(n_iter):
+        init = torch.randn(batch, C * nf, S, S, generator=torch.Generator().manual_seed(50 + i))
+        fn, _ = _injector(synth.make_noise(config, batch, subsample + 1, seed=60 + i))
+        gen = sampler_ref.sample(init, net, cond=cond, kind="ddpm", final_only=True, denoise=True, subsample_steps=subsample,
+                                 clip_before=True, noise_fn=fn)[0]
+        preds.append(gen)
+        if i != n_iter - 1:
+            cond = torch.cat([cond[:, C * nf:], gen[:, C * max(0, nf - nc):]], dim=1)
+    return torch.cat(preds, dim=1)[:, :C * nfp]
+
+
+def test_autoregressive_config5_matches_reference(golden_dir):
+    """BASELINE config 5 (cityscapes, 128x128, nc=2 < nf=5): two autoregressive blocks cropped to 8 frames, reference vs oracle."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    g = load(golden_dir, "cityscapes_big_b1_ar8.pt")
+    config = synth.make_config(g["config_name"])
+    out = ar_oracle(config, synth.make_state_dict(config, seed=123), g["batch"], g["nfp"], g["subsample"])
+    assert out.shape == g["pred"].shape
+    assert (out - g["pred"]).abs().max().item() <= 2e-4      # two chained 100-step blocks
 
 
 def test_fpndm_matches_reference(golden_dir):

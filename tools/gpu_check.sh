@@ -1,48 +1,63 @@
 #!/bin/bash
-# One gpurun call: build check, GPU parity tests, smoke, short bench, (optional) rocprofv3 kernel trace.
-# Usage (from the repo root on the GPU box): bash tools/gpu_check.sh [quick|full|prof]
-MODE=${1:-full}
+# One gpurun call.  Usage (from the repo root on the GPU box): bash tools/gpu_check.sh MODE...
+# Modes (any number, run in order): test | smoke | bench | bench2 (N=2 gloo plumbing on one GPU) | graphab | others | prof | pmc_mfma | pmc_sq
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 rocm-smi --showproductname > gpurun_out/rocm_smi.log 2>&1
 nproc > gpurun_out/nproc.log; lscpu | head -20 >> gpurun_out/nproc.log
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
 echo "build rc=$?" >> gpurun_out/build.log
-if [ "$MODE" != "prof" ] && [ "$MODE" != "pmc3" ]; then
-  timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
-  echo "smoke rc=$?" >> gpurun_out/smoke.log
-  tail -3 gpurun_out/smoke.log
-  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
-  echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-  tail -40 gpurun_out/pytest_gpu.log
-fi
-if [ "$MODE" != "quick" ] && [ "$MODE" != "prof" ] && [ "$MODE" != "pmc3" ]; then
-  timeout 900 python bench.py --steps 1 --warmup 1 > gpurun_out/bench.json 2> gpurun_out/bench.err
-  echo "bench rc=$?" >> gpurun_out/bench.err
-  cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
-fi
-if [ "$MODE" = "pmc2" ]; then
-  R=$GRAFT_REPO_ROOT
+TUNE=$R/gpurun_out/tune_cfg2_B64.json
+for MODE in "$@"; do
+case $MODE in
+smoke)
+  timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log; tail -3 gpurun_out/smoke.log;;
+test)
+  timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; tail -30 gpurun_out/pytest_gpu.log;;
+testall)
+  timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; tail -40 gpurun_out/pytest_gpu.log;;
+bench)
+  timeout 900 python bench.py --steps 2 --warmup 1 --tune-cache $TUNE > gpurun_out/bench.json 2> gpurun_out/bench.err
+  echo "bench rc=$?" >> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err;;
+graphab)
+  for g in 0 1; do
+    timeout 600 python bench.py --steps 2 --warmup 1 --graph $g --no-cpu-baseline --tune-cache $TUNE > gpurun_out/bench_graph$g.json 2> gpurun_out/bench_graph$g.err
+    python -c "import json;d=json.load(open('gpurun_out/bench_graph$g.json'));print('graph$g', d['value'], d['ms_per_step'])"
+  done;;
+bench2)
+  MCVD_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 1 --warmup 1 --batch 8 --no-cpu-baseline > gpurun_out/bench_2proc.json 2> gpurun_out/bench_2proc.err
+  echo "bench2 rc=$?" >> gpurun_out/bench_2proc.err; cat gpurun_out/bench_2proc.json | cut -c1-600; tail -3 gpurun_out/bench_2proc.err;;
+others)
+  for c in smmnist_big5 kth64_big_ngf128 bair_big_spade cityscapes_big cityscapes_big_variant; do
+    for g in 0 1; do
+      timeout 900 python bench.py --config $c --steps 1 --warmup 1 --graph $g --no-cpu-baseline > gpurun_out/bench_other_${c}_g$g.json 2> gpurun_out/bench_other_${c}_g$g.err
+      python -c "import json;d=json.load(open('gpurun_out/bench_other_${c}_g$g.json'));print('$c graph$g', d['value'], d['ms_per_step'], d['roofline']['frac'])"
+    done
+  done;;
+prof)
   cd /tmp
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_mfma -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline > $R/gpurun_out/pmc_mfma.json 2> $R/gpurun_out/pmc_mfma.err
-  cd $R; python tools/summarize_prof.py mfma > gpurun_out/pmc_mfma_summary.txt 2>&1; head -30 gpurun_out/pmc_mfma_summary.txt
-fi
-if [ "$MODE" = "pmc3" ]; then
-  # wave-state split of the kernels: parked (s_waitcnt / barrier) vs issue-stalled (pipe busy) vs issuing; LDS conflicts
-  R=$GRAFT_REPO_ROOT
-  cd /tmp
-  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/pmc_sq -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
-  cd $R; python tools/summarize_prof.py sq > gpurun_out/pmc_sq_summary.txt 2>&1; head -30 gpurun_out/pmc_sq_summary.txt
-fi
-if [ "$MODE" = "prof" ]; then
-  R=$GRAFT_REPO_ROOT
-  cd /tmp
-  # pass 1: kernel trace + stats of the default bench command (same workload as the bench line)
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_bench.err
-  # passes 2,3: HBM-side PMC counters, each in its own run (kernel-trace only), on a shortened sampler (6 forwards)
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.json 2> $R/gpurun_out/pmc_fetch.err
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline > $R/gpurun_out/pmc_write.json 2> $R/gpurun_out/pmc_write.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --tune-cache $TUNE > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_bench.err
+  # HBM-side PMC counters, each in its own run (kernel-trace only); the kernel table comes from the cache: no autotune launches
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --graph 0 --tune-cache $TUNE > $R/gpurun_out/pmc_fetch.json 2> $R/gpurun_out/pmc_fetch.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --graph 0 --tune-cache $TUNE > $R/gpurun_out/pmc_write.json 2> $R/gpurun_out/pmc_write.err
   cd $R; python tools/summarize_prof.py > gpurun_out/prof_summary.txt 2>&1; head -40 gpurun_out/prof_summary.txt
-  # keep the merged payload small: raw per-dispatch CSVs can be large
-  find gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -size +20M -delete
-fi
+  python tools/summarize_prof.py traffic gpurun_out/conv_wino_traffic.json > gpurun_out/traffic.log 2>&1; tail -3 gpurun_out/traffic.log
+  find gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -size +20M -delete;;
+pmc_mfma)
+  cd /tmp
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_mfma -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --graph 0 --tune-cache $TUNE > $R/gpurun_out/pmc_mfma.json 2> $R/gpurun_out/pmc_mfma.err
+  cd $R; python tools/summarize_prof.py mfma > gpurun_out/pmc_mfma_summary.txt 2>&1; head -30 gpurun_out/pmc_mfma_summary.txt
+  find gpurun_out/pmc_mfma -name "*.csv" -size +20M -delete;;
+pmc_sq)
+  # wave-state split of the kernels: parked (s_waitcnt / barrier) vs issue-stalled (pipe busy) vs issuing; LDS conflicts
+  cd /tmp
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/pmc_sq -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --graph 0 --tune-cache $TUNE > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
+  cd $R; python tools/summarize_prof.py sq > gpurun_out/pmc_sq_summary.txt 2>&1; head -30 gpurun_out/pmc_sq_summary.txt
+  find gpurun_out/pmc_sq -name "*.csv" -size +20M -delete;;
+*) echo "unknown mode $MODE";;
+esac
+cd $R
+done

@@ -100,33 +100,53 @@ def sq():
 
 
 def traffic(out_json):
-    """HBM-side bytes per launch of the dominant kernel (largest total time in the kernel stats) from the two PMC passes."""
+    """HBM-side bytes per conv launch of the Winograd kernel family from the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs,
+    kernel-trace only), over the SAME population bench.py's `algorithmic_bytes_per_launch` averages: every Winograd-served 3x3 conv
+    op of the forwards of the run (a K-split op = conv_wino_kernel + its reduce pass), no autotune launches (the runs load the
+    kernel table from the tune cache).  Forwards are counted by temb_mlp_kernel dispatches.  Also a per-instantiation table."""
     import json
-    agg = defaultdict(float)
-    for f in glob.glob(os.path.join(OUT, "prof", "**", "*kernel_stats.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            agg[short(r["Name"])] += float(r["TotalDurationNs"])
-    if not agg:
-        return
-    dom = max(agg, key=agg.get)
-    res = {"kernel": dom}
+    res = {"kernel_family": "conv_wino_kernel<*> + wino_ksplit_reduce_kernel", "per_instantiation": {}}
+    fam = lambda k: k.startswith("conv_wino_kernel") or k.startswith("wino_ksplit_reduce_kernel")
+    tot = {}
     for key, dirname, counter in (("fetch", "pmc_fetch", "FETCH_SIZE"), ("write", "pmc_write", "WRITE_SIZE")):
-        n, v = 0, 0.0
+        per = defaultdict(lambda: [0, 0.0])
+        fwd = 0
         for f in glob.glob(os.path.join(OUT, dirname, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if r.get("Counter_Name") == counter and short(r["Kernel_Name"]) == dom:
-                    n += 1
-                    v += float(r["Counter_Value"])
-        res[f"launches_{key}"] = n
-        res[f"{key}_size_kib_per_launch_raw"] = v / max(n, 1)
-    fetch = res["fetch_size_kib_per_launch_raw"] * 1024.0
-    write = res["write_size_kib_per_launch_raw"] * 1024.0
+                if r.get("Counter_Name") != counter:
+                    continue
+                k = short(r["Kernel_Name"])
+                if k.startswith("temb_mlp_kernel"):
+                    fwd += 1
+                if fam(k):
+                    per[k][0] += 1
+                    per[k][1] += float(r["Counter_Value"])
+        res[f"forwards_{key}"] = fwd
+        tot[key] = sum(v for _, v in per.values()) * 1024.0                      # rocprofv3 reports KiB
+        for k, (c, v) in per.items():
+            e = res["per_instantiation"].setdefault(k, {})
+            e[f"launches_{key}"] = c
+            e[f"{key}_kib_per_launch_raw"] = v / max(c, 1)
+    ops_per_forward = None
+    try:
+        ops_per_forward = json.load(open(os.path.join(OUT, "pmc_fetch.json")))["roofline"]["launches"]
+    except Exception:
+        pass
+    res["wino_ops_per_forward"] = ops_per_forward
+    n_ops = (ops_per_forward or 0) * res.get("forwards_fetch", 0)
     res["fetch_correction"] = "x2 (gfx950 FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)"
-    res["traffic_bytes_per_launch"] = 2.0 * fetch + write
-    res["note"] = ("separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (kernel-trace only), bench.py --subsample 5 (6 forwards) incl. "
-                   "the autotuner's timing launches; averaged over every layer shape the kernel serves; Infinity-Cache hits are counted")
+    if n_ops:
+        res["traffic_bytes_per_launch"] = (2.0 * tot["fetch"] + tot["write"]) / n_ops
+        res["fetch_bytes_per_launch_corrected"] = 2.0 * tot["fetch"] / n_ops
+        res["write_bytes_per_launch"] = tot["write"] / n_ops
+        try:
+            res["algorithmic_bytes_per_launch"] = json.load(open(os.path.join(OUT, "pmc_fetch.json")))["roofline"]["algorithmic_bytes_per_launch"]
+        except Exception:
+            pass
+    res["note"] = ("bench.py --subsample 5 (6 forwards), --graph 0, kernel table from the tune cache (no autotune launches); one PMC counter "
+                   "per run; Infinity-Cache hits are counted as traffic (memory-side L2 counters)")
     json.dump(res, open(out_json, "w"), indent=1)
-    print("wrote", out_json, res)
+    print("wrote", out_json, {k: v for k, v in res.items() if k != "per_instantiation"})
 
 
 if __name__ == "__main__":
