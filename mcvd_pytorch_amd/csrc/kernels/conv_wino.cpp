@@ -61,7 +61,10 @@ constexpr int WR_PP = 24;
 //     Used where the (region, cout tile) count alone cannot fill the 256 CUs (8x8 and some 16x16 layers).  An earlier
 //     version added the halves into a zero-filled output with fp32 atomics: the memset + 3 M scalar atomics per launch cost
 //     what the split gained.
-template <int COT, int PRO, bool G8>
+// EXP != 0: timing-only ablations of the K loop (wrong results; env MCVD_WINO_EXP, tests/gpu_diag.py wexp): bit 0 no tile
+//     transform (WRITE_V), bit 1 no patch activation/park (WRITE_P), bit 2 no VMEM in the loop, bit 3 no B-operand LDS reads,
+//     bit 4 no MFMA, bit 5 no chunk barrier, bits 8-9: s_setprio scheme (1: prio = 3 - grp, 2: prio = grp, 3: all waves prio 1).
+template <int COT, int PRO, bool G8, int EXP = 0>
 __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     constexpr int NT = WR_NT, CK = WR_CK, T = WR_T, BCO = 32 * COT;
     constexpr int VSZ = CK * 16 * T;            // floats per V chunk
@@ -178,13 +181,17 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     {                                                                                                           \
         float* sPw = sP + (((ch) & 1) ? PBUF : 0);                                                              \
         const int nvalid = Cin - (ch) * CK;                                                                     \
+        f32x2 cfv[MAXP];                     /* all coefficient reads first: ONE LDS round trip, not MAXP */     \
+        if (PRO >= 1) {                                                                                         \
+            _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                               \
+                const int cch = min((ch) * CK + (p_ci[sl] & (CK - 1)), Cin - 1) + (G8 ? p_img[sl] * Cin : 0);   \
+                cfv[sl] = *reinterpret_cast<const f32x2*>(sCo + cch * 2);                                       \
+            }                                                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cfv[0]), "+v"(cfv[1]), "+v"(cfv[MAXP > 2 ? 2 : 0]) :: "memory"); \
+        }                                                                                                       \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
             float v = D[sl];                                                                                    \
-            if (PRO >= 1) {                                                                                     \
-                const int cch = min((ch) * CK + (p_ci[sl] & (CK - 1)), Cin - 1) + (G8 ? p_img[sl] * Cin : 0);   \
-                const f32x2 cf = *reinterpret_cast<const f32x2*>(sCo + cch * 2);                                \
-                v = v * cf.x + cf.y;                                                                            \
-            }                                                                                                   \
+            if (PRO >= 1) v = v * cfv[sl].x + cfv[sl].y;                                                        \
             if (PRO == 2) v = silu_wr(v);                                                                       \
             sPw[p_lds[sl]] = (p_ci[sl] < min(nvalid, CK)) ? v : 0.0f;                                           \
         }                                                                                                       \
@@ -276,6 +283,61 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     //               first use of A1 (group 4): issued at the top, younger = MAXP patch + COT mid loads            (VM_A)
     //               first use of A0 (group 0 of the next chunk): issued at mid, younger = COT + MAXP loads of that chunk's top
     float xb = 0.0f, yb = 0.0f;            // B operands; yb = 0: the first "deferred" group multiplies zeros
+    if (EXP != 0) {        // ablation build of the loop: same order, pieces compiled out (timing only)
+        if (((EXP >> 8) & 3) == 1) { if (grp == 0) __builtin_amdgcn_s_setprio(3); if (grp == 1) __builtin_amdgcn_s_setprio(2); if (grp == 2) __builtin_amdgcn_s_setprio(1); }
+        if (((EXP >> 8) & 3) == 2) { if (grp == 3) __builtin_amdgcn_s_setprio(3); if (grp == 2) __builtin_amdgcn_s_setprio(2); if (grp == 1) __builtin_amdgcn_s_setprio(1); }
+        if (((EXP >> 8) & 3) == 3) __builtin_amdgcn_s_setprio(1);
+#define X_V(ch) if (!(EXP & 1)) WR_WRITE_V(ch)
+#define X_P(ch, D) if (!(EXP & 2)) WR_WRITE_P(ch, D)
+#define X_LA(u, S) if (!(EXP & 4)) WR_LOAD_A(u, S)
+#define X_LP(ch, D) if (!(EXP & 4)) WR_LOAD_P(ch, D)
+#define X_WA(N, S) if (!(EXP & 4)) WR_WAIT_A(N, S)
+#define X_WP(N, D) if (!(EXP & 4)) WR_WAIT_P(N, D)
+#define X_B(g, BV) if (!(EXP & 8)) WR_LOAD_B(g, BV)
+#define X_M(kp, BV, S) if (!(EXP & 16)) WR_DO_MFMA(kp, BV, S)
+        for (int c = c_begin; c + 1 < c_end; ++c) {
+            const float* sVc = sV + ((c & 1) ? VSZ : 0);
+            X_M(3, yb, A1)
+            X_B(0, xb)
+            X_WP(VM_P, pd)
+            X_P(c + 2, pd)
+            X_LA(2 * c + 1, A1)
+            X_LP(c + 3, pd)
+            if (grp == 3) X_V(c + 1)
+            X_WA(VM_A, A0)
+            X_M(0, xb, A0)
+            X_B(1, yb)
+            if (grp == 2) X_V(c + 1)
+            X_M(1, yb, A0)
+            X_B(2, xb)
+            if (grp == 0) X_V(c + 1)
+            X_M(2, xb, A0)
+            X_B(3, yb)
+            if (grp == 1) X_V(c + 1)
+            X_M(3, yb, A0)
+            X_B(4, xb)
+            X_LA(2 * c + 2, A0)
+            X_WA(VM_A, A1)
+            X_M(0, xb, A1)
+            X_B(5, yb)
+            X_M(1, yb, A1)
+            X_B(6, xb)
+            X_M(2, xb, A1)
+            X_B(7, yb)
+            if (!(EXP & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+#undef X_V
+#undef X_P
+#undef X_LA
+#undef X_LP
+#undef X_WA
+#undef X_WP
+#undef X_B
+#undef X_M
+    } else
     for (int c = c_begin; c + 1 < c_end; ++c) {
         const float* sVc = sV + ((c & 1) ? VSZ : 0);
         WR_DO_MFMA(3, yb, A1)              // group 7 of the previous chunk (operands were read before the barrier)
@@ -429,6 +491,42 @@ static size_t wino_lds_bytes(int Cin, bool g8) {
     return k > epi ? k : epi;
 }
 
+template <int EXP>
+static int wino_launch_exp1(const ConvArgs& k, dim3 grid, size_t lds, hipStream_t s) {
+    static PerDeviceOnce raised;
+    if (raised.first_use()) {
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<3, 2, false, EXP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised.done();
+    }
+    hipLaunchKernelGGL((conv_wino_kernel<3, 2, false, EXP>), grid, dim3(WR_NT), lds, s, k);
+    return 0;
+}
+static int wino_launch_exp(int e, const ConvArgs& k, dim3 grid, size_t lds, hipStream_t s) {
+    switch (e) {
+        case 1: return wino_launch_exp1<1>(k, grid, lds, s);          // no transform
+        case 2: return wino_launch_exp1<2>(k, grid, lds, s);          // no patch activation / park
+        case 3: return wino_launch_exp1<3>(k, grid, lds, s);          // neither
+        case 4: return wino_launch_exp1<4>(k, grid, lds, s);          // no VMEM in the loop
+        case 7: return wino_launch_exp1<7>(k, grid, lds, s);          // MFMA + B reads + barrier only
+        case 15: return wino_launch_exp1<15>(k, grid, lds, s);        // MFMA + barrier only
+        case 47: return wino_launch_exp1<47>(k, grid, lds, s);        // MFMA only, no barrier
+        case 16: return wino_launch_exp1<16>(k, grid, lds, s);        // everything but the MFMAs
+        case 32: return wino_launch_exp1<32>(k, grid, lds, s);        // no chunk barrier (racy)
+        case 17: return wino_launch_exp1<17>(k, grid, lds, s);        // no MFMA, no transform
+        case 18: return wino_launch_exp1<18>(k, grid, lds, s);        // no MFMA, no WRITE_P
+        case 19: return wino_launch_exp1<19>(k, grid, lds, s);        // no MFMA, neither
+        case 20: return wino_launch_exp1<20>(k, grid, lds, s);        // no MFMA, no VMEM
+        case 23: return wino_launch_exp1<23>(k, grid, lds, s);        // barrier only (+ loop overhead)
+        case 22: return wino_launch_exp1<22>(k, grid, lds, s);        // no MFMA, no VMEM, no WRITE_P: transform only
+        case 21: return wino_launch_exp1<21>(k, grid, lds, s);        // no MFMA, no VMEM, no transform: WRITE_P only
+        case 256: return wino_launch_exp1<256>(k, grid, lds, s);      // s_setprio 3 - grp
+        case 512: return wino_launch_exp1<512>(k, grid, lds, s);      // s_setprio grp
+        case 768: return wino_launch_exp1<768>(k, grid, lds, s);      // s_setprio 1 everywhere
+        default: mcvd::set_error("MCVD_WINO_EXP=%d is not a built ablation", e); return -1;
+    }
+}
+
 template <int COT, int PRO, bool G8>
 static int wino_launch3(const ConvArgs& a, hipStream_t s) {
     constexpr int BCO = 32 * COT;
@@ -447,6 +545,11 @@ static int wino_launch3(const ConvArgs& a, hipStream_t s) {
         const char* w = getenv("MCVD_DBG_WAVE");       // which wave records its phase times (diagnostics)
         k.wdma = w ? atoi(w) : 0;
     }
+    const char* exp_s = getenv("MCVD_WINO_EXP");           // read per launch: the diagnostics script flips it between runs
+    const int exp_env = exp_s ? atoi(exp_s) : 0;
+    if (COT == 3 && PRO == 2 && !G8 && exp_env != 0) {      // timing-only ablations (tests/gpu_diag.py wexp)
+        if (int rc = wino_launch_exp(exp_env, k, grid, lds, s)) return rc;
+    } else
     hipLaunchKernelGGL((conv_wino_kernel<COT, PRO, G8>), grid, dim3(WR_NT), lds, s, k);
     MCVD_HIP_CHECK(hipGetLastError());
     if (ksp == 2) {                                    // second pass: p0 + p1 + bias + res, scaled

@@ -227,11 +227,65 @@ def wphases(f):
     ctx.opt("conv_shape", -1)
 
 
+def wexp(f):
+    """Timing-only ablations of the Winograd K loop (conv_wino.cpp EXP builds, env MCVD_WINO_EXP): kernel time and the K-loop
+    cycles per 16-channel chunk of one wave, per ablation."""
+    from tests.hiputil import Ctx, P
+    ctx = Ctx()
+    B = 64
+    labels = {0: "baseline", 1: "no transform (WRITE_V)", 2: "no patch activation/park (WRITE_P)", 3: "no WRITE_V, no WRITE_P",
+              4: "no VMEM in the loop", 7: "MFMA + B reads + barrier only", 15: "MFMA + barrier only", 47: "MFMA only, no barrier",
+              16: "everything but the MFMAs", 17: "no MFMA, no transform", 18: "no MFMA, no WRITE_P", 19: "no MFMA, no V, no P (VMEM only)",
+              20: "no MFMA, no VMEM", 21: "WRITE_P only", 22: "transform only", 23: "barrier + loop overhead only", 32: "no chunk barrier (racy)", 256: "s_setprio 3-grp", 512: "s_setprio grp",
+              768: "s_setprio 1 everywhere"}
+    cases = [(96, 96, 64), (192, 192, 32), (480, 192, 32)]
+    if os.environ.get("MCVD_WEXP_CASES", "all") != "all":
+        cases = [cases[int(v)] for v in os.environ["MCVD_WEXP_CASES"].split(",")]
+    if os.environ.get("MCVD_WEXP_ONLY"):
+        keep = [int(v) for v in os.environ["MCVD_WEXP_ONLY"].split(",")]
+        labels = {k: v for k, v in labels.items() if k in keep}
+    f.write("# winograd K-loop ablations, B=64, conv_wino_kernel<3,2,false>; ideal MFMA time per chunk per SIMD = 4 waves x 24 x 64 = 6144 cycles\n")
+    ctx.opt("conv_shape", 4)
+    for cin, cout, H in cases:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda")
+        for e, lab in labels.items():
+            os.environ["MCVD_WINO_EXP"] = str(e)
+            for _ in range(2):
+                ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 4
+            per = []
+            for wv in (0, 15):
+                os.environ["MCVD_DBG_WAVE"] = str(wv)
+                dbg = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
+                _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
+                ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+                torch.cuda.synchronize()
+                _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
+                d = dbg.view(-1, 8).cpu().double()
+                d = d[d[:, 7] > 0]
+                m = d.mean(0)
+                per.append((m[0].item(), m[1].item() / max(m[6].item(), 1), m[5].item(), m[7].item()))
+            f.write(f"cin{cin} cout{cout} H{H} exp{e:4d} {lab:40s}: kernel {us:7.1f} us | wave0 pro {per[0][0]:6.0f} loop/chunk {per[0][1]:6.0f} epi {per[0][2]:6.0f} total {per[0][3]:7.0f}"
+                    f" | wave15 pro {per[1][0]:6.0f} loop/chunk {per[1][1]:6.0f} epi {per[1][2]:6.0f} total {per[1][3]:7.0f}\n")
+            f.flush()
+    os.environ["MCVD_WINO_EXP"] = "0"
+    ctx.opt("conv_shape", -1)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["precision", "ops", "sweep"]
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 

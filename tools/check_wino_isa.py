@@ -29,7 +29,7 @@ def _regs(text):
 
 def check(asm_text):
     problems, seen = [], 0
-    for m in re.finditer(r"^(_ZN4mcvd16conv_wino_kernelILi(\d)ELi(\d)ELb(\d)EEEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN4mcvd16conv_wino_kernelILi(\d)ELi(\d)ELb(\d)E(?:Li0E)?EEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
         name, cot, g8, body = m.group(1), int(m.group(2)), int(m.group(4)), m.group(5)
         npatch = 2 if g8 else 3                                        # patch loads per thread and chunk (MAXP)
         seen += 1
