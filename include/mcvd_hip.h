@@ -69,6 +69,9 @@ typedef struct mcvd_unet_desc {
     int32_t sigma_dist;        /* 0 = linear, 1 = cosine (models/__init__.py:16-35) */
     float sigma_begin;         /* model.sigma_begin */
     float sigma_end;           /* model.sigma_end */
+    int32_t cond_emb;          /* model.cond_emb: Embedding(2, ngf/2) of the per-sample cond_mask concatenated to temb (ncsnpp_more.py:97-99, :282-286) */
+    int32_t noise_in_cond;     /* model.noise_in_cond: every forward diffuses the conditioning frames to the level of its labels (:755-768) */
+    int32_t gamma;             /* model.gamma: gamma-distributed noise (ncsnpp_more.py:744-749, :761-765; models/__init__.py:273-276, :319-322) */
 } mcvd_unet_desc;
 
 /* sampler kinds / flags (models/__init__.py) */
@@ -77,6 +80,7 @@ typedef struct mcvd_unet_desc {
 #define MCVD_FLAG_DENOISE 1      /* denoise=True  (:331-333) */
 #define MCVD_FLAG_CLIP_BEFORE 2  /* clip_before=True (:288-289) */
 #define MCVD_FLAG_JUST_BETA 4    /* just_beta=True (:325-326) */
+#define MCVD_FLAG_GAMMA 8        /* gamma=True: step / re-noise draws are standardised gamma variates (:273-276, :319-322) */
 
 /* ---- context ---------------------------------------------------------------------- */
 int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out);
@@ -133,6 +137,20 @@ int mcvd_unet_forward(mcvd_model* m, const float* x, const int64_t* labels, cons
 /* Same forward with float timesteps t:[B] (device pointer), which may be fractional or negative: the F-PNDM sampler evaluates the
  * network at (t + t_next) / 2 (models/pndm.py:42) and the reference's embedding takes timesteps.float() (layers.py:504-518). */
 int mcvd_unet_forward_ft(mcvd_model* m, const float* x, const float* t, const float* cond, float* eps_out, int B);
+/* The same forward with the per-sample conditioning mask of `model.cond_emb` nets: cond_mask:[B] int32 (0 / 1, device) or NULL
+ * (= all ones, what every sampler passes: models/__init__.py:263 binds only cond).  NULL-equivalent for nets without cond_emb. */
+int mcvd_unet_forward_masked(mcvd_model* m, const float* x, const int64_t* labels, const float* cond, const int32_t* cond_mask,
+                             float* eps_out, int B);
+/* `model.noise_in_cond` nets draw z ~ N(0,1) shaped like cond in EVERY forward and feed sqrt(a[t]) cond + sqrt(1 - a[t]) z
+ * (a = alphas, t = the row's label) to the network (ncsnpp_more.py:755-768).  This sets where the following forwards take z from:
+ * z_device != NULL: [n, B, C*nc, S, S] consumed one [B, ...] slab per forward (parity runs, or z drawn by the caller the way the
+ * reference does with torch); NULL: the on-device Philox stream keyed by (seed, sample_offset + row, forward counter), continuing
+ * from first_draw.  With model.gamma the caller passes z already standardised ((g - k theta) / sqrt(1 - a), :761-765) or lets the
+ * library draw it (mcvd_sampler_run only: all rows share the label there). */
+int mcvd_model_set_cond_noise(mcvd_model* m, const float* z_device, uint64_t seed, uint64_t sample_offset, uint64_t first_draw);
+/* Gamma-noise tables of `model.gamma` nets exactly as UNetMore_DDPM registers them (k_cum, theta_t: ncsnpp_more.py:745-749); host
+ * pointers, n = num_classes.  Required before mcvd_sampler_run with MCVD_FLAG_GAMMA. */
+int mcvd_model_set_gamma_tables(mcvd_model* m, const float* k_cum_host, const float* theta_t_host, int n);
 /* SPADE models (model.spade): the gamma/beta modulation maps depend only on the conditioning frames (layerspp.py:164-168), so
  * they are computed by mcvd_model_prepare_cond and cached; later forwards that pass the SAME cond pointer and batch size reuse
  * them until mcvd_model_invalidate_cond / another prepare (the caller promises not to modify cond in between).  A forward whose
@@ -168,7 +186,9 @@ int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst_device
 /* The whole L-step loop on device: schedule subsampling (:229-237), labels, forward, x0/clip/posterior (+noise),
  * t_min re-noise (:269-280), denoise pass with label L-1 (:331-333).  x_inout:[B,C*nf,S,S] is overwritten.
  * noise: NULL -> counter-based Philox keyed by (seed, sample_offset + row, step) so results do not depend on how rows are
- * sharded over GPUs; else [n_draws, B, C*nf, S, S] consumed in draw order (t_min draw first, then one per step). */
+ * sharded over GPUs; else [n_draws, B, C*nf, S, S] consumed in draw order (t_min draw first, then one per step).
+ * MCVD_FLAG_GAMMA: the draws are gamma variates g ~ Gamma(k_cum[i], scale theta_t[i]) standardised as (g - k theta) / sqrt(1 - a_i);
+ * an injected `noise` then holds the RAW g (what Gamma(...).sample() returns in the reference). */
 int mcvd_sampler_run(mcvd_model* m, int kind, float* x_inout, const float* cond, const float* noise, uint64_t seed,
                      uint64_t sample_offset, int subsample_steps, int flags, float t_min, int B);
 /* One fused update (host-driven loops, final_only=False / verbose paths).  Coefficients are the fp32 scalars the
@@ -178,6 +198,11 @@ int mcvd_sampler_update(mcvd_ctx* ctx, int kind, float* x_inout, const float* ep
 /* z ~ N(0,1) from the same Philox stream mcvd_sampler_run uses: out:[B, per_sample]. */
 int mcvd_randn(mcvd_ctx* ctx, float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B,
                int64_t per_sample);
+/* Standardised gamma noise of the `gamma=True` samplers (models/__init__.py:273-276, :319-322): out = (g - kt) / sd, g = raw[i]
+ * when raw != NULL (a Gamma(k, rate 1/theta).sample() drawn elsewhere) else theta * Gamma(k) from the library's Philox stream;
+ * kt = k * theta and sd = sqrt(1 - alpha_i) are passed as the fp32 scalars the reference computes.  out:[B, per_sample]. */
+int mcvd_gamma_noise(mcvd_ctx* ctx, float* out, const float* raw, float k, float theta, float kt, float sd, uint64_t seed,
+                     uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample);
 /* F-PNDM building blocks (models/pndm.py), fp32 with one rounding per operation in the order of the reference's tensor
  * expressions (no FMA contraction), n elements, device pointers:
  *   mcvd_lincomb:        out = scale * (((w0*in0 + w1*in1) + w2*in2) + w3*in3), the first nin (1..4) terms; out may alias an input

@@ -21,11 +21,12 @@ class UNetDesc(C.Structure):
                 ("ch_mult", C.c_int32 * MAX_LEVELS), ("num_res_blocks", C.c_int32), ("n_attn", C.c_int32),
                 ("attn_resolutions", C.c_int32 * MAX_LEVELS), ("n_head_channels", C.c_int32), ("spade", C.c_int32),
                 ("spade_dim", C.c_int32), ("num_classes", C.c_int32), ("sigma_dist", C.c_int32),
-                ("sigma_begin", C.c_float), ("sigma_end", C.c_float)]
+                ("sigma_begin", C.c_float), ("sigma_end", C.c_float), ("cond_emb", C.c_int32), ("noise_in_cond", C.c_int32),
+                ("gamma", C.c_int32)]
 
 
 SAMPLER_DDPM, SAMPLER_DDIM = 0, 1
-FLAG_DENOISE, FLAG_CLIP_BEFORE, FLAG_JUST_BETA = 1, 2, 4
+FLAG_DENOISE, FLAG_CLIP_BEFORE, FLAG_JUST_BETA, FLAG_GAMMA = 1, 2, 4, 8
 
 _vp, _i, _f, _i64, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64
 _PROTOS = {
@@ -50,6 +51,9 @@ _PROTOS = {
     "mcvd_model_set_temb_freqs": (_i, [_vp, _vp, _i]),
     "mcvd_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     "mcvd_unet_forward_ft": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
+    "mcvd_unet_forward_masked": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "mcvd_model_set_cond_noise": (_i, [_vp, _vp, _u64, _u64, _u64]),
+    "mcvd_model_set_gamma_tables": (_i, [_vp, _vp, _vp, _i]),
     "mcvd_model_prepare_cond": (_i, [_vp, _vp, _i]),
     "mcvd_model_invalidate_cond": (_i, [_vp]),
     "mcvd_model_num_launches": (_i, [_vp, _i]),
@@ -63,6 +67,7 @@ _PROTOS = {
     "mcvd_sampler_run": (_i, [_vp, _i, _vp, _vp, _vp, _u64, _u64, _i, _i, _f, _i]),
     "mcvd_sampler_update": (_i, [_vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _i64]),
     "mcvd_randn": (_i, [_vp, _vp, _u64, _u64, _u64, _i, _i64]),
+    "mcvd_gamma_noise": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _u64, _u64, _u64, _i, _i64]),
     "mcvd_lincomb": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _i64]),
     "mcvd_pndm_transfer": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _i64]),
     "mcvd_upfirdn2d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i]),

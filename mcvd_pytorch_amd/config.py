@@ -28,18 +28,12 @@ def load_config(path, config_mod=()):
     return dict2namespace(cfg)
 
 
-_UNSUPPORTED_FLAGS = ("cond_emb", "noise_in_cond", "gamma", "output_all_frames")
-
-
 def desc_from_config(config):
     """mcvd_unet_desc from config.data / config.model (keys: SURVEY section 5 'config')."""
     d, m = config.data, config.model
     arch = getattr(m, "arch", "unetmore")
     if arch != "unetmore":
         raise NotImplementedError(f"model.arch={arch!r}: only 'unetmore' (2-D) is on the accelerated path")
-    for flag in _UNSUPPORTED_FLAGS:
-        if getattr(m, flag, False):
-            raise NotImplementedError(f"model.{flag}=True is not supported by the HIP path")
     if not getattr(m, "time_conditional", True):
         raise NotImplementedError("model.time_conditional=False is not supported by the HIP path")
     desc = _lib.UNetDesc()
@@ -69,4 +63,10 @@ def desc_from_config(config):
     desc.sigma_dist = 0 if dist == "linear" else 1
     desc.sigma_begin = float(m.sigma_begin)
     desc.sigma_end = float(m.sigma_end)
+    # SURVEY 8f rank 4 flags.  `output_all_frames` needs no descriptor field: in the reference's `unetmore` net the last conv always
+    # has C*num_frames outputs, so the flag only adds a torch.split that cannot succeed when cond is given (ncsnpp_more.py:384-385);
+    # HipScoreNet reproduces that failure at call time.
+    desc.cond_emb = 1 if getattr(m, "cond_emb", False) else 0
+    desc.noise_in_cond = 1 if getattr(m, "noise_in_cond", False) else 0
+    desc.gamma = 1 if getattr(m, "gamma", False) else 0
     return desc

@@ -174,6 +174,9 @@ void mcvd_model_destroy(mcvd_model* m) {
     if (m->labels) (void)hipFree(m->labels);
     if (m->eps_buf) (void)hipFree(m->eps_buf);
     if (m->ksplit_buf) (void)hipFree(m->ksplit_buf);
+    if (m->alphas_dev) (void)hipFree(m->alphas_dev);
+    if (m->cond_z) (void)hipFree(m->cond_z);
+    if (m->noise_buf) (void)hipFree(m->noise_buf);
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     delete m;
 }
@@ -282,6 +285,23 @@ int mcvd_model_set_schedule(mcvd_model* m, const float* betas, const float* alph
     m->betas.assign(betas, betas + n);
     m->alphas.assign(alphas, alphas + n);
     m->alphas_prev.assign(alphas_prev, alphas_prev + n);
+    m->alphas_dev_valid = false;
+    return 0;
+}
+
+int mcvd_model_set_gamma_tables(mcvd_model* m, const float* k_cum, const float* theta_t, int n) {
+    MCVD_REQUIRE(m && k_cum && theta_t && n == m->d.num_classes, "set_gamma_tables: bad arguments");
+    m->k_cum.assign(k_cum, k_cum + n);
+    m->theta_t.assign(theta_t, theta_t + n);
+    return 0;
+}
+
+int mcvd_model_set_cond_noise(mcvd_model* m, const float* z_device, uint64_t seed, uint64_t sample_offset, uint64_t first_draw) {
+    MCVD_REQUIRE(m, "set_cond_noise: NULL model");
+    m->cond_noise_src = z_device;
+    m->cond_noise_seed = seed;
+    m->cond_noise_offset = sample_offset;
+    m->cond_noise_draw = first_draw;
     return 0;
 }
 
@@ -300,6 +320,17 @@ int mcvd_unet_forward(mcvd_model* m, const float* x, const int64_t* labels, cons
     API_TRY
     MCVD_REQUIRE(m, "forward: NULL model");
     return m->forward(x, labels, cond, eps_out, B);
+    API_CATCH
+}
+
+int mcvd_unet_forward_masked(mcvd_model* m, const float* x, const int64_t* labels, const float* cond, const int32_t* cond_mask,
+                             float* eps_out, int B) {
+    API_TRY
+    MCVD_REQUIRE(m, "forward: NULL model");
+    m->cond_mask = cond_mask;
+    const int rc = m->forward(x, labels, cond, eps_out, B);
+    m->cond_mask = nullptr;
+    return rc;
     API_CATCH
 }
 
@@ -485,20 +516,50 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
     struct CacheGuard { mcvd_model* m; ~CacheGuard() { m->cond_cache_valid = false; } } guard{m};
     hipStream_t s = m->ctx->stream;
     m->profile_armed = true;          // with option "profile": the first forward of this call is event-instrumented
-    const int use_philox = noise ? 0 : 1;
+    const bool gam = (flags & MCVD_FLAG_GAMMA) != 0;
+    if (gam) {
+        MCVD_REQUIRE(kind == MCVD_SAMPLER_DDPM, "sampler_run: gamma noise exists for the DDPM sampler only");
+        MCVD_REQUIRE(m->d.gamma && (int)m->k_cum.size() == T && m->noise_buf, "sampler_run: MCVD_FLAG_GAMMA needs a model.gamma net "
+                     "with mcvd_model_set_gamma_tables");
+    }
+    const bool cond_lib_noise = m->d.noise_in_cond && m->d.num_frames_cond > 0 && !m->cond_noise_src;
+    if (cond_lib_noise) {             // conditioning noise from the library's own stream for this call
+        m->cond_noise_seed = seed;
+        m->cond_noise_offset = sample_offset;
+        m->cond_noise_draw = 0;
+    }
+    struct CondGammaGuard { mcvd_model* m; ~CondGammaGuard() { m->cond_gamma_k = 0.f; } } cg_guard{m};
+    auto set_cond_gamma = [&](int label) {         // ncsnpp_more.py:761-765: k_cum[labels], theta_t[labels], alphas[labels]
+        if (!(gam && m->d.noise_in_cond)) return;
+        m->cond_gamma_k = m->k_cum[label];
+        m->cond_gamma_theta = m->theta_t[label];
+        m->cond_gamma_kt = m->k_cum[label] * m->theta_t[label];
+        m->cond_gamma_sd = sqrtf(1.0f - m->alphas[label]);
+    };
+    const int use_philox = (noise || gam) ? 0 : 1;
     uint64_t draw = 0;
     bool started = false;
+    // gamma: z_i = (g - k_i theta_i) / sqrt(1 - a_i), g ~ Gamma(k_i, scale theta_i) or the injected raw draw  (:273-276, :319-322)
+    auto gamma_draw = [&](int i) -> int {
+        const float k = m->k_cum[steps[i]], th = m->theta_t[steps[i]];
+        return launch_gamma_noise(m->noise_buf, noise ? noise + draw * n : nullptr, k, th, k * th, sqrtf(1.0f - al[i]), seed, sample_offset,
+                                  draw, B, per, s);
+    };
     for (int i = 0; i < L; ++i) {
         if ((double)steps[i] < (double)t_min * (double)L) continue;                       // :269-270
         const float a = al[i], ap = alp[i], b = be[i];
         if (!started && t_min > 0.0f) {                                                   // :272-279
-            if (int rc = launch_renoise(x, noise ? noise + draw * n : nullptr, sqrtf(a), sqrtf(1.0f - a), n, use_philox, seed,
-                                        sample_offset, draw, per, s))
+            if (gam) {
+                if (int rc = gamma_draw(i)) return rc;
+            }
+            if (int rc = launch_renoise(x, gam ? m->noise_buf : (noise ? noise + draw * n : nullptr), sqrtf(a), sqrtf(1.0f - a), n,
+                                        use_philox, seed, sample_offset, draw, per, s))
                 return rc;
             ++draw;
         }
         started = true;
         if (int rc = launch_fill_labels(m->labels, steps[i], B, s)) return rc;           // :283
+        set_cond_gamma(steps[i]);
         if (int rc = m->forward(x, m->labels, cond, m->eps_buf, B)) return rc;           // :284
         const float c_x0a = 1.0f / sqrtf(a), c_x0b = sqrtf(1.0f - a);                    // :287
         float c0, c1, cn = 0.0f;
@@ -512,7 +573,10 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
             c1 = sqrtf(1.0f - ap);
         }
         const bool draws = (kind == MCVD_SAMPLER_DDPM) && (i + 1 != L);
-        if (int rc = launch_sampler_update(kind, x, m->eps_buf, (noise && draws) ? noise + draw * n : nullptr, c_x0a, c_x0b, c0,
+        if (draws && gam)
+            if (int rc = gamma_draw(i)) return rc;
+        const float* zsrc = !draws ? nullptr : (gam ? m->noise_buf : (noise ? noise + draw * n : nullptr));
+        if (int rc = launch_sampler_update(kind, x, m->eps_buf, zsrc, c_x0a, c_x0b, c0,
                                            c1, cn, (flags & MCVD_FLAG_CLIP_BEFORE) ? 1 : 0, n, (draws && use_philox) ? 1 : 0,
                                            seed, sample_offset, draw, per, s))
             return rc;
@@ -520,6 +584,7 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
     }
     if (flags & MCVD_FLAG_DENOISE) {                                                      // :331-333, label L-1 (sic)
         if (int rc = launch_fill_labels(m->labels, L - 1, B, s)) return rc;
+        set_cond_gamma(L - 1);
         if (int rc = m->forward(x, m->labels, cond, m->eps_buf, B)) return rc;
         if (int rc = launch_axpy_out(x, m->eps_buf, sqrtf(1.0f - al[L - 1]), n, s)) return rc;
     }
@@ -532,6 +597,12 @@ int mcvd_sampler_update(mcvd_ctx* ctx, int kind, float* x, const float* eps, con
     MCVD_REQUIRE(ctx && x && eps, "sampler_update: NULL argument");
     return launch_sampler_update(kind, x, eps, noise, c_x0a, c_x0b, c_mean0, c_mean1, c_noise, clip, n, 0, 0, 0, 0, 4,
                                  ctx->stream);
+}
+
+int mcvd_gamma_noise(mcvd_ctx* ctx, float* out, const float* raw, float k, float theta, float kt, float sd, uint64_t seed,
+                     uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample) {
+    MCVD_REQUIRE(ctx && out, "gamma_noise: NULL argument");
+    return launch_gamma_noise(out, raw, k, theta, kt, sd, seed, sample_offset, draw, B, per_sample, ctx->stream);
 }
 
 int mcvd_randn(mcvd_ctx* ctx, float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample) {

@@ -127,8 +127,10 @@ int launch_nearest_resize(const float* in, float* out, int BC, int H, int W, int
 // ------------------------------------------------------------------ time embedding
 // silu_temb[b][:] = SiLU( W1 * SiLU(W0 * emb(t_b) + b0) + b1 )      (ncsnpp_more.py:273-280 + layerspp.py:521)
 // labels: int64 [B], or float [B] when labels_f32 (fractional timesteps of the F-PNDM sampler)
+// cond_emb: the row continues with SiLU(emb_table[mask_b][0 .. nf/2)) at column 4*nf (mask NULL = 1); out_stride = row length
 int launch_temb_mlp(const void* labels, int labels_f32, const float* freqs, const float* w0, const float* b0, const float* w1,
-                    const float* b1, float* silu_temb, int B, int nf, hipStream_t s);
+                    const float* b1, float* silu_temb, int B, int nf, int out_stride, const float* emb_table, const int32_t* mask,
+                    hipStream_t s);
 // out[b][n] = sum_k act[b][k] * wt[k][n] + bias[n]   (all Dense_0 projections of a forward in one launch)
 int launch_dense_all(const float* act, const float* wt, const float* bias, float* out, int B, int K, int N,
                      hipStream_t s);
@@ -145,6 +147,13 @@ int launch_renoise(float* x, const float* noise, float ca, float cb, int64_t n, 
 int launch_axpy_out(float* x, const float* eps, float c, int64_t n, hipStream_t s);   // x -= c * eps
 int launch_randn(float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample,
                  hipStream_t s);
+// standardised gamma variates (models/__init__.py:273-276, :319-322): out = (g - kt) / sd with g = raw[i] when raw != NULL, else
+// g = theta * Gamma(k) drawn from the Philox stream (Marsaglia-Tsang); kt = k * theta and sd = sqrt(1 - alpha) as fp32 scalars
+int launch_gamma_noise(float* out, const float* raw, float k, float theta, float kt, float sd, uint64_t seed,
+                       uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample, hipStream_t s);
+// noise_in_cond (ncsnpp_more.py:755-768): out[b] = sqrt(alphas[t_b]) * cond[b] + sqrt(1 - alphas[t_b]) * z[b], t_b = labels[b]
+int launch_cond_noise(const float* cond, const float* z, const float* alphas_dev, const int64_t* labels, int T, float* out, int B,
+                      int64_t per_sample, hipStream_t s);
 // out = scale * sum_k w[k] * in[k], k < nin <= 4 (left-to-right, separately rounded, as the reference's tensor expression);
 // out may alias an input
 int launch_lincomb(float* out, const float* const* in, const float* w, float scale, int nin, int64_t n, hipStream_t s);

@@ -40,6 +40,94 @@ __device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint64_t sample,
     return make_float4(r0 * cs0, r0 * s0, r1 * cs1, r1 * s1);
 }
 
+// 4 uniforms in (0,1) for counter (sample, draw, ctr); the gamma sampler's stream (bit 39 of the draw word keeps it apart from
+// the normal stream of the same draw index)
+__device__ __forceinline__ float4 philox_uniform4(uint64_t seed, uint64_t sample, uint64_t draw, uint64_t ctr) {
+    draw |= (1ull << 39);
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32) ^ (uint32_t)(draw << 8), c2 = (uint32_t)sample,
+             c3 = (uint32_t)(sample >> 32) ^ (uint32_t)(draw >> 24);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float sc = 1.0f / 16777216.0f;
+    return make_float4(((float)(c0 >> 8) + 0.5f) * sc, ((float)(c1 >> 8) + 0.5f) * sc, ((float)(c2 >> 8) + 0.5f) * sc,
+                       ((float)(c3 >> 8) + 0.5f) * sc);
+}
+
+// Gamma(shape k, scale 1) by Marsaglia & Tsang (2000): d = k - 1/3, c = 1/sqrt(9 d); x ~ N(0,1), v = (1 + c x)^3, accept when
+// v > 0 and log u < x^2/2 + d - d v + d log v.  k < 1 uses Gamma(k + 1) * u^(1/k).  Acceptance > 95 % for k >= 1; after 8 rejections
+// the last candidate is kept (probability < 1e-10).  Counter-based: element e, attempt j -> Philox counter 8 e + j.
+__device__ float philox_gamma(float k, uint64_t seed, uint64_t sample, uint64_t draw, uint64_t elem) {
+    const float kk = k < 1.0f ? k + 1.0f : k;
+    const float d = kk - (1.0f / 3.0f), c = rsqrtf(9.0f * d);
+    float g = d;
+    for (int j = 0; j < 8; ++j) {
+        const float4 u = philox_uniform4(seed, sample, draw, elem * 8 + (uint64_t)j);
+        const float r = sqrtf(-2.0f * logf(u.x));
+        const float x = r * cosf(6.283185307179586f * u.y);
+        const float t = 1.0f + c * x;
+        const float v = t * t * t;
+        g = d * fmaxf(v, 1e-30f);
+        if (v > 0.0f && logf(u.z) < 0.5f * x * x + d - d * v + d * logf(v)) {
+            if (k < 1.0f) g *= powf(u.w, 1.0f / k);
+            break;
+        }
+    }
+    return g;
+}
+
+__global__ __launch_bounds__(256) void gamma_noise_kernel(float* out, const float* raw, float k, float theta, float kt, float sd,
+                                                           uint64_t seed, uint64_t sample_offset, uint64_t draw, int64_t n,
+                                                           int64_t per_sample) {
+    for (int64_t i = blockIdx.x * 256L + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float g;
+        if (raw) {
+            g = raw[i];
+        } else {
+            const int64_t row = i / per_sample;
+            g = theta * philox_gamma(k, seed, sample_offset + (uint64_t)row, draw, (uint64_t)(i - row * per_sample));
+        }
+        out[i] = (g - kt) / sd;                       // (z - ks_cum[i] * thetas[i]) / (1 - alphas[i]).sqrt()
+    }
+}
+
+int launch_gamma_noise(float* out, const float* raw, float k, float theta, float kt, float sd, uint64_t seed,
+                       uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample, hipStream_t s) {
+    MCVD_REQUIRE(out && (raw || (k > 0.0f && theta > 0.0f)) && sd > 0.0f, "gamma_noise: bad arguments (k=%g theta=%g sd=%g)", k, theta, sd);
+    const int64_t n = (int64_t)B * per_sample;
+    const int grid = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+    hipLaunchKernelGGL(gamma_noise_kernel, dim3(grid), dim3(256), 0, s, out, raw, k, theta, kt, sd, seed, sample_offset, draw, n,
+                       per_sample);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// out[b] = sqrt(a_b) * cond[b] + sqrt(1 - a_b) * z[b],  a_b = alphas[labels[b]]        ncsnpp_more.py:758, :768
+__global__ __launch_bounds__(256) void cond_noise_kernel(const float* cond, const float* z, const float* alphas, const int64_t* labels,
+                                                          int T, float* out, int64_t n, int64_t per_sample) {
+    for (int64_t i = blockIdx.x * 256L + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / per_sample;
+        int64_t t = labels[row];
+        t = t < 0 ? t + T : t;                        // torch indexing wraps negative labels
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const float a = alphas[t];
+        out[i] = sqrtf(a) * cond[i] + sqrtf(1.0f - a) * z[i];
+    }
+}
+
+int launch_cond_noise(const float* cond, const float* z, const float* alphas_dev, const int64_t* labels, int T, float* out, int B,
+                      int64_t per_sample, hipStream_t s) {
+    MCVD_REQUIRE(cond && z && alphas_dev && labels && out, "cond_noise: NULL argument");
+    const int64_t n = (int64_t)B * per_sample;
+    const int grid = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+    hipLaunchKernelGGL(cond_noise_kernel, dim3(grid), dim3(256), 0, s, cond, z, alphas_dev, labels, T, out, n, per_sample);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 __global__ void fill_labels_kernel(int64_t* labels, int64_t v, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) labels[i] = v;

@@ -10,7 +10,8 @@ __device__ __forceinline__ float silu_t(float v) { return v / (1.0f + expf(-v));
 // one workgroup per sample; hidden width T = 4*nf <= 1024 (nf <= 256)
 __global__ __launch_bounds__(256) void temb_mlp_kernel(const void* labels, int labels_f32, const float* freqs, const float* w0,
                                                         const float* b0, const float* w1, const float* b1,
-                                                        float* silu_temb, int nf) {
+                                                        float* silu_temb, int nf, int out_stride, const float* emb_table,
+                                                        const int32_t* mask) {
     __shared__ float emb[256];
     __shared__ float hid[1024];
     const int b = blockIdx.x;
@@ -36,14 +37,20 @@ __global__ __launch_bounds__(256) void temb_mlp_kernel(const void* labels, int l
         const float* w = w1 + (long)o * T;
         float acc = 0.0f;
         for (int k = 0; k < T; ++k) acc = fmaf(hid[k], w[k], acc);
-        silu_temb[(long)b * T + o] = silu_t(acc + b1[o]);
+        silu_temb[(long)b * out_stride + o] = silu_t(acc + b1[o]);
+    }
+    if (emb_table) {        // cond_emb: temb = cat([temb, Embedding(cond_mask)]) (ncsnpp_more.py:282-285); Dense_0 sees SiLU of it
+        const int mb = mask ? (mask[b] != 0 ? 1 : 0) : 1;
+        for (int j = threadIdx.x; j < half; j += 256) silu_temb[(long)b * out_stride + T + j] = silu_t(emb_table[mb * half + j]);
     }
 }
 
 int launch_temb_mlp(const void* labels, int labels_f32, const float* freqs, const float* w0, const float* b0, const float* w1,
-                    const float* b1, float* silu_temb, int B, int nf, hipStream_t s) {
+                    const float* b1, float* silu_temb, int B, int nf, int out_stride, const float* emb_table, const int32_t* mask,
+                    hipStream_t s) {
     MCVD_REQUIRE(nf <= 256 && nf >= 4, "temb: ngf=%d out of range [4,256]", nf);
-    hipLaunchKernelGGL(temb_mlp_kernel, dim3(B), dim3(256), 0, s, labels, labels_f32, freqs, w0, b0, w1, b1, silu_temb, nf);
+    hipLaunchKernelGGL(temb_mlp_kernel, dim3(B), dim3(256), 0, s, labels, labels_f32, freqs, w0, b0, w1, b1, silu_temb, nf,
+                       out_stride, emb_table, mask);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -51,7 +58,7 @@ int launch_temb_mlp(const void* labels, int labels_f32, const float* freqs, cons
 // out[b][n] = bias[n] + sum_k act[b][k] * wt[k][n].  Block: 256 outputs n x 8 samples; act rows staged in LDS.
 __global__ __launch_bounds__(256) void dense_all_kernel(const float* act, const float* wt, const float* bias, float* out,
                                                          int B, int K, int N) {
-    __shared__ float sa[8 * 1024];
+    __shared__ float sa[8 * 1152];
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int b0 = blockIdx.y * 8;
     const int nb = (B - b0) < 8 ? (B - b0) : 8;
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(256) void dense_all_kernel(const float* act, const 
 
 int launch_dense_all(const float* act, const float* wt, const float* bias, float* out, int B, int K, int N,
                      hipStream_t s) {
-    MCVD_REQUIRE(K <= 1024, "dense_all: K=%d > 1024", K);
+    MCVD_REQUIRE(K <= 1152, "dense_all: K=%d > 1152", K);
     hipLaunchKernelGGL(dense_all_kernel, dim3((N + 255) / 256, (B + 7) / 8), dim3(256), 0, s, act, wt, bias, out, B, K, N);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;

@@ -116,7 +116,7 @@ struct Builder {
         const int cond_ch = m.d.channels * m.d.num_frames_cond;
         TRef seg = alloc(cond_ch, R);
         Op op{};
-        op.kind = OP_NEAREST; op.module = -1; op.prep = true; op.src0 = TRef{REF_COND, 0, cond_ch}; op.dst = seg;
+        op.kind = OP_NEAREST; op.module = -1; op.prep = true; op.src0 = m.cond_src; op.dst = seg;
         op.H = op.W = R;
         m.ops.push_back(op);
         seg_by_res[R] = seg;
@@ -356,22 +356,34 @@ int mcvd_model::build_plan() {
     MCVD_REQUIRE(c.channels > 0 && c.num_frames > 0 && c.num_frames_cond >= 0, "desc: frames/channels");
     MCVD_REQUIRE(!c.spade || (c.num_frames_cond > 0 && c.spade_dim > 0), "desc: spade needs conditioning frames and spade_dim");
     MCVD_REQUIRE(c.num_classes >= 2, "desc: num_classes=%d", c.num_classes);
+    MCVD_REQUIRE(!c.cond_emb || c.ngf % 2 == 0, "desc: cond_emb needs an even ngf");
     const int nf = c.ngf, C = c.channels, L = c.n_levels, S = c.image_size;
-    T = 4 * nf;
+    T = 4 * nf + (c.cond_emb ? nf / 2 : 0);          // temb_dim (ncsnpp_more.py:95-99)
     NE = 0;
     Builder bld(*this);
 
     // modules 0,1: time MLP (ncsnpp_more.py:88-95)
-    add_param("unet.all_modules.0.weight", {T, nf});
-    add_param("unet.all_modules.0.bias", {T});
-    add_param("unet.all_modules.1.weight", {T, T});
-    add_param("unet.all_modules.1.bias", {T});
+    add_param("unet.all_modules.0.weight", {4 * nf, nf});
+    add_param("unet.all_modules.0.bias", {4 * nf});
+    add_param("unet.all_modules.1.weight", {4 * nf, 4 * nf});
+    add_param("unet.all_modules.1.bias", {4 * nf});
+    if (c.cond_emb) add_param("unet.all_modules.2.weight", {2, nf / 2});      // nn.Embedding(2, nf // 2), ncsnpp_more.py:98
+    first_module = c.cond_emb ? 3 : 2;
     Op temb{};
     temb.kind = OP_TEMB; temb.module = 1;      // output = SiLU(module 1's output), what every Dense_0 consumes
     ops.push_back(temb);
     Op dense_op{};
     dense_op.kind = OP_DENSE; dense_op.module = -1;
     ops.push_back(dense_op);
+    // conditioning frames as the network sees them: the caller's tensor, or (noise_in_cond) its diffused copy made per forward
+    const int cond_ch_all = C * c.num_frames_cond;
+    cond_src = TRef{REF_COND, 0, cond_ch_all};
+    if (c.noise_in_cond && c.num_frames_cond > 0) {
+        cond_src = bld.alloc(cond_ch_all, S);
+        Op cn{};
+        cn.kind = OP_CONDNOISE; cn.module = -1; cn.src0 = TRef{REF_COND, 0, cond_ch_all}; cn.dst = cond_src; cn.H = cn.W = S;
+        ops.push_back(cn);
+    }
 
     auto in_attn = [&](int res) {
         for (int i = 0; i < c.n_attn; ++i)
@@ -379,11 +391,12 @@ int mcvd_model::build_plan() {
         return false;
     };
 
-    // module 2: stem conv over [x, cond] (ncsnpp_more.py:188, :257)
-    int idx = 2;
+    // stem conv over [x, cond] (ncsnpp_more.py:188, :257)
+    int idx = first_module;
     const int cx = C * c.num_frames, cc = c.spade ? 0 : C * c.num_frames_cond;
-    add_param("unet.all_modules.2.weight", {nf, cx + cc, 3, 3});
-    add_param("unet.all_modules.2.bias", {nf});
+    const std::string stem = "unet.all_modules." + std::to_string(idx);
+    add_param(stem + ".weight", {nf, cx + cc, 3, 3});
+    add_param(stem + ".bias", {nf});
     std::vector<Act> hs;
     {
         Act h;
@@ -392,8 +405,8 @@ int mcvd_model::build_plan() {
         Op cv{};
         cv.kind = OP_CONV; cv.module = idx; cv.H = cv.W = S; cv.dst = h.a;
         cv.src0 = TRef{REF_X, 0, cx};
-        if (cc > 0) cv.src1 = TRef{REF_COND, 0, cc};
-        bld.conv_pack(cv, {"unet.all_modules.2.weight"}, {"unet.all_modules.2.bias"}, nf, cx + cc, 3, 0);
+        if (cc > 0) cv.src1 = cond_src;
+        bld.conv_pack(cv, {stem + ".weight"}, {stem + ".bias"}, nf, cx + cc, 3, 0);
         ops.push_back(cv);
         hs.push_back(h);
     }
@@ -496,6 +509,10 @@ int mcvd_model::build_plan() {
     freqs_off = bld.alloc_packed(nf / 2);
     arena_per_sample = bld.arena;
     packed_floats = bld.packed;
+    if (c.noise_in_cond) {            // gamma/beta depend on the noised conditioning frames: nothing can be hoisted out of the step
+        for (Op& op : ops) op.prep = false;
+        has_prep = false;
+    }
     return 0;
 }
 
@@ -507,7 +524,9 @@ int mcvd_model::ensure_workspace(int B) {
     if (labels) MCVD_HIP_CHECK(hipFree(labels));
     if (eps_buf) MCVD_HIP_CHECK(hipFree(eps_buf));
     if (ksplit_buf) MCVD_HIP_CHECK(hipFree(ksplit_buf));
-    arena = nullptr; labels = nullptr; eps_buf = nullptr; ksplit_buf = nullptr; arena_B = 0;
+    if (cond_z) MCVD_HIP_CHECK(hipFree(cond_z));
+    if (noise_buf) MCVD_HIP_CHECK(hipFree(noise_buf));
+    arena = nullptr; labels = nullptr; eps_buf = nullptr; ksplit_buf = nullptr; cond_z = nullptr; noise_buf = nullptr; arena_B = 0;
     const size_t per = (size_t)d.channels * d.num_frames * d.image_size * d.image_size;
     MCVD_HIP_CHECK(hipMalloc((void**)&arena, (size_t)arena_per_sample * B * sizeof(float)));
     MCVD_HIP_CHECK(hipMalloc((void**)&labels, (size_t)B * sizeof(int64_t)));
@@ -517,6 +536,9 @@ int mcvd_model::ensure_workspace(int B) {
         if (op.kind == OP_CONV && op.ks == 3 && op.wpw >= 0 && op.H * op.W <= 256)
             kfl = std::max(kfl, (size_t)2 * B * op.Cout * op.H * op.W);
     if (kfl) MCVD_HIP_CHECK(hipMalloc((void**)&ksplit_buf, kfl * sizeof(float)));
+    if (d.noise_in_cond && d.num_frames_cond > 0)
+        MCVD_HIP_CHECK(hipMalloc((void**)&cond_z, (size_t)d.channels * d.num_frames_cond * d.image_size * d.image_size * B * sizeof(float)));
+    if (d.gamma) MCVD_HIP_CHECK(hipMalloc((void**)&noise_buf, per * B * sizeof(float)));
     arena_B = B;
     cond_cache_valid = false;
     tuned_B = 0;
@@ -542,7 +564,9 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             const float* b0 = blob + params[find_param("unet.all_modules.0.bias")].off;
             const float* w1 = blob + params[find_param("unet.all_modules.1.weight")].off;
             const float* b1 = blob + params[find_param("unet.all_modules.1.bias")].off;
-            return launch_temb_mlp(lab, labels_f32, packed + freqs_off, w0, b0, w1, b1, resolve(op.dst, x, cond, out, B), B, d.ngf, s);
+            const float* emb = d.cond_emb ? blob + params[find_param("unet.all_modules.2.weight")].off : nullptr;
+            return launch_temb_mlp(lab, labels_f32, packed + freqs_off, w0, b0, w1, b1, resolve(op.dst, x, cond, out, B), B, d.ngf, T,
+                                   emb, cond_mask, s);
         }
         case OP_DENSE:
             return launch_dense_all(resolve(op.src0, x, cond, out, B), packed + dense_wt, packed + dense_bias,
@@ -614,8 +638,37 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
         }
         case OP_NEAREST:
             MCVD_REQUIRE(cond, "forward: SPADE model needs the conditioning tensor");
-            return launch_nearest_resize(cond, resolve(op.dst, x, cond, out, B), B * op.src0.C, d.image_size, d.image_size,
-                                         op.H, op.W, s);
+            return launch_nearest_resize(resolve(op.src0, x, cond, out, B), resolve(op.dst, x, cond, out, B), B * op.src0.C,
+                                         d.image_size, d.image_size, op.H, op.W, s);
+        case OP_CONDNOISE: {
+            // cond <- sqrt(a[t]) cond + sqrt(1 - a[t]) z, a fresh z per forward (ncsnpp_more.py:755-768)
+            MCVD_REQUIRE(cond, "forward: noise_in_cond model needs the conditioning tensor");
+            MCVD_REQUIRE(!labels_f32, "forward: noise_in_cond indexes alphas with the labels; float timesteps are not valid there");
+            const int64_t per = (int64_t)op.src0.C * d.image_size * d.image_size;
+            if (!alphas_dev) MCVD_HIP_CHECK(hipMalloc((void**)&alphas_dev, (size_t)d.num_classes * sizeof(float)));
+            if (!alphas_dev_valid) {
+                MCVD_HIP_CHECK(hipMemcpyAsync(alphas_dev, alphas.data(), (size_t)d.num_classes * sizeof(float), hipMemcpyHostToDevice, s));
+                alphas_dev_valid = true;
+            }
+            const float* z = cond_noise_src;
+            if (z) {
+                cond_noise_src += per * B;                        // injected sequence: one slab per forward
+            } else {
+                if (cond_gamma_k > 0.0f) {
+                    if (int rc = launch_gamma_noise(cond_z, nullptr, cond_gamma_k, cond_gamma_theta, cond_gamma_kt, cond_gamma_sd,
+                                                    cond_noise_seed, cond_noise_offset, (1ull << 32) + cond_noise_draw, B, per, s))
+                        return rc;
+                } else {
+                    MCVD_REQUIRE(!d.gamma, "forward: a gamma model draws its conditioning noise per row (k_cum[labels]); pass z through "
+                                           "mcvd_model_set_cond_noise or use mcvd_sampler_run");
+                    if (int rc = launch_randn(cond_z, cond_noise_seed, cond_noise_offset, (1ull << 32) + cond_noise_draw, B, per, s)) return rc;
+                }
+                ++cond_noise_draw;
+                z = cond_z;
+            }
+            return launch_cond_noise(cond, z, alphas_dev, static_cast<const int64_t*>(lab), d.num_classes,
+                                     resolve(op.dst, x, cond, out, B), B, per, s);
+        }
         case OP_COEF2:
             return launch_coef2(resolve(ops[1].dst, x, cond, out, B), NE, op.emb_off, resolve(op.dst, x, cond, out, B), B,
                                 op.Cout, s);
@@ -790,12 +843,12 @@ int mcvd_model::forward(const float* x, const void* lab, const float* cond, floa
         }
         return 0;
     }
-    if (ctx->graph) {
+    if (ctx->graph && !d.noise_in_cond) {          // noise_in_cond: every forward has its own noise slab / draw index
         // Replay policy: a pointer set is run eagerly the first time it is seen (kernel attributes get set, nothing unusual
         // happens inside a capture), captured + instantiated the second time, replayed from then on.  The sampler loop
         // presents the same (x, labels, eps, cond, B) for every step of a call.
         GraphKey k;
-        k.x = x; k.lab = lab; k.cond = cond; k.out = out; k.B = B; k.labels_f32 = labels_f32; k.epoch = epoch; k.ctx_epoch = ctx->epoch;
+        k.x = x; k.lab = lab; k.cond = cond; k.out = out; k.B = B; k.labels_f32 = labels_f32; k.mask = cond_mask; k.epoch = epoch; k.ctx_epoch = ctx->epoch;
         if (graph_exec && k == graph_key) {
             MCVD_HIP_CHECK(hipGraphLaunch(graph_exec, ctx->stream));
             ++graph_replays;

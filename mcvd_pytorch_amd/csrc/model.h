@@ -52,7 +52,7 @@ struct TRef {
     int C = 0;
 };
 
-enum OpKind { OP_TEMB, OP_DENSE, OP_GN, OP_CONV, OP_FIR, OP_ATTN, OP_NEAREST, OP_COEF2, OP_APPLY };
+enum OpKind { OP_TEMB, OP_DENSE, OP_GN, OP_CONV, OP_FIR, OP_ATTN, OP_NEAREST, OP_COEF2, OP_APPLY, OP_CONDNOISE };
 
 struct Op {
     OpKind kind;
@@ -118,7 +118,19 @@ struct mcvd_model {
     float* packed = nullptr;          // kernel-layout weights (device)
     int64_t dense_wt = -1, dense_bias = -1, freqs_off = -1;
     int NE = 0;                       // total Dense_0 outputs
-    int T = 0;                        // temb width
+    int T = 0;                        // temb width (4*ngf, + ngf/2 with cond_emb)
+    int first_module = 2;             // all_modules index of the stem conv (3 with cond_emb: module 2 is the mask embedding)
+    mcvd::TRef cond_src;              // what the network reads as conditioning frames: the caller's cond, or its noised copy
+    const int32_t* cond_mask = nullptr;      // cond_emb: mask of the forward in flight (NULL = ones)
+    float* alphas_dev = nullptr;      // [num_classes] device copy of alphas (noise_in_cond)
+    bool alphas_dev_valid = false;
+    float* cond_z = nullptr;          // [arena_B * C*nc*S*S] scratch for the conditioning noise of one forward
+    const float* cond_noise_src = nullptr;   // injected z sequence (advances one slab per forward) or NULL = Philox
+    uint64_t cond_noise_seed = 0, cond_noise_offset = 0, cond_noise_draw = 0;
+    float cond_gamma_kt = 0.f, cond_gamma_sd = 1.f;
+    float* noise_buf = nullptr;       // [arena_B * C*nf*S*S] standardised gamma draws of one sampler step (model.gamma)
+    float cond_gamma_k = 0.f, cond_gamma_theta = 0.f;   // > 0: library-drawn conditioning noise is a standardised gamma variate (sampler loop)
+    std::vector<float> k_cum, theta_t;
 
     int64_t arena_per_sample = 0;     // floats
     float* arena = nullptr;
@@ -153,10 +165,11 @@ struct mcvd_model {
     // hipGraph replay of one forward (ctx option "graph")
     struct GraphKey {
         const float* x = nullptr; const void* lab = nullptr; const float* cond = nullptr; float* out = nullptr;
+        const void* mask = nullptr;
         int B = 0, labels_f32 = 0; unsigned epoch = 0, ctx_epoch = 0;
         bool operator==(const GraphKey& o) const {
-            return x == o.x && lab == o.lab && cond == o.cond && out == o.out && B == o.B && labels_f32 == o.labels_f32 &&
-                   epoch == o.epoch && ctx_epoch == o.ctx_epoch;
+            return x == o.x && lab == o.lab && cond == o.cond && out == o.out && mask == o.mask && B == o.B &&
+                   labels_f32 == o.labels_f32 && epoch == o.epoch && ctx_epoch == o.ctx_epoch;
         }
     };
     GraphKey graph_key, graph_seen;        // key of the instantiated graph / of the last eager forward

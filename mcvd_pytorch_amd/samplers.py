@@ -59,10 +59,13 @@ def _f(t):
 @torch.no_grad()
 def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False, denoise=True, subsample_steps=None,
             same_noise=False, noise_val=None, frac_steps=None, verbose=False, log=False, clip_before=True, t_min=-1,
-            gamma=False, noise=None, seed=None, sample_offset=0, **kwargs):
+            gamma=False, noise=None, seed=None, sample_offset=0, cond_noise=None, **kwargs):
     net = _unwrap(scorenet)
     if gamma:
-        raise NotImplementedError("gamma noise is out of scope of the HIP path (SURVEY 8f rank 4)")
+        if kind != _lib.SAMPLER_DDPM:
+            gamma = False                  # ddim_sampler accepts the kwarg and never reads it (models/__init__.py:102-203)
+        elif not getattr(net, "gamma", False):
+            raise AttributeError("'HipScoreNet' object has no attribute 'k_cum' (gamma=True needs a model.gamma net, models/__init__.py:224)")
     net.sync_parameters(force=True)
     dev = net.device
     x = x_mod.to(device=dev, dtype=torch.float32).contiguous().clone()
@@ -74,7 +77,7 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
         noise = noise.to(device=dev, dtype=torch.float32).contiguous()
     if noise_val is not None:
         noise_val = noise_val.to(device=dev, dtype=torch.float32).contiguous()
-    name = "DDPM" if kind == _lib.SAMPLER_DDPM else "DDIM"
+    name = ("DDPM gamma" if gamma else "DDPM") if kind == _lib.SAMPLER_DDPM else "DDIM"
     # The device loop hands raw pointers to the library, which sizes everything from the model description: check every
     # shape here (the same conditions HipScoreNet.__call__ enforces per forward), so a wrong-shaped tensor raises instead of
     # being read / written out of bounds.
@@ -96,20 +99,36 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
             raise RuntimeError(f"injected noise has shape {tuple(noise.shape)}; need at least [{need}, {', '.join(map(str, x.shape))}]")
     if noise_val is not None and tuple(noise_val.shape) != tuple(x.shape):
         raise RuntimeError(f"noise_val has shape {tuple(noise_val.shape)}, expected {tuple(x.shape)}")
+    nic = bool(getattr(net, "noise_in_cond", False)) and cond is not None
+    if cond_noise is not None:
+        if not nic:
+            raise RuntimeError("cond_noise was passed but the model has no noise_in_cond")
+        cond_noise = cond_noise.to(device=dev, dtype=torch.float32).contiguous()
+        n_fwd = L_all + 1
+        if cond_noise.dim() != 5 or tuple(cond_noise.shape[1:]) != tuple(cond.shape) or cond_noise.shape[0] < n_fwd:
+            raise RuntimeError(f"cond_noise has shape {tuple(cond_noise.shape)}; need at least [{n_fwd}, {', '.join(map(str, cond.shape))}]")
 
     fast = final_only and not verbose and not log and not same_noise and noise_val is None and frac_steps is None
     if fast:
         flags = (_lib.FLAG_DENOISE if denoise else 0) | (_lib.FLAG_CLIP_BEFORE if clip_before else 0) \
-            | (_lib.FLAG_JUST_BETA if just_beta else 0)
-        if noise is None and seed is None:
+            | (_lib.FLAG_JUST_BETA if just_beta else 0) | (_lib.FLAG_GAMMA if gamma else 0)
+        if seed is None and (noise is None or (nic and cond_noise is None)):
             seed = _draw_seed()
         with torch.cuda.device(dev):
             net._bind_stream()
-            _lib.check(_lib.lib.mcvd_sampler_run(
-                net._model, kind, C.c_void_p(x.data_ptr()), C.c_void_p(cond.data_ptr()) if cond is not None else None,
-                C.c_void_p(noise.data_ptr()) if noise is not None else None, C.c_uint64(seed or 0),
-                C.c_uint64(sample_offset), int(subsample_steps) if subsample_steps is not None else 0, flags,
-                float(t_min), B), "sampler_run")
+            if nic:                        # conditioning noise: the injected sequence, else the library's Philox stream of this call
+                _lib.check(_lib.lib.mcvd_model_set_cond_noise(
+                    net._model, C.c_void_p(cond_noise.data_ptr()) if cond_noise is not None else None, 0, 0, 0), "set_cond_noise")
+            try:
+                rc = _lib.lib.mcvd_sampler_run(
+                    net._model, kind, C.c_void_p(x.data_ptr()), C.c_void_p(cond.data_ptr()) if cond is not None else None,
+                    C.c_void_p(noise.data_ptr()) if noise is not None else None, C.c_uint64(seed or 0),
+                    C.c_uint64(sample_offset), int(subsample_steps) if subsample_steps is not None else 0, flags,
+                    float(t_min), B)
+            finally:
+                if nic:
+                    _lib.lib.mcvd_model_set_cond_noise(net._model, None, 0, 0, 0)
+            _lib.check(rc, "sampler_run")
         net._cond_key = None          # the device loop prepared (and then dropped) its own SPADE cache
         return x.unsqueeze(0)
 
@@ -121,8 +140,38 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
     if same_noise and noise_val is None:
         noise_val = x.detach().clone()                                              # :259-260
     draw = [0]
+    fwd_no = [0]
+    if gamma:                                                                       # :224-225, :238-240, :255-257
+        ks_cum, thetas = net.k_cum.cpu(), net.theta_t.cpu()
+        if subsample_steps is not None and subsample_steps < len(net.alphas):
+            ks_cum, thetas = ks_cum.index_select(0, steps), thetas.index_select(0, steps)
+        if frac_steps is not None:
+            ks_cum, thetas = ks_cum[steps], thetas[steps]
 
-    def next_noise():
+    def call_net(xx, labels):
+        if nic and cond_noise is not None:
+            net.set_next_cond_noise(cond_noise[fwd_no[0]])
+        fwd_no[0] += 1
+        return net(xx, labels, cond=cond)
+
+    def next_noise(i=None):
+        if gamma:           # z = (Gamma(k_i, rate 1/theta_i).sample() - k_i theta_i) / sqrt(1 - alpha_i)       :273-276, :319-322
+            k, th = ks_cum[i], thetas[i]
+            kt, sd = _f(k * th), _f((1 - alphas[i]).sqrt())
+            z = torch.empty_like(x)
+            raw = None
+            if noise is not None:
+                raw = noise[draw[0]].contiguous()
+            elif seed is None:                                                      # torch's device sampler, as the reference
+                raw = torch.distributions.gamma.Gamma(torch.full(tuple(x.shape[1:]), _f(k), device=dev),
+                                                      torch.full(tuple(x.shape[1:]), _f(1 / th), device=dev)).sample((B,)).contiguous()
+            with torch.cuda.device(dev):
+                net._bind_stream()
+                _lib.check(_lib.lib.mcvd_gamma_noise(net._ctx, C.c_void_p(z.data_ptr()), C.c_void_p(raw.data_ptr()) if raw is not None else None,
+                                                     _f(k), _f(th), kt, sd, C.c_uint64(seed or 0), C.c_uint64(sample_offset),
+                                                     C.c_uint64(draw[0]), B, per), "gamma_noise")
+            draw[0] += 1
+            return z
         if noise is not None:
             z = noise[draw[0]]
         elif seed is not None:
@@ -150,11 +199,11 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
             continue
         c_beta, c_alpha, c_alpha_prev = betas[i], alphas[i], alphas_prev[i]
         if not x_transf and t_min > 0:                                              # :272-279
-            z = next_noise()
+            z = next_noise(i)
             x.mul_(_f(c_alpha.sqrt())).add_(z, alpha=_f((1 - c_alpha).sqrt()))
         x_transf = True
         labels = (int(step) * torch.ones(B, device=dev)).long()                     # :283
-        grad = net(x, labels, cond=cond)                                            # :284
+        grad = call_net(x, labels)                                                  # :284
         c_x0a, c_x0b = _f(1 / c_alpha.sqrt()), _f((1 - c_alpha).sqrt())             # :287
         last_step = i + 1 == L
         if kind == _lib.SAMPLER_DDPM:
@@ -169,7 +218,7 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
         split = add_noise and (not final_only or need_log)
         z, cn = None, 0.0
         if add_noise:
-            z = noise_val if same_noise else next_noise()
+            z = noise_val if same_noise else next_noise(i)
             cn = _f(c_beta.sqrt()) if just_beta else _f(((1 - c_alpha_prev) / (1 - c_alpha) * c_beta).sqrt())   # :326/:328
         update(grad, None if split else z, c_x0a, c_x0b, c0, c1, 0.0 if split else cn)
         if not final_only:
@@ -190,7 +239,7 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
 
     if denoise:                                                                     # :331-335 (label L-1, sic)
         last_noise = ((L - 1) * torch.ones(B, device=dev)).long()
-        x = x - _f((1 - alphas[-1]).sqrt()) * net(x, last_noise, cond=cond)
+        x = x - _f((1 - alphas[-1]).sqrt()) * call_net(x, last_noise)
         if not final_only:
             images.append(x.to("cpu"))
     if final_only:

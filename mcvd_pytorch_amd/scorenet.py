@@ -20,7 +20,7 @@ from . import _lib
 from .config import desc_from_config
 
 _IncompatibleKeys = namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
-_BUFFER_KEYS = ("betas", "alphas", "alphas_prev", "unet.sigmas")
+_BUFFER_KEYS = ("betas", "alphas", "alphas_prev", "unet.sigmas", "k", "k_cum", "theta_t")
 
 
 def _get_sigmas(config):
@@ -93,10 +93,21 @@ class HipScoreNet:
                 torch.zeros(shp, dtype=torch.float32, device=self.device), requires_grad=True)
         self._loaded = False
         self._dirty = True
+        self._cond_z = None
         self._cond_key = None          # (data_ptr, _version, B) of the cond whose SPADE maps are cached in the library
         # schedule buffers + sinusoid table, computed exactly like the reference and handed to the library
         betas, alphas, alphas_prev = _schedule(config)
         self._set_schedule(betas, alphas, alphas_prev)
+        self.noise_in_cond = bool(getattr(config.model, "noise_in_cond", False))            # ncsnpp_more.py:751
+        self.output_all_frames = bool(getattr(config.model, "output_all_frames", False))
+        self.gamma = bool(getattr(config.model, "gamma", False))                            # ncsnpp_more.py:744-749
+        if self.gamma:
+            self.theta_0 = 0.001
+            self.k = self.betas / (self.alphas * (self.theta_0 ** 2))
+            self.k_cum = torch.cumsum(self.k.flip(0), 0).flip(0)
+            self.theta_t = torch.sqrt(self.alphas) * self.theta_0
+            kc, th = self.k_cum.float().cpu().contiguous(), self.theta_t.float().cpu().contiguous()
+            _lib.check(_lib.lib.mcvd_model_set_gamma_tables(self._model, _fptr(kc), _fptr(th), self._desc.num_classes), "set_gamma_tables")
         half = self._desc.ngf // 2
         emb = math.log(10000) / (half - 1)                                   # layers.py:505-510
         freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -emb).contiguous()
@@ -121,6 +132,8 @@ class HipScoreNet:
     def state_dict(self):
         sd = OrderedDict((k, v.data) for k, v in self._params.items())
         sd["betas"], sd["alphas"], sd["alphas_prev"] = self.betas, self.alphas, self.alphas_prev
+        if self.gamma:
+            sd["k"], sd["k_cum"], sd["theta_t"] = self.k, self.k_cum, self.theta_t
         return sd
 
     def load_state_dict(self, state_dict, strict=True):
@@ -143,6 +156,12 @@ class HipScoreNet:
                 unexpected.append(k)
         if all(k in sched for k in ("betas", "alphas", "alphas_prev")):
             self._set_schedule(sched["betas"], sched["alphas"], sched["alphas_prev"])
+        if self.gamma and all(k in sched for k in ("k_cum", "theta_t")):          # buffers of a model.gamma checkpoint (ncsnpp_more.py:747-749)
+            self.k_cum, self.theta_t = sched["k_cum"].float().to(self.device), sched["theta_t"].float().to(self.device)
+            if "k" in sched:
+                self.k = sched["k"].float().to(self.device)
+            kc, th = self.k_cum.cpu().contiguous(), self.theta_t.cpu().contiguous()
+            _lib.check(_lib.lib.mcvd_model_set_gamma_tables(self._model, _fptr(kc), _fptr(th), self._desc.num_classes), "set_gamma_tables")
         missing = [k for k in self._params if k not in seen]
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...")
@@ -283,20 +302,62 @@ class HipScoreNet:
         y = y.to(device=self.device, dtype=torch.float32 if float_t else torch.int64).contiguous()
         if y.shape != (B,):
             raise RuntimeError(f"labels have shape {tuple(y.shape)}")
+        if self.output_all_frames and cond is not None:
+            # ncsnpp_more.py:384-385: torch.split(h, [C*nc, C*nf]) on the C*nf-channel output of conv3x3_last cannot succeed
+            raise RuntimeError(f"split_with_sizes expects split_sizes to sum exactly to {d.channels * d.num_frames} (input tensor's size "
+                               f"at dimension 1), but got split_sizes=[{d.channels * d.num_frames_cond}, {d.channels * d.num_frames}] "
+                               "-- model.output_all_frames is broken for arch 'unetmore' in the reference as well")
+        mask = None
+        if self._desc.cond_emb and cond_mask is not None:
+            mask = cond_mask.to(device=self.device, dtype=torch.int32).contiguous()
+            if mask.shape != (B,):
+                raise RuntimeError(f"cond_mask has shape {tuple(mask.shape)}")
         out = torch.empty_like(x)
         with torch.cuda.device(self.device):
             self._bind_stream()
-            if self._desc.spade:
+            if self.noise_in_cond and cond is not None:                        # ncsnpp_more.py:755-768: fresh noise every forward
+                if float_t:
+                    raise IndexError("tensors used as indices must be long, int, byte or bool tensors (noise_in_cond indexes alphas "
+                                     "with the labels)")
+                z = self._cond_z
+                self._cond_z = None
+                if z is None:
+                    if self.gamma:                                              # :761-765, torch's device gamma sampler like the reference
+                        ua = self.alphas[y].reshape(B, 1, 1, 1)
+                        uk = self.k_cum[y].reshape(B, 1, 1, 1).repeat(1, *cond.shape[1:])
+                        ut = self.theta_t[y].reshape(B, 1, 1, 1).repeat(1, *cond.shape[1:])
+                        z = torch.distributions.gamma.Gamma(uk, 1 / ut).sample()
+                        z = (z - uk * ut) / (1 - ua).sqrt()
+                    else:
+                        z = torch.randn_like(cond)
+                z = z.to(device=self.device, dtype=torch.float32).contiguous()
+                if z.shape != cond.shape:
+                    raise RuntimeError(f"conditioning noise has shape {tuple(z.shape)}, cond {tuple(cond.shape)}")
+                _lib.check(_lib.lib.mcvd_model_set_cond_noise(self._model, _fptr(z), 0, 0, 0), "set_cond_noise")
+            if self._desc.spade and not self.noise_in_cond:
                 # SPADE gamma/beta depend only on cond: recompute only when the tensor (or its content version) changes
                 key = (cond.data_ptr(), cond._version, B)
                 if key != self._cond_key:
                     _lib.check(_lib.lib.mcvd_model_prepare_cond(self._model, _fptr(cond), B), "prepare_cond")
                     self._cond_key = key
                     self._cond_keepalive = cond
-            fwd = _lib.lib.mcvd_unet_forward_ft if float_t else _lib.lib.mcvd_unet_forward
-            _lib.check(fwd(self._model, _fptr(x), C.c_void_p(y.data_ptr()), _fptr(cond) if cond is not None else None,
-                           _fptr(out), B), "unet_forward")
+            cptr = _fptr(cond) if cond is not None else None
+            if mask is not None and not float_t:
+                rc = _lib.lib.mcvd_unet_forward_masked(self._model, _fptr(x), C.c_void_p(y.data_ptr()), cptr, C.c_void_p(mask.data_ptr()),
+                                                       _fptr(out), B)
+            elif mask is not None:
+                raise RuntimeError("cond_mask with float timesteps is not supported")
+            else:
+                fwd = _lib.lib.mcvd_unet_forward_ft if float_t else _lib.lib.mcvd_unet_forward
+                rc = fwd(self._model, _fptr(x), C.c_void_p(y.data_ptr()), cptr, _fptr(out), B)
+            if self.noise_in_cond:
+                _lib.lib.mcvd_model_set_cond_noise(self._model, None, 0, 0, 0)          # never leave a pointer to a dead tensor behind
+            _lib.check(rc, "unet_forward")
         return out
+
+    def set_next_cond_noise(self, z):
+        """noise_in_cond: use `z` (shaped like cond) instead of a fresh device draw in the NEXT forward (parity runs)."""
+        self._cond_z = z
 
     forward = __call__
 

@@ -243,6 +243,163 @@ def main():
         gen_forward_only(name, batch)
 
 
+class SiteInjector:
+    """torch.randn_like replacement that serves two pre-drawn sequences by CALL SITE: draws made inside the network's forward
+    (ncsnpp_more.py:766, the noise_in_cond branch) come from `cond_seq`, the samplers' own draws from `step_seq`."""
+
+    def __init__(self, step_seq, cond_seq):
+        self.step_seq, self.cond_seq, self.ks, self.kc = step_seq, cond_seq, 0, 0
+
+    def __call__(self, like, *a, **kw):
+        if sys._getframe(1).f_code.co_filename.endswith("ncsnpp_more.py"):
+            z = self.cond_seq[self.kc]
+            self.kc += 1
+        else:
+            z = self.step_seq[self.ks]
+            self.ks += 1
+        assert z.shape == like.shape, (z.shape, like.shape)
+        return z.to(like)
+
+
+def gen_f4():
+    """SURVEY 8f rank 4 flags on the real reference (tiny nets): cond_emb (+ cond_mask), noise_in_cond (concat and SPADE), gamma
+    (sampler + noise_in_cond, with the Gamma sampler replaced by a deterministic stand-in so the draws can be injected),
+    output_all_frames (the reference's own failure)."""
+    import models as ref_models
+    import torch.distributions.gamma as tdg
+    # ---- cond_emb
+    name, B = "tiny_condemb", 3
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    check_names(net, config)
+    net.load_state_dict(synth.make_state_dict(config, seed=123), strict=False)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = torch.tensor([(37 * (b + 1)) % 1000 for b in range(B)]).long()
+    mask = torch.tensor([1, 0, 1], dtype=torch.int32)
+    taps, hooks = {}, []
+    for i, m in enumerate(net.unet.all_modules):
+        hooks.append(m.register_forward_hook(lambda mod, inp, o, i=i: taps.__setitem__(i, probe(o))))
+    with torch.no_grad():
+        eps_mask = net(x, t, cond=cond, cond_mask=mask)
+        taps_mask = dict(taps)
+        eps_none = net(x, t, cond=cond)
+    for h in hooks:
+        h.remove()
+    noise = synth.make_noise(config, B, 11, seed=2)
+    inj = NoiseInjector(noise)
+    orig = torch.randn_like
+    torch.randn_like = inj
+    try:
+        res = ref_models.ddpm_sampler(x.clone(), net, cond=cond, final_only=True, denoise=True, subsample_steps=10, clip_before=True,
+                                      verbose=False, log=False, cond_mask=mask)       # cond_mask lands in **kwargs and is dropped (:263)
+    finally:
+        torch.randn_like = orig
+    torch.save(dict(config_name=name, batch=B, fwd_t=t, mask=mask, eps_mask=eps_mask.clone(), eps_none=eps_none.clone(),
+                    fwd_taps=taps_mask, sampler=res.clone(), n_noise=inj.k), os.path.join(OUT, "tiny_condemb_b3.pt"))
+    print(f"wrote tiny_condemb_b3.pt  |eps_mask - eps_none| {float((eps_mask - eps_none).abs().max()):.3f}")
+
+    # ---- noise_in_cond (concat and SPADE)
+    for name in ("tiny_noisecond", "tiny_spade_noisecond"):
+        B = 2
+        config = synth.make_config(name)
+        net = build_ref_net(config)
+        check_names(net, config)
+        net.load_state_dict(synth.make_state_dict(config, seed=123), strict=False)
+        x, cond = synth.make_inputs(config, B, seed=0)
+        t = torch.tensor([700, 20]).long()
+        g = torch.Generator().manual_seed(77)
+        cond_seq = torch.randn(12, *cond.shape, generator=g)
+        step_seq = synth.make_noise(config, B, 11, seed=2)
+        inj = SiteInjector(step_seq, cond_seq)
+        orig = torch.randn_like
+        torch.randn_like = inj
+        try:
+            with torch.no_grad():
+                eps = net(x, t, cond=cond)                               # consumes cond_seq[0]
+            res = ref_models.ddpm_sampler(x.clone(), net, cond=cond, final_only=True, denoise=True, subsample_steps=10,
+                                          clip_before=True, verbose=False, log=False)      # cond_seq[1..11], step_seq[0..8]
+        finally:
+            torch.randn_like = orig
+        assert inj.kc == 12 and inj.ks == 9, (inj.kc, inj.ks)
+        torch.save(dict(config_name=name, batch=B, fwd_t=t, fwd_eps=eps.clone(), cond_seq=cond_seq, sampler=res.clone()),
+                   os.path.join(OUT, f"{name}_b2.pt"))
+        print(f"wrote {name}_b2.pt  sampler range [{res.min():.3f}, {res.max():.3f}]")
+
+    # ---- gamma (sampler draws + noise_in_cond draws), Gamma.sample replaced by a deterministic stand-in
+    name, B = "tiny_gamma", 2
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    net.load_state_dict(synth.make_state_dict(config, seed=123), strict=False)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    normals = torch.randn(40, *x.shape, generator=torch.Generator().manual_seed(91))
+    log_raw = []
+
+    class FakeGamma:
+        n = 0
+
+        def __init__(self, concentration, rate):
+            self.c, self.r = concentration, rate
+
+        def sample(self, shape=()):
+            c = self.c.expand(tuple(shape) + tuple(self.c.shape)) if len(shape) else self.c
+            r = self.r.expand(tuple(shape) + tuple(self.r.shape)) if len(shape) else self.r
+            g = c / r + c.sqrt() / r * normals[FakeGamma.n].reshape(c.shape)      # mean k theta, variance k theta^2
+            site = "cond" if sys._getframe(1).f_code.co_filename.endswith("ncsnpp_more.py") else "step"
+            log_raw.append((site, g.clone()))
+            FakeGamma.n += 1
+            return g
+    o1, o2 = ref_models.Gamma, tdg.Gamma
+    ref_models.Gamma = FakeGamma
+    tdg.Gamma = FakeGamma
+    torch.distributions.gamma.Gamma = FakeGamma
+    try:
+        res = ref_models.ddpm_sampler(x.clone(), net, cond=cond, final_only=True, denoise=True, subsample_steps=10, clip_before=True,
+                                      verbose=False, log=False, gamma=True)
+        res_tmin = ref_models.ddpm_sampler(x.clone(), net, cond=cond, final_only=True, denoise=True, subsample_steps=10,
+                                           clip_before=True, verbose=False, log=False, gamma=True, t_min=0.35)
+    finally:
+        ref_models.Gamma, tdg.Gamma = o1, o2
+        torch.distributions.gamma.Gamma = o2
+    # first call: per step [cond, step] (no step draw after the last step), then the denoise forward's cond draw
+    n1 = 11 + 9
+    first, second = log_raw[:n1], log_raw[n1:]
+
+    def split(log, labels):
+        """raw step draws; conditioning draws standardised with the label's tables, as ncsnpp_more.py:761-765 does."""
+        steps_raw = torch.stack([g for s_, g in log if s_ == "step"])
+        conds = [g for s_, g in log if s_ == "cond"]
+        assert len(conds) == len(labels)
+        zc = []
+        for g, lab in zip(conds, labels):
+            k, th, a = net.k_cum[lab], net.theta_t[lab], net.alphas[lab]
+            zc.append((g - k * th) / (1 - a).sqrt())
+        return steps_raw, torch.stack(zc)
+    steps10 = list(range(0, 1000, 100))
+    s1, c1 = split(first, steps10 + [9])                                    # denoise label L - 1 = 9 (sic)
+    kept = [t for t in steps10 if not (t < 0.35 * 10)]                       # step < t_min * len(alphas_subsampled): none skipped but 0..3?
+    kept = [t for t in steps10 if not (t < 0.35 * len(steps10))]
+    s2, c2 = split(second, kept + [9])
+    torch.save(dict(config_name=name, batch=B, sampler=res.clone(), step_raw=s1, cond_z=c1, sampler_tmin=res_tmin.clone(),
+                    step_raw_tmin=s2, cond_z_tmin=c2, k_cum=net.k_cum.clone(), theta_t=net.theta_t.clone()),
+               os.path.join(OUT, "tiny_gamma_b2.pt"))
+    print(f"wrote tiny_gamma_b2.pt  range [{res.min():.3f}, {res.max():.3f}]  draws {len(first)} + {len(second)}")
+
+    # ---- output_all_frames: the reference itself cannot run it with cond (records the failure)
+    config = synth.make_config("tiny_allframes")
+    net = build_ref_net(config)
+    net.load_state_dict(synth.make_state_dict(config, seed=123), strict=False)
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    try:
+        with torch.no_grad():
+            net(x, torch.tensor([5, 6]), cond=cond)
+        msg = None
+    except RuntimeError as e:
+        msg = str(e)
+    assert msg is not None, "reference output_all_frames unexpectedly works"
+    torch.save(dict(config_name="tiny_allframes", error=msg), os.path.join(OUT, "tiny_allframes_err.pt"))
+    print("wrote tiny_allframes_err.pt:", msg[:100])
+
+
 def main_round2():
     """Fixtures added in round 2 (VERDICT r01 'next round' item 1): the headline config end-to-end, configs 3 / 4 full samplers,
     the autoregressive driver at config 5 width, the BASELINE.json ch_mult variant, the cosine schedule."""
@@ -262,6 +419,8 @@ def main_round2():
         gen_sampler_only("bair_big_spade", 2, 100)
     if "cfg5" in which:
         gen_autoregressive("cityscapes_big", 1, 8, 100)
+    if "f4" in which:
+        gen_f4()
 
 
 if __name__ == "__main__":

@@ -31,17 +31,29 @@ def subsampled_schedule(alphas, alphas_prev, betas, subsample_steps):
 
 @torch.no_grad()
 def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=False, denoise=True,
-           subsample_steps=None, clip_before=True, t_min=-1, noise_fn=None, frac_steps=None):
+           subsample_steps=None, clip_before=True, t_min=-1, noise_fn=None, frac_steps=None, gamma=False):
     """kind='ddpm': models/__init__.py:266-333.  kind='ddim': :142-198.
-    noise_fn(i, like) -> tensor shaped like `like` (i = -1 for the t_min re-noise draw)."""
+    noise_fn(i, like) -> tensor shaped like `like` (i = -1 for the t_min re-noise draw).
+    gamma=True (:224-225, :238-240, :273-276, :319-322): noise_fn returns the RAW draw g ~ Gamma(k_cum[i], rate 1/theta[i]) and the
+    loop standardises it, z = (g - k theta) / sqrt(1 - alpha_i), as the reference does."""
     assert kind in ("ddpm", "ddim")
     if noise_fn is None:
         noise_fn = lambda i, like: torch.randn_like(like)
     steps, alphas, alphas_prev, betas = subsampled_schedule(
         scorenet.alphas, scorenet.alphas_prev, scorenet.betas, subsample_steps)
+    gamma = gamma and kind == "ddpm"
+    if gamma:
+        ks_cum, thetas = scorenet.k_cum, scorenet.theta_t
+        if subsample_steps is not None and subsample_steps < len(scorenet.alphas):
+            ks_cum, thetas = ks_cum.index_select(0, steps), thetas.index_select(0, steps)
     if frac_steps is not None and kind == "ddpm":                     # :250-254
         steps = steps[int((1 - frac_steps) * len(steps)):]
         alphas, alphas_prev, betas = alphas[steps], alphas_prev[steps], betas[steps]
+        if gamma:
+            ks_cum, thetas = ks_cum[steps], thetas[steps]
+
+    def std(g, i):
+        return (g - ks_cum[i] * thetas[i]) / (1 - alphas[i]).sqrt() if gamma else g
 
     images = []
     started = False
@@ -50,7 +62,7 @@ def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=
         if step < t_min * len(alphas):                                # :269-270
             continue
         if not started and t_min > 0:                                 # :272-279
-            z = noise_fn(-1, x_mod)
+            z = std(noise_fn(-1, x_mod), i)
             x_mod = alphas[i].sqrt() * x_mod + (1 - alphas[i]).sqrt() * z
         started = True
 
@@ -71,7 +83,7 @@ def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=
             images.append(x_mod.clone())
 
         if kind == "ddpm" and i + 1 != L:                             # :311-328
-            noise = noise_fn(i, x_mod)
+            noise = std(noise_fn(i, x_mod), i)
             if just_beta:
                 x_mod = x_mod + c_beta.sqrt() * noise
             else:

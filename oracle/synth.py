@@ -63,6 +63,17 @@ def make_config(name):
         model.update(ngf=32, n_head_channels=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8, 16],
                      sigma_dist="cosine")
         sampling.update(subsample=10)
+    elif name in ("tiny_condemb", "tiny_noisecond", "tiny_gamma", "tiny_allframes"):   # SURVEY 8f rank 4 flags on the `tiny` net
+        data.update(image_size=32, num_frames=2, num_frames_cond=2)
+        model.update(ngf=32, n_head_channels=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8, 16])
+        model.update(dict(tiny_condemb=dict(cond_emb=True), tiny_noisecond=dict(noise_in_cond=True),
+                          tiny_gamma=dict(gamma=True, noise_in_cond=True), tiny_allframes=dict(output_all_frames=True))[name])
+        sampling.update(subsample=10)
+    elif name == "tiny_spade_noisecond":     # SPADE + noise_in_cond: gamma/beta cannot be hoisted out of the step
+        data.update(image_size=32, channels=3, num_frames=2, num_frames_cond=1, num_frames_future=1)
+        model.update(ngf=32, n_head_channels=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8, 16],
+                     spade=True, spade_dim=32, noise_in_cond=True)
+        sampling.update(subsample=10)
     elif name == "tiny_spade":
         data.update(image_size=32, channels=3, num_frames=2, num_frames_cond=1, num_frames_future=1)
         model.update(ngf=32, n_head_channels=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8, 16],

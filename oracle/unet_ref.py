@@ -56,9 +56,11 @@ def hot_cfg(config):
     c.sigma_dist = cfg_get(m, "sigma_dist", "linear")
     c.sigma_begin = float(m.sigma_begin)
     c.sigma_end = float(m.sigma_end)
-    for flag in ("cond_emb", "noise_in_cond", "gamma", "output_all_frames"):
-        if cfg_get(m, flag, False):
-            raise NotImplementedError(f"model.{flag} is out of scope (SURVEY 8f rank 4)")
+    # SURVEY 8f rank 4 flags
+    c.cond_emb = bool(cfg_get(m, "cond_emb", False))                  # ncsnpp_more.py:61, :97-99, :282-286
+    c.noise_in_cond = bool(cfg_get(m, "noise_in_cond", False))        # :751, :755-768
+    c.gamma = bool(cfg_get(m, "gamma", False))                        # :744-749
+    c.output_all_frames = bool(cfg_get(m, "output_all_frames", False))   # :384-385
     if cfg_get(m, "arch", "unetmore") != "unetmore":
         raise NotImplementedError("only arch=unetmore is on the hot path")
     return c
@@ -81,8 +83,10 @@ def module_plan(c):
     in0 = C * c.num_frames if c.spade else C * (c.num_frames + c.num_frames_cond)
     res = [c.image_size // (2 ** i) for i in range(len(c.ch_mult))]
     mods = [dict(kind="linear", cin=nf, cout=4 * nf),
-            dict(kind="linear", cin=4 * nf, cout=4 * nf),
-            dict(kind="conv3", cin=in0, cout=nf)]
+            dict(kind="linear", cin=4 * nf, cout=4 * nf)]
+    if getattr(c, "cond_emb", False):
+        mods.append(dict(kind="embed", n=2, dim=nf // 2))          # torch.nn.Embedding(2, nf // 2), ncsnpp_more.py:98
+    mods.append(dict(kind="conv3", cin=in0, cout=nf))
     hs_c = [nf]
     in_ch = nf
     L = len(c.ch_mult)
@@ -119,7 +123,7 @@ def module_plan(c):
 def param_shapes(c):
     """name -> shape for every parameter of UNetMore_DDPM.state_dict()
     (checked against the live reference by gen_golden.py)."""
-    temb = 4 * c.ngf
+    temb = 4 * c.ngf + (c.ngf // 2 if getattr(c, "cond_emb", False) else 0)      # temb_dim, ncsnpp_more.py:95-99
     cond_ch = c.num_frames_cond * c.channels
     out = {}
 
@@ -145,6 +149,8 @@ def param_shapes(c):
         if k == "linear":
             out[p + ".weight"] = (m["cout"], m["cin"])
             out[p + ".bias"] = (m["cout"],)
+        elif k == "embed":
+            out[p + ".weight"] = (m["n"], m["dim"])
         elif k == "conv3":
             out[p + ".weight"] = (m["cout"], m["cin"], 3, 3)
             out[p + ".bias"] = (m["cout"],)
@@ -371,7 +377,7 @@ def attn_block(sd, p, x, c):
     return (x + o) / RSQRT2_DIV
 
 
-def unet_forward(sd, config, x, t, cond=None, taps=None):
+def unet_forward(sd, config, x, t, cond=None, taps=None, cond_mask=None):
     """UNetMore_DDPM.forward (ncsnpp_more.py:753-770) -> NCSNpp.forward (:251-392)
     or SPADE_NCSNpp.forward (:590-718).  `taps`, if a dict, receives the output of
     every module index (for per-module golden checks)."""
@@ -389,10 +395,16 @@ def unet_forward(sd, config, x, t, cond=None, taps=None):
     temb = timestep_embedding(t, c.ngf).to(x.dtype)               # :273 (fp32 there; cast only matters for fp64 noise-floor runs)
     temb = tap(0, temb @ sd[P + "0.weight"].t() + sd[P + "0.bias"])
     temb = tap(1, silu(temb) @ sd[P + "1.weight"].t() + sd[P + "1.bias"])   # :278-280
+    i = 2
+    if c.cond_emb:                                                # :282-286
+        if cond_mask is None:
+            cond_mask = torch.ones(x.shape[0], dtype=torch.int32)
+        e = tap(i, sd[P + "2.weight"][cond_mask.long()].to(x.dtype))          # nn.Embedding lookup
+        temb = torch.cat([temb, e], dim=1)
+        i += 1
     temb_act = silu(temb)                                         # act_emb(emb), layerspp.py:521
 
-    i = 2
-    hs = [tap(i, conv2d(x, sd[P + "2.weight"], sd[P + "2.bias"]))]
+    hs = [tap(i, conv2d(x, sd[P + f"{i}.weight"], sd[P + f"{i}.bias"]))]
     i += 1
     L = len(c.ch_mult)
     for lv in range(L):
@@ -420,7 +432,17 @@ def unet_forward(sd, config, x, t, cond=None, taps=None):
     h = tap(i, act_norm(sd, P + str(i), h, None, c, cond)); i += 1    # :375 / :704
     h = tap(i, conv2d(h, sd[P + str(i) + ".weight"], sd[P + str(i) + ".bias"])); i += 1
     assert i == len(mods)
+    if c.output_all_frames and cond is not None:                  # :384-385 -- the split sizes cannot match conv3x3_last's C*nf channels
+        _, h = torch.split(h, [c.num_frames_cond * c.channels, c.num_frames * c.channels], dim=1)
     return h
+
+
+def gamma_tables(betas, alphas, theta_0=0.001):
+    """ncsnpp_more.py:745-749: k, k_cum, theta_t of a model.gamma net."""
+    k = betas / (alphas * (theta_0 ** 2))
+    k_cum = torch.cumsum(k.flip(0), 0).flip(0)
+    theta_t = torch.sqrt(alphas) * theta_0
+    return k, k_cum, theta_t
 
 
 class OracleScoreNet:
@@ -435,7 +457,16 @@ class OracleScoreNet:
         self.sd = {k: v.to(dtype) for k, v in sd.items()}
         # dtype=float64: same fp32-rounded tables and weights, all arithmetic in double (noise-floor measurements)
         self.betas, self.alphas, self.alphas_prev = (t.to(dtype) for t in make_schedule(self.c))
+        if self.c.gamma:
+            self.k, self.k_cum, self.theta_t = gamma_tables(self.betas, self.alphas)
+        self.cond_noise_fn = None          # noise_in_cond: callable(cond) -> z, else torch.randn_like
 
     @torch.no_grad()
     def __call__(self, x, y, cond=None, cond_mask=None):
-        return unet_forward(self.sd, self.c, x, y, cond)
+        """UNetMore_DDPM.forward, ncsnpp_more.py:753-770 (the gamma branch of noise_in_cond takes its z from cond_noise_fn too:
+        the caller standardises, :761-765)."""
+        if self.c.noise_in_cond and cond is not None:
+            ua = self.alphas[y].reshape(cond.shape[0], 1, 1, 1)
+            z = self.cond_noise_fn(cond) if self.cond_noise_fn is not None else torch.randn_like(cond)
+            cond = ua.sqrt() * cond + (1 - ua).sqrt() * z
+        return unet_forward(self.sd, self.c, x, y, cond, cond_mask=cond_mask)

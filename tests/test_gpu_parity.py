@@ -674,3 +674,106 @@ def test_sampler_rejects_bad_shapes():
     with pytest.raises(RuntimeError):
         ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10,
                      noise=synth.make_noise(config, 2, 4, seed=2).cuda())
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 8f rank 4 flags
+def test_cond_emb_vs_reference_golden(golden_dir):
+    """model.cond_emb (ncsnpp_more.py:97-99, :282-286): forward with a cond_mask, with the default mask, module by module vs the
+    oracle, and the sampler (which never forwards the mask)."""
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    from tests.hiputil import module_output
+    g = torch.load(os.path.join(golden_dir, "tiny_condemb_b3.pt"), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    B = g["batch"]
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t, mask = g["fwd_t"], g["mask"]
+    em = net(x.cuda(), t.cuda(), cond=cond.cuda(), cond_mask=mask.cuda())
+    taps = {}
+    with torch.no_grad():
+        unet_ref.unet_forward(sd, config, x, t, cond, taps=taps, cond_mask=mask)
+    bad = []
+    for i in sorted(taps):
+        if i in (0, 1, 2) or i == len(taps) - 1:
+            continue
+        try:
+            got = module_output(net, i, B)
+        except RuntimeError:
+            continue
+        sc = max(taps[i].abs().max().item(), 1e-6)
+        err = (got.cpu() - taps[i]).abs().max().item()
+        if err > 2e-5 + 1e-4 * sc:
+            bad.append((i, err, sc))
+    assert not bad, bad[:6]
+    en = net(x.cuda(), t.cuda(), cond=cond.cuda())
+    assert (em.cpu() - g["eps_mask"]).abs().max().item() <= 1e-4 * g["eps_mask"].abs().max().item()
+    assert (en.cpu() - g["eps_none"]).abs().max().item() <= 1e-4 * g["eps_none"].abs().max().item()
+    noise = synth.make_noise(config, B, 11, seed=2)
+    for fo in (True, False):
+        out = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=fo, subsample_steps=10, noise=noise.cuda(), cond_mask=mask)
+        assert (out[-1:].cpu() - g["sampler"]).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("fx", ["tiny_noisecond_b2.pt", "tiny_spade_noisecond_b2.pt"])
+def test_noise_in_cond_vs_reference_golden(golden_dir, fx):
+    """model.noise_in_cond (ncsnpp_more.py:755-768) with the reference run's conditioning-noise draws injected: one forward, the
+    device loop and the host loop; then the library's own streams (no injection) for sanity."""
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    g = torch.load(os.path.join(golden_dir, fx), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    B = g["batch"]
+    x, cond = synth.make_inputs(config, B, seed=0)
+    cs = g["cond_seq"]
+    net.set_next_cond_noise(cs[0].cuda())
+    eps = net(x.cuda(), g["fwd_t"].cuda(), cond=cond.cuda())
+    assert (eps.cpu() - g["fwd_eps"]).abs().max().item() <= 1e-4 * g["fwd_eps"].abs().max().item()
+    noise = synth.make_noise(config, B, 11, seed=2)
+    for fo in (True, False):
+        out = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=fo, subsample_steps=10, noise=noise.cuda(),
+                           cond_noise=cs[1:].cuda())
+        err = (out[-1:].cpu() - g["sampler"]).abs().max().item()
+        assert err <= 1e-4, f"{fx} final_only={fo}: {err:.3e}"
+    a = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10, seed=3)
+    b = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10, seed=3)
+    c = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10, seed=4)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all() and a.abs().max().item() < 6.0
+    e1 = net(x.cuda(), g["fwd_t"].cuda(), cond=cond.cuda())          # fresh torch.randn_like(cond) per call, as the reference
+    e2 = net(x.cuda(), g["fwd_t"].cuda(), cond=cond.cuda())
+    assert not torch.equal(e1, e2)
+
+
+def test_gamma_sampler_vs_reference_golden(golden_dir, ctx):
+    """gamma=True on a model.gamma + noise_in_cond net: the reference run's raw Gamma draws replayed through both loops (also
+    with t_min > 0), then the library's own Marsaglia-Tsang Philox stream checked for its first two moments."""
+    import ctypes as C
+    from mcvd_pytorch_amd import _lib
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    from tests.hiputil import P
+    g = torch.load(os.path.join(golden_dir, "tiny_gamma_b2.pt"), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    torch.testing.assert_close(net.k_cum.cpu(), g["k_cum"], rtol=1e-6, atol=0)
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    for key, extra in (("", {}), ("_tmin", dict(t_min=0.35))):
+        for fo in (True, False):
+            out = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=fo, subsample_steps=10, gamma=True,
+                               noise=g["step_raw" + key].cuda(), cond_noise=g["cond_z" + key].cuda(), **extra)
+            err = (out[-1:].cpu() - g["sampler" + key]).abs().max().item()
+            assert err <= 1e-4, f"gamma{key} final_only={fo}: {err:.3e}"
+    for k, th in ((5000.0, 0.9e-3), (3.5, 0.2), (0.6, 1.0)):
+        n = 1 << 18
+        out = torch.empty(n, device="cuda")
+        _lib.check(_lib.lib.mcvd_gamma_noise(ctx.h, P(out), None, k, th, 0.0, 1.0, 11, 0, 2, 4, n // 4))
+        m, v = out.double().mean().item(), out.double().var().item()
+        assert abs(m - k * th) <= 4 * (k ** 0.5) * th / n ** 0.5 + 1e-3 * k * th, (k, m)
+        assert abs(v - k * th * th) <= 0.03 * k * th * th, (k, v)
+        assert out.min().item() > 0
+    a = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10, gamma=True, seed=9)
+    assert torch.isfinite(a).all() and a.abs().max().item() < 6.0
+
+
+def test_output_all_frames_fails_like_the_reference(golden_dir):
+    g = torch.load(os.path.join(golden_dir, "tiny_allframes_err.pt"), weights_only=False)
+    config, sd, net = _net("tiny_allframes")
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    with pytest.raises(RuntimeError) as e:
+        net(x.cuda(), torch.tensor([5, 6]).cuda(), cond=cond.cuda())
+    assert "split_with_sizes" in str(e.value) and "split_with_sizes" in g["error"]

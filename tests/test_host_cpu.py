@@ -53,7 +53,8 @@ def _plan(name):
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_spade", "smmnist_big5", "smmnist_big5_ngf96", "kth64_big_ngf128",
-                                  "bair_big_spade", "cityscapes_big", "cityscapes_big_variant"])
+                                  "bair_big_spade", "cityscapes_big", "cityscapes_big_variant", "tiny_condemb", "tiny_gamma",
+                                  "tiny_spade_noisecond"])
 def test_plan_parameter_table_matches_reference_names(name):
     """Names, shapes and ORDER equal the reference state_dict (oracle.param_shapes is pinned to it by gen_golden)."""
     _lib, config, m = _plan(name)
@@ -85,7 +86,7 @@ def test_library_default_schedule_close_to_torch(name):
 def test_unsupported_configs_raise():
     from mcvd_pytorch_amd.config import desc_from_config
     cfg = synth.make_config("tiny")
-    cfg.model.gamma = True
+    cfg.model.time_conditional = False
     with pytest.raises(NotImplementedError):
         desc_from_config(cfg)
     cfg = synth.make_config("tiny")

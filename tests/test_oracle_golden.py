@@ -149,6 +149,81 @@ def test_autoregressive_config5_matches_reference(golden_dir):
     assert (out - g["pred"]).abs().max().item() <= 2e-4      # two chained 100-step blocks
 
 
+# ---------------------------------------------------------------- SURVEY 8f rank 4 flags
+def _seq(fn_seq):
+    k = [0]
+
+    def fn(*_):
+        k[0] += 1
+        return fn_seq[k[0] - 1]
+    return fn, k
+
+
+def test_cond_emb_matches_reference(golden_dir):
+    """model.cond_emb: Embedding(2, ngf/2)(cond_mask) concatenated to temb (ncsnpp_more.py:97-99, :282-286), with a mask, with the
+    default all-ones mask, and through the sampler (which never forwards cond_mask, models/__init__.py:263)."""
+    g = load(golden_dir, "tiny_condemb_b3.pt")
+    config = synth.make_config(g["config_name"])
+    sd = synth.make_state_dict(config, seed=123)
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    taps = {}
+    with torch.no_grad():
+        em = unet_ref.unet_forward(sd, config, x, g["fwd_t"], cond, taps=taps, cond_mask=g["mask"])
+        en = unet_ref.unet_forward(sd, config, x, g["fwd_t"], cond)
+    assert (em - g["eps_mask"]).abs().max().item() <= 1e-4 * g["eps_mask"].abs().max().item()
+    assert (en - g["eps_none"]).abs().max().item() <= 1e-4 * g["eps_none"].abs().max().item()
+    assert sorted(taps) == sorted(g["fwd_taps"])
+    for i, p in g["fwd_taps"].items():
+        torch.testing.assert_close(taps[i].reshape(-1)[p["idx"]], p["sample"], rtol=1e-4, atol=2e-5, msg=f"module {i}")
+    fn, k = _injector(synth.make_noise(config, g["batch"], 11, seed=2))
+    out = sampler_ref.sample(x.clone(), unet_ref.OracleScoreNet(config, sd), cond=cond, kind="ddpm", final_only=True, denoise=True,
+                             subsample_steps=10, noise_fn=fn)
+    assert k[0] == g["n_noise"] and (out - g["sampler"]).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("fx", ["tiny_noisecond_b2.pt", "tiny_spade_noisecond_b2.pt"])
+def test_noise_in_cond_matches_reference(golden_dir, fx):
+    """model.noise_in_cond (ncsnpp_more.py:755-768): every forward diffuses cond to its labels' level with a fresh draw."""
+    g = load(golden_dir, fx)
+    config = synth.make_config(g["config_name"])
+    net = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123))
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    net.cond_noise_fn, kc = _seq(g["cond_seq"])
+    eps = net(x, g["fwd_t"], cond=cond)
+    assert (eps - g["fwd_eps"]).abs().max().item() <= 1e-4 * g["fwd_eps"].abs().max().item()
+    fn, k = _injector(synth.make_noise(config, g["batch"], 11, seed=2))
+    out = sampler_ref.sample(x.clone(), net, cond=cond, kind="ddpm", final_only=True, denoise=True, subsample_steps=10, noise_fn=fn)
+    assert kc[0] == 12 and k[0] == 9
+    assert (out - g["sampler"]).abs().max().item() <= 1e-4
+
+
+def test_gamma_sampler_matches_reference(golden_dir):
+    """gamma=True (models/__init__.py:224-225, :273-276, :319-322) on a model.gamma + noise_in_cond net: the raw Gamma draws of the
+    reference run are replayed; also with t_min > 0 (the re-noise draw)."""
+    g = load(golden_dir, "tiny_gamma_b2.pt")
+    config = synth.make_config(g["config_name"])
+    net = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123))
+    torch.testing.assert_close(net.k_cum, g["k_cum"], rtol=1e-6, atol=0)
+    torch.testing.assert_close(net.theta_t, g["theta_t"], rtol=1e-6, atol=0)
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    for key, extra in (("", {}), ("_tmin", dict(t_min=0.35))):
+        net.cond_noise_fn, kc = _seq(g["cond_z" + key])
+        fn, k = _seq(g["step_raw" + key])
+        out = sampler_ref.sample(x.clone(), net, cond=cond, kind="ddpm", final_only=True, denoise=True, subsample_steps=10,
+                                 noise_fn=fn, gamma=True, **extra)
+        assert k[0] == len(g["step_raw" + key]) and kc[0] == len(g["cond_z" + key])
+        assert (out - g["sampler" + key]).abs().max().item() <= 1e-4
+
+
+def test_output_all_frames_fails_like_the_reference(golden_dir):
+    g = load(golden_dir, "tiny_allframes_err.pt")
+    config = synth.make_config("tiny_allframes")
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    with pytest.raises(RuntimeError) as e:
+        unet_ref.unet_forward(synth.make_state_dict(config, seed=123), config, x, torch.tensor([5, 6]), cond)
+    assert "split_with_sizes" in str(e.value) and "split_with_sizes" in g["error"]
+
+
 def test_fpndm_matches_reference(golden_dir):
     """FPNDM_sampler (models/__init__.py:38-99 + models/pndm.py): every step of the clipped run, and the un-clipped final state
     (which grows to |x| ~ 360 on random weights: relative tolerance)."""
