@@ -93,8 +93,10 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
         raise RuntimeError("this model takes no conditioning frames (num_frames_cond == 0) but cond was passed")
     L_all = d.num_classes if (subsample_steps is None or subsample_steps >= d.num_classes) else \
         len(range(0, d.num_classes, d.num_classes // int(subsample_steps)))
+    skip_all = d.num_classes // int(subsample_steps) if (subsample_steps is not None and subsample_steps < d.num_classes) else 1
+    n_exec = sum(1 for st in range(0, d.num_classes, skip_all) if not (st < t_min * L_all))      # steps the loop runs (:269-270)
     if noise is not None:
-        need = (L_all - 1 if kind == _lib.SAMPLER_DDPM else 0) + (1 if t_min > 0 else 0)
+        need = (max(n_exec - 1, 0) if kind == _lib.SAMPLER_DDPM else 0) + (1 if (t_min > 0 and n_exec > 0) else 0)
         if noise.dim() != 5 or tuple(noise.shape[1:]) != tuple(x.shape) or noise.shape[0] < need:
             raise RuntimeError(f"injected noise has shape {tuple(noise.shape)}; need at least [{need}, {', '.join(map(str, x.shape))}]")
     if noise_val is not None and tuple(noise_val.shape) != tuple(x.shape):
@@ -104,7 +106,7 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
         if not nic:
             raise RuntimeError("cond_noise was passed but the model has no noise_in_cond")
         cond_noise = cond_noise.to(device=dev, dtype=torch.float32).contiguous()
-        n_fwd = L_all + 1
+        n_fwd = n_exec + (1 if denoise else 0)
         if cond_noise.dim() != 5 or tuple(cond_noise.shape[1:]) != tuple(cond.shape) or cond_noise.shape[0] < n_fwd:
             raise RuntimeError(f"cond_noise has shape {tuple(cond_noise.shape)}; need at least [{n_fwd}, {', '.join(map(str, cond.shape))}]")
 

@@ -102,11 +102,13 @@ class HipScoreNet:
         self.output_all_frames = bool(getattr(config.model, "output_all_frames", False))
         self.gamma = bool(getattr(config.model, "gamma", False))                            # ncsnpp_more.py:744-749
         if self.gamma:
+            # computed on the CPU like the schedule itself: g ~ k theta +- sqrt(k) theta with k up to 1e9 is standardised by a
+            # catastrophically cancelling (g - k theta), so the tables must be the reference's bit for bit (a device cumsum is not)
             self.theta_0 = 0.001
-            self.k = self.betas / (self.alphas * (self.theta_0 ** 2))
-            self.k_cum = torch.cumsum(self.k.flip(0), 0).flip(0)
-            self.theta_t = torch.sqrt(self.alphas) * self.theta_0
-            kc, th = self.k_cum.float().cpu().contiguous(), self.theta_t.float().cpu().contiguous()
+            k = betas / (alphas * (self.theta_0 ** 2))
+            kc = torch.cumsum(k.flip(0), 0).flip(0).float().contiguous()
+            th = (torch.sqrt(alphas) * self.theta_0).float().contiguous()
+            self.k, self.k_cum, self.theta_t = k.to(self.device), kc.to(self.device), th.to(self.device)
             _lib.check(_lib.lib.mcvd_model_set_gamma_tables(self._model, _fptr(kc), _fptr(th), self._desc.num_classes), "set_gamma_tables")
         half = self._desc.ngf // 2
         emb = math.log(10000) / (half - 1)                                   # layers.py:505-510
