@@ -111,6 +111,7 @@ struct GnArgs {
 int launch_gn_coef(const GnArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ attention
+bool attention_mfma_supported(int C, int heads, int HW);      // head dim 32..256 in steps of 32, HW % 32 == 0; else the general kernel
 int launch_attention_mfma(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
 int launch_attention_naive(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
 

@@ -23,8 +23,9 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const float* __restrict_
                                                          int heads, int S, float scale) {
     constexpr int D = 32 * DT;
     constexpr int VP = 33;                       // V tile pitch (odd -> conflict-free channel-strided reads)
-    __shared__ __attribute__((aligned(16))) float sK[D * 32];
-    __shared__ __attribute__((aligned(16))) float sV[D * VP];
+    extern __shared__ __attribute__((aligned(16))) float smem_attn[];      // dynamic: D = 256 needs 65 KiB
+    float* sK = smem_attn;                       // [D][32]
+    float* sV = smem_attn + D * 32;              // [D][VP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int bh = blockIdx.y;
@@ -59,9 +60,12 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const float* __restrict_
             rv[i] = *reinterpret_cast<const f32x4*>(vb + off);
         }
     };
-    gload(0);
+    constexpr bool PREF = DT <= 6;               // the next tile's K/V prefetch lives in 2*NLD float4 across the MFMA phase; beyond
+                                                 // D = 192 Q (D/2) + O (D/2) leave no room for it: load just before the LDS write
+    if (PREF) gload(0);
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();                          // previous tile fully consumed
+        if (!PREF) gload(t);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = i * 256 + tid;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const float* __restrict_
             dv[0] = rv[i][0]; dv[1] = rv[i][1]; dv[2] = rv[i][2]; dv[3] = rv[i][3];
         }
         __syncthreads();
-        if (t + 1 < ntiles) gload(t + 1);
+        if (PREF && t + 1 < ntiles) gload(t + 1);
 
         // ---- S^T tile: 32 keys x 32 queries
         f32x16 st;
@@ -122,19 +126,39 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const float* __restrict_
     }
 }
 
+bool attention_mfma_supported(int C, int heads, int HW) {
+    if (heads <= 0 || C % heads != 0) return false;
+    const int D = C / heads;
+    return D % 32 == 0 && D >= 32 && D <= 256 && HW % 32 == 0;
+}
+
 int launch_attention_mfma(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s) {
     MCVD_REQUIRE(heads > 0 && C % heads == 0, "attention: C=%d heads=%d", C, heads);
     const int D = C / heads;
-    MCVD_REQUIRE(D % 32 == 0 && D >= 32 && D <= 128, "attention: head dim %d must be 32/64/96/128", D);
-    MCVD_REQUIRE(HW % 32 == 0, "attention: HW=%d must be a multiple of 32", HW);
+    // The flash kernel keeps Q and the O accumulators of a head in registers: head dims 32..256 in steps of 32.  Anything else
+    // (n_head_channels = -1 on a wide level -> one head of C channels, layerspp.py:219-228; odd widths; HW not a multiple of 32)
+    // runs the general one-thread-per-query kernel: correct for every shape, far slower.
+    if (!attention_mfma_supported(C, heads, HW)) return launch_attention_naive(qkv, out, B, C, heads, HW, s);
     const float scale = (float)pow((double)D, -0.5);   // int(C)**-0.5 as a Python double, then fp32 (layerspp.py:239)
     dim3 grid((HW + 127) / 128, B * heads);
-    switch (D / 32) {
-        case 1: hipLaunchKernelGGL(attn_mfma_kernel<1>, grid, dim3(256), 0, s, qkv, out, C, heads, HW, scale); break;
-        case 2: hipLaunchKernelGGL(attn_mfma_kernel<2>, grid, dim3(256), 0, s, qkv, out, C, heads, HW, scale); break;
-        case 3: hipLaunchKernelGGL(attn_mfma_kernel<3>, grid, dim3(256), 0, s, qkv, out, C, heads, HW, scale); break;
-        case 4: hipLaunchKernelGGL(attn_mfma_kernel<4>, grid, dim3(256), 0, s, qkv, out, C, heads, HW, scale); break;
+    const size_t lds = (size_t)D * (32 + 33) * sizeof(float);
+#define ATTN_CASE(DT)                                                                                              \
+    case DT: {                                                                                                     \
+        if (lds > 64 * 1024) {                                                                                     \
+            static PerDeviceOnce raised;                                                                           \
+            if (raised.first_use()) {                                                                              \
+                MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<DT>),           \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
+                raised.done();                                                                                     \
+            }                                                                                                      \
+        }                                                                                                          \
+        hipLaunchKernelGGL(attn_mfma_kernel<DT>, grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale);          \
+        break;                                                                                                     \
     }
+    switch (D / 32) {
+        ATTN_CASE(1) ATTN_CASE(2) ATTN_CASE(3) ATTN_CASE(4) ATTN_CASE(5) ATTN_CASE(6) ATTN_CASE(7) ATTN_CASE(8)
+    }
+#undef ATTN_CASE
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -227,6 +227,56 @@ def wphases(f):
     ctx.opt("conv_shape", -1)
 
 
+def sweep1(f):
+    """Every 1x1 layer shape of config 2 at B=64 against every kernel candidate (direct tiles 0-2, all-DMA 16/32-channel chunks x cout tiles)."""
+    from tests.hiputil import Ctx
+    ctx = Ctx()
+    B = 64
+    shapes = [(192, 192, 64, 0, 0), (288, 96, 64, 0, 0), (192, 96, 64, 0, 0), (96, 96, 32, 0, 0), (96, 192, 32, 0, 0), (480, 192, 32, 0, 0),
+              (384, 192, 32, 0, 0), (288, 192, 32, 0, 0), (288, 288, 32, 0, 0), (192, 576, 32, 1, 0), (192, 192, 32, 0, 1),
+              (288, 864, 16, 1, 0), (288, 288, 16, 0, 1), (672, 288, 16, 0, 0), (384, 384, 16, 0, 0), (384, 1152, 8, 1, 0),
+              (384, 384, 8, 0, 1), (768, 384, 8, 0, 0)]
+    f.write("# 1x1 conv candidates at B=64: Cin Cout H coef res | candidate: us (TF)\n")
+    for cin, cout, H, use_coef, use_res in shapes:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, 1, 1, device="cuda") / cin ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda") if use_coef else None
+        res = torch.randn(B, cout, H, H, device="cuda") if use_res else None
+        flops = 2.0 * B * H * H * cout * cin
+        byts = 4.0 * B * H * H * (cin + cout * (2 if use_res else 1))
+        line = f"{cin:4d} {cout:4d} {H:3d} c{use_coef} r{use_res} |"
+        best = (1e9, "")
+        cands = [(0, 0), (1, 0), (2, 0)] + [(5, c) for c in (9, 6, 4, 3, 2, 1)] + [(6, c) for c in (6, 4, 3, 2, 1)]
+        for shape, cot in cands:
+            n32 = -(-cout // 32)
+            if shape >= 5 and n32 % cot != 0:
+                continue
+            ctx.opt("conv_shape", shape)
+            ctx.opt("conv_cot", cot)
+            try:
+                for _ in range(2):
+                    ctx.conv2d(x, w, b, coef=coef, act=0, res=res, scale=0.7)
+                if shape >= 5 and _lib.lib.mcvd_last_conv_kernel() != shape:
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    ctx.conv2d(x, w, b, coef=coef, act=0, res=res, scale=0.7)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 5
+                line += f" s{shape}c{cot}:{us:6.1f}({flops / us / 1e6:5.1f})"
+                if us < best[0]:
+                    best = (us, f"s{shape}c{cot}")
+            except RuntimeError as e:
+                line += f" s{shape}c{cot}:n/a"
+        f.write(line + f" || best {best[1]} {best[0]:.1f} us = {flops / best[0] / 1e6:.1f} TF, {byts / best[0] / 1e6:.2f} TB/s alg\n")
+        f.flush()
+    ctx.opt("conv_shape", -1)
+    ctx.opt("conv_cot", 0)
+
+
 def wexp(f):
     """Timing-only ablations of the Winograd K loop (conv_wino.cpp EXP builds, env MCVD_WINO_EXP): kernel time and the K-loop
     cycles per 16-channel chunk of one wave, per ablation."""
@@ -286,6 +336,6 @@ if __name__ == "__main__":
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "sweep1": sweep1}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 

@@ -175,7 +175,13 @@ def test_gn_coef(ctx, B, C0, C1, H, mode):
 
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,C,heads,H", [(2, 64, 2, 8), (2, 192, 2, 32), (3, 288, 3, 16), (2, 384, 4, 8), (2, 256, 2, 16),
-                                         (1, 64, 1, 16)])
+                                         (1, 64, 1, 16),
+                                         (2, 320, 2, 16),      # head dim 160
+                                         (2, 192, 1, 16),      # head dim 192 (configs/cityscapes_big_spade.yml: n_head_channels 192)
+                                         (1, 448, 2, 8),       # head dim 224: no register prefetch of the next K/V tile
+                                         (2, 256, 1, 16),      # head dim 256: 65 KiB of dynamic LDS
+                                         (1, 320, 1, 8),       # head dim 320 (n_head_channels = -1 on a wide level): general kernel
+                                         (1, 48, 1, 8)])       # head dim not a multiple of 32: general kernel
 @pytest.mark.parametrize("naive", [0, 1], ids=["mfma", "naive"])
 def test_attention(ctx, B, C, heads, H, naive):
     g = _g(9)
@@ -337,6 +343,23 @@ def test_fpndm_vs_reference_golden(golden_dir, ctx):
     assert get_sampler(config).func is fpndm_sampler
     with pytest.raises(TypeError):
         fpndm_sampler(x.cuda(), net, cond=cond.cuda())                  # subsample_steps is mandatory, as in the reference
+
+
+def test_single_head_attention_model():
+    """model.n_head_channels = -1: one head spanning all channels of the level (layerspp.py:219-228)."""
+    config = synth.make_config("tiny")
+    config.model.n_head_channels = -1
+    config.device = "cuda:0"
+    from mcvd_pytorch_amd.scorenet import HipScoreNet
+    sd = synth.make_state_dict(config, seed=123)
+    net = HipScoreNet(config)
+    net.load_state_dict(sd, strict=True)
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    t = torch.tensor([990, 130])
+    eps = net(x.cuda(), t.cuda(), cond=cond.cuda()).cpu()
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t, cond)
+    assert (eps - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
 def test_float_timesteps_match_integer_labels():
