@@ -92,7 +92,8 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  * kernel to the autotuner), "conv_cot" (with conv_shape 5: cout tile, in 32-channel units, that mcvd_op_conv2d requests), "conv_wdma" (1: weight
  * chunks by LDS-DMA, 0: register staging), "autotune" (1: time the conv tile candidates per layer shape on first use of a batch
  * size and keep the fastest), "side_stream" (1: ResBlock shortcut convs run on a second HIP stream concurrently with Conv_0; default 0, it measured slower), "profile" (0/1, see
- * mcvd_model_profile_read), "graph" (0/1: replay each UNet forward as ONE hipGraph launch instead of ~190 kernel launches -- a forward is
+ * mcvd_model_profile_read), "gn_stats" (1: GroupNorm statistics come out of the producing conv's epilogue where the kernel supports it, 0: always one pass
+ * over the normalised tensor), "graph" (0/1: replay each UNet forward as ONE hipGraph launch instead of ~190 kernel launches -- a forward is
  * run eagerly the first time a (x, labels, cond, eps, B) pointer set is seen, captured on a private stream the second time and
  * replayed afterwards; mcvd_sampler_run presents the same set on every step.  Any option change, re-tune, workspace growth or
  * mcvd_model_finalize drops the captured graph.  Also MCVD_GRAPH=1 in the environment at mcvd_ctx_create). */
@@ -228,6 +229,18 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
  * implicit-GEMM tile shapes, 4 Winograd F(2x2,3x3), 8 Winograd with the 2-way K split, 5 / 6 all-DMA 1x1 GEMM; -1 none yet.  A forced
  * "conv_shape" that does not apply to a launch falls back to the direct kernel -- tests use this to assert what really ran. */
 int mcvd_last_conv_kernel(void);
+/* GroupNorm statistics from the producing conv's epilogue.  When a buffer is set (device floats, >= B*Cout*(H*W/32)*2; NULL
+ * disables), mcvd_op_conv2d's MFMA kernels also write, for every (sample, cout), np partial pairs (sum, M2 about the partial's own
+ * mean) over disjoint sets of H*W/np output pixels: stats[((b*Cout + co)*np + p)*2 + {0,1}].  np depends on the kernel family that
+ * ran -- mcvd_last_conv_stats_np(): Winograd H*W/128 (8x8 images: 1), Winograd K split 1, all-DMA 1x1 H*W/32, 0 = that kernel
+ * does not emit (direct implicit-GEMM tiles) and a consumer must take mcvd_op_gn_coef's pass over the tensor instead.
+ * mcvd_op_gn_finalize folds the partials of one tensor or of a virtual channel concat of two (each with its own np) into the same
+ * (A, B) coefficients mcvd_op_gn_coef produces (modes / p0 / p1 / emb_* as there).  Inside a model forward this is automatic
+ * (ctx option "gn_stats", default 1). */
+int mcvd_ctx_set_stats_buffer(mcvd_ctx* ctx, float* device_floats);
+int mcvd_last_conv_stats_np(void);
+int mcvd_op_gn_finalize(mcvd_ctx* ctx, const float* st0, int C0, int np0, const float* st1, int C1, int np1, int groups, float eps,
+                        int mode, const float* p0, const float* p1, int emb_stride, int emb_off, float* coef_out, int B, int HW);
 /* GroupNorm statistics folded to per-(b,c) affine coefficients: y = A*x + B.
  * mode 0: plain (A=rstd, B=-mean*rstd); mode 1: temb scale/shift, emb:[B, emb_stride] with scale at emb_off+c and shift at
  * emb_off+C+c (layerspp.py:521-535); mode 2: affine weight/bias:[C] (torch GroupNorm affine=True). */

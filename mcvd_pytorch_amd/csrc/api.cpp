@@ -46,6 +46,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     if (const char* t = getenv("MCVD_WINOGRAD")) c->winograd = atoi(t);
     if (const char* t = getenv("MCVD_CONV_DMA1")) c->conv_dma1 = atoi(t);
     if (const char* t = getenv("MCVD_GRAPH")) c->graph = atoi(t);
+    if (const char* t = getenv("MCVD_GN_STATS")) c->gn_stats = atoi(t);
     const char* e = getenv("MCVD_NAIVE");
     if (e) {
         const int v = atoi(e);
@@ -79,6 +80,12 @@ int mcvd_ctx_set_debug_buffer(mcvd_ctx* ctx, void* device_u64) {
     return 0;
 }
 
+int mcvd_ctx_set_stats_buffer(mcvd_ctx* ctx, float* device_floats) {
+    MCVD_REQUIRE(ctx, "ctx is NULL");
+    ctx->stats_buf = device_floats;
+    return 0;
+}
+
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     MCVD_REQUIRE(ctx && key, "ctx/key is NULL");
     ++ctx->epoch;                  // captured graphs embed the kernels the options select
@@ -93,6 +100,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "winograd")) ctx->winograd = value;
     else if (!strcmp(key, "conv_dma1")) ctx->conv_dma1 = value;
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
+    else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
     else {
         set_error("unknown option '%s'", key);
         return MCVD_EINVAL;
@@ -657,11 +665,23 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     if ((ctx->conv_shape == 5 || ctx->conv_shape == 6) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
     a.wdma = ctx->conv_wdma;
     a.dbg = ctx->dbg;
+    a.stats = ctx->naive_conv ? nullptr : ctx->stats_buf;
     return ctx->naive_conv ? launch_conv_naive(a, ctx->stream) : launch_conv_mfma(a, ctx->stream);
     API_CATCH
 }
 
 int mcvd_last_conv_kernel(void) { return last_conv_kernel(); }
+
+int mcvd_last_conv_stats_np(void) { return last_conv_stats_np(); }
+
+int mcvd_op_gn_finalize(mcvd_ctx* ctx, const float* st0, int C0, int np0, const float* st1, int C1, int np1, int groups, float eps,
+                        int mode, const float* p0, const float* p1, int emb_stride, int emb_off, float* coef_out, int B, int HW) {
+    MCVD_REQUIRE(ctx && st0 && coef_out, "op_gn_finalize: NULL argument");
+    GnArgs a{};
+    a.C0 = C0; a.C1 = st1 ? C1 : 0; a.groups = groups; a.eps = eps; a.mode = mode; a.p0 = p0; a.p1 = p1;
+    a.emb_stride = emb_stride; a.emb_off = emb_off; a.coef = coef_out; a.B = B; a.HW = HW;
+    return launch_gn_finalize(a, st0, np0, st1, np1, ctx->stream);
+}
 
 int mcvd_model_graph_stats(mcvd_model* m, int64_t* captures, int64_t* replays) {
     MCVD_REQUIRE(m, "graph_stats: NULL model");

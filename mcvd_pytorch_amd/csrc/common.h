@@ -73,7 +73,14 @@ struct ConvArgs {
     float* part;          // ksplit == 2: scratch for the two partial results, 2 * B*Cout*H*W floats
     int wdma;             // 1: stage weight chunks by LDS-DMA (default), 0: through registers
     unsigned long long* dbg;   // optional: per-block phase cycle counters [n_blocks][8] (diagnostics), else null
+    // GroupNorm statistics from the producer's epilogue (layerspp.py:518-549 consumes them): when non-null, the kernel writes for
+    // every (sample, cout) `np` partial pairs (sum, M2 about the partial's own mean) over disjoint pixel sets of HW / np pixels
+    // each, stats[((b * Cout + co) * np + p) * 2 + {0, 1}], of the FINAL output values.  np depends on the kernel that runs
+    // (last_conv_stats_np() reports it; 0 = this kernel does not emit, the consumer then reads the tensor itself).
+    float* stats;
 };
+void set_last_conv_stats_np(int np);          // (launchers)
+int last_conv_stats_np();                     // partials per (sample, channel) the thread's last conv launch wrote to a.stats; 0 = none
 int conv_cout_tile(int Cout);                 // 32-channel units per block along Cout
 int conv_chunk(int ks);                       // input-channel chunk the MFMA kernel consumes per stage
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s);
@@ -109,6 +116,10 @@ struct GnArgs {
     int B, HW;
 };
 int launch_gn_coef(const GnArgs& a, hipStream_t s);
+// The same coefficients from producer-side partial statistics (ConvArgs::stats) instead of a pass over the tensor: partial p of
+// channel c of source i holds (sum, M2) over HW / np_i pixels; combined per group with the pairwise (Chan et al.) update, in a
+// fixed order.  x0 / x1 of `a` are not read.
+int launch_gn_finalize(const GnArgs& a, const float* st0, int np0, const float* st1, int np1, hipStream_t s);
 
 // ------------------------------------------------------------------ attention
 bool attention_mfma_supported(int C, int heads, int HW);      // head dim 32..256 in steps of 32, HW % 32 == 0; else the general kernel

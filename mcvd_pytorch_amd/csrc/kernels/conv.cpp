@@ -25,7 +25,13 @@ static int env_int(const char* name, int dflt) {
 static thread_local int g_last_conv_kernel = -1;
 int last_conv_kernel() { return g_last_conv_kernel; }
 
+// partials per (sample, channel) the last conv launch of this thread wrote into a.stats (0: the kernel that ran does not emit)
+static thread_local int g_last_stats_np = 0;
+int last_conv_stats_np() { return g_last_stats_np; }
+void set_last_conv_stats_np(int np) { g_last_stats_np = np; }
+
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
+    g_last_stats_np = 0;
     MCVD_REQUIRE(a.ks == 1 || a.ks == 3, "conv: kernel size %d unsupported", a.ks);
     MCVD_REQUIRE(a.W >= 8 && (a.W & (a.W - 1)) == 0 && a.W <= 256, "conv: W=%d must be a power of two in [8,256]", a.W);
     static const int forced = env_int("MCVD_CONV_SHAPE", -1);

@@ -149,6 +149,22 @@ __global__ __launch_bounds__(256, COT <= 3 ? 4 : 1) void conv1x1_dma_kernel(Conv
             const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const float v = (acc[ct][r] + a.bias[co] + rv[r]) * a.out_scale;     // bias is zero-padded to CoutP
             if (co < a.Cout) a.y[obase + (long)co * HW] = v;
+            if (a.stats) {
+                // GroupNorm partials for the next norm (ConvArgs::stats): the 32 lanes of a half-wave hold 32 consecutive pixels
+                // of ONE image (HW % 32 == 0) for this cout -> (sum, M2 about their mean), partial index = pixel block op / 32
+                float sm = v;
+#pragma unroll
+                for (int o2 = 16; o2 > 0; o2 >>= 1) sm += __shfl_xor(sm, o2);
+                const float d = v - sm * (1.0f / 32.0f);
+                float m2 = d * d;
+#pragma unroll
+                for (int o2 = 16; o2 > 0; o2 >>= 1) m2 += __shfl_xor(m2, o2);
+                if (l31 == 0 && co < a.Cout) {
+                    float* q = a.stats + (((long)ob * a.Cout + co) * (HW >> 5) + (op >> 5)) * 2;
+                    q[0] = sm;
+                    q[1] = m2;
+                }
+            }
         }
     }
 }
@@ -223,7 +239,9 @@ int launch_conv1x1_dma(const ConvArgs& a, int cot_req, int ck, hipStream_t s) {
     const int n32 = a.CoutP / 32;
     const int cot = g1_cot_ok(n32, cot_req) ? cot_req : conv1x1_dma_cout_tile(a.CoutP);
     MCVD_REQUIRE(!(ck == 32 && cot == 9), "conv1x1 dma: cout tile 9 with 32-channel chunks exceeds the LDS budget");
-    return ck == 32 ? g1_dispatch<32>(a, cot, s) : g1_dispatch<16>(a, cot, s);
+    const int rc = ck == 32 ? g1_dispatch<32>(a, cot, s) : g1_dispatch<16>(a, cot, s);
+    if (rc == 0 && a.stats) set_last_conv_stats_np(a.H * a.W / 32);
+    return rc;
 }
 
 }  // namespace mcvd

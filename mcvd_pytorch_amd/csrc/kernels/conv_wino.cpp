@@ -442,10 +442,46 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
             float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
             const float bvv = fin ? a.bias[co] : 0.0f;          // zero-padded to CoutP
             const float osc = fin ? a.out_scale : 1.0f;
+            const float v00 = (y00 + bvv + r0.x) * osc, v01 = (y01 + bvv + r0.y) * osc;
+            const float v10 = (y10 + bvv + r1.x) * osc, v11 = (y11 + bvv + r1.y) * osc;
             if (co < a.Cout && e_valid) {
                 const long o = ((long)e_b * a.Cout + co) * HW + pix;
-                *reinterpret_cast<float2*>(ydst + o) = make_float2((y00 + bvv + r0.x) * osc, (y01 + bvv + r0.y) * osc);
-                *reinterpret_cast<float2*>(ydst + o + W) = make_float2((y10 + bvv + r1.x) * osc, (y11 + bvv + r1.y) * osc);
+                *reinterpret_cast<float2*>(ydst + o) = make_float2(v00, v01);
+                *reinterpret_cast<float2*>(ydst + o + W) = make_float2(v10, v11);
+            }
+            if (a.stats && fin) {
+                // GroupNorm partials of the FINAL values for the next norm (ConvArgs::stats).  The 32 tiles of this cout are the 32
+                // lanes of a half-wave (G8: 16 lanes = one DPP row per image).  Each lane folds its own 2x2 pixels into (mean, M2)
+                // exactly, then the lanes are merged pairwise with the equal-count update  M2 = M2a + M2b + (ma - mb)^2 * n/2,
+                // mean = (ma + mb)/2  over DPP moves (no LDS traffic): xor 1, xor 2 inside quads, rotate 4, rotate 8 inside the
+                // 16-lane row (every lane then holds the row total), row_bcast:15 into the upper row of the half-wave.
+                float mu = 0.25f * ((v00 + v01) + (v10 + v11));
+                const float d0 = v00 - mu, d1 = v01 - mu, d2 = v10 - mu, d3 = v11 - mu;
+                float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                float hn = 2.0f;                      // n/2 of the two partials being merged (4 pixels each at the first step)
+#define WR_MERGE(CTRL, ROWMASK)                                                                                     \
+                {                                                                                                   \
+                    const float mo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, mu), __builtin_bit_cast(int, mu), CTRL, ROWMASK, 0xf, false)); \
+                    const float qo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m2), __builtin_bit_cast(int, m2), CTRL, ROWMASK, 0xf, false)); \
+                    const float dd = mu - mo;                                                                       \
+                    m2 = (m2 + qo) + dd * dd * hn;                                                                  \
+                    mu = 0.5f * (mu + mo);                                                                          \
+                    hn += hn;                                                                                       \
+                }
+                WR_MERGE(0xB1, 0xf)                   // quad_perm [1,0,3,2]
+                WR_MERGE(0x4E, 0xf)                   // quad_perm [2,3,0,1]
+                WR_MERGE(0x124, 0xf)                  // row_ror:4
+                WR_MERGE(0x128, 0xf)                  // row_ror:8   -> 16 lanes = 64 pixels merged, in every lane of the row
+                if (!G8) WR_MERGE(0x142, 0xa)         // row_bcast:15 (rows 1 and 3 take the total of rows 0 and 2): lanes 16-31 / 48-63
+#undef WR_MERGE
+                constexpr int NPIX = G8 ? 64 : 128;
+                const bool writer = G8 ? (e_tile & 15) == 0 : e_tile == 31;
+                if (writer && co < a.Cout && e_valid) {
+                    const int np = G8 ? 1 : rx_n * ry_n;
+                    float* q = a.stats + (((long)e_b * a.Cout + co) * np + rr) * 2;
+                    q[0] = mu * (float)NPIX;          // the partial's sum
+                    q[1] = m2;
+                }
             }
         }
         if (ct + 1 < COT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -482,6 +518,37 @@ __global__ __launch_bounds__(256) void wino_ksplit_reduce_kernel(const float* pa
         f32x4 v = p0 + p1 + bv;
         if (res) v = v + reinterpret_cast<const f32x4*>(res)[i];
         reinterpret_cast<f32x4*>(y)[i] = v * scale;
+    }
+}
+
+// The same pass with GroupNorm partials of the final values (ConvArgs::stats): one (sample, channel) plane = HW4 consecutive
+// float4 of the flat index = PL lanes of one wave (HW4 = 16 or 64), one partial per plane over its HW pixels.
+template <int PL>
+__global__ __launch_bounds__(256) void wino_ksplit_reduce_stats_kernel(const float* part, const float* bias, const float* res, float scale,
+                                                                       float* y, long n4, long half_stride, int Cout, float* stats) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    const bool in = i < n4;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (in) {
+        const f32x4 p0 = reinterpret_cast<const f32x4*>(part)[i];
+        const f32x4 p1 = reinterpret_cast<const f32x4*>(part + half_stride)[i];
+        const float bv = bias[(i / PL) % Cout];
+        v = p0 + p1 + bv;
+        if (res) v = v + reinterpret_cast<const f32x4*>(res)[i];
+        v = v * scale;
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+    float sm = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int o = PL / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    const float mu = sm * (1.0f / (4 * PL));
+    const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
+    float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+    for (int o = PL / 2; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+    if (in && (threadIdx.x & (PL - 1)) == 0) {          // a plane is never split between valid and invalid lanes (n4 % PL == 0)
+        stats[(i / PL) * 2] = sm;
+        stats[(i / PL) * 2 + 1] = m2;
     }
 }
 
@@ -554,10 +621,24 @@ static int wino_launch3(const ConvArgs& a, hipStream_t s) {
     MCVD_HIP_CHECK(hipGetLastError());
     if (ksp == 2) {                                    // second pass: p0 + p1 + bias + res, scaled
         const long n = (long)a.B * a.Cout * a.H * a.W, n4 = n / 4;
-        const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
-        hipLaunchKernelGGL(wino_ksplit_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale, a.y, n4, n,
-                           a.Cout, a.H * a.W / 4);
+        const int hw4 = a.H * a.W / 4;
+        if (a.stats && (hw4 == 16 || hw4 == 64)) {     // ... with the GroupNorm partials of the final values (one per plane)
+            const int blocks = (int)((n4 + 255) / 256);
+            if (hw4 == 16)
+                hipLaunchKernelGGL(wino_ksplit_reduce_stats_kernel<16>, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale,
+                                   a.y, n4, n, a.Cout, a.stats);
+            else
+                hipLaunchKernelGGL(wino_ksplit_reduce_stats_kernel<64>, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale,
+                                   a.y, n4, n, a.Cout, a.stats);
+            set_last_conv_stats_np(1);
+        } else {
+            const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+            hipLaunchKernelGGL(wino_ksplit_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale, a.y, n4, n,
+                               a.Cout, hw4);
+        }
         MCVD_HIP_CHECK(hipGetLastError());
+    } else if (a.stats) {
+        set_last_conv_stats_np(G8 ? 1 : (a.H / 8) * (a.W / 16));
     }
     return 0;
 }

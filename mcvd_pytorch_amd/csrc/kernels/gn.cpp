@@ -81,6 +81,83 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(GnArgs a) {
     }
 }
 
+// One wave per (sample, group).  Partials (sum_i, M2_i, n_i) -> N = sum n_i, mean = sum sum_i / N,
+// M2 = sum (M2_i + n_i (sum_i / n_i - mean)^2): exact identities, every term non-negative (no cancellation).
+__global__ __launch_bounds__(64) void gn_finalize_kernel(GnArgs a, const float* st0, int np0, const float* st1, int np1) {
+    const int C = a.C0 + a.C1;
+    const int gs = C / a.groups;
+    const int b = blockIdx.x / a.groups;
+    const int g = blockIdx.x - b * a.groups;
+    const int c0 = g * gs;
+    const int lane = threadIdx.x;
+    // channels of the group that live in source 0 / source 1
+    const int n_in0 = max(0, min(c0 + gs, a.C0) - c0), n_in1 = gs - n_in0;
+    const int P0 = n_in0 * np0, P = P0 + n_in1 * np1;
+    const float n0 = (float)(a.HW / max(np0, 1)), n1 = (float)(a.HW / max(np1, 1));
+    auto part = [&](int i, float& sum, float& m2, float& n) {
+        if (i < P0) {
+            const int cl = i / np0, p = i - cl * np0;
+            const float* q = st0 + (((long)b * a.C0 + c0 + cl) * np0 + p) * 2;
+            sum = q[0]; m2 = q[1]; n = n0;
+        } else {
+            const int j = i - P0;
+            const int cl = j / np1, p = j - cl * np1;
+            const int c1 = max(c0, a.C0) - a.C0 + cl;
+            const float* q = st1 + (((long)b * a.C1 + c1) * np1 + p) * 2;
+            sum = q[0]; m2 = q[1]; n = n1;
+        }
+    };
+    float tot = 0.0f;
+    for (int i = lane; i < P; i += 64) {
+        float sm, m2, n;
+        part(i, sm, m2, n);
+        tot += sm;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    const float N = (float)gs * (float)a.HW;
+    const float mean = tot / N;
+    float acc = 0.0f;
+    for (int i = lane; i < P; i += 64) {
+        float sm, m2, n;
+        part(i, sm, m2, n);
+        const float d = sm / n - mean;
+        acc += m2 + n * d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const float var = acc / N;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    for (int cl = lane; cl < gs; cl += 64) {
+        const int c = c0 + cl;
+        float A, Bc;
+        if (a.mode == 1) {
+            const float* e = a.p0 + (long)b * a.emb_stride + a.emb_off;
+            const float sc = 1.0f + e[c];
+            A = rstd * sc;
+            Bc = e[C + c] - mean * rstd * sc;
+        } else if (a.mode == 2) {
+            A = rstd * a.p0[c];
+            Bc = a.p1[c] - mean * rstd * a.p0[c];
+        } else {
+            A = rstd;
+            Bc = -mean * rstd;
+        }
+        a.coef[((long)b * C + c) * 2] = A;
+        a.coef[((long)b * C + c) * 2 + 1] = Bc;
+    }
+}
+
+int launch_gn_finalize(const GnArgs& a, const float* st0, int np0, const float* st1, int np1, hipStream_t s) {
+    const int C = a.C0 + a.C1;
+    MCVD_REQUIRE(a.groups > 0 && C % a.groups == 0, "gn: %d channels not divisible by %d groups", C, a.groups);
+    MCVD_REQUIRE(st0 && np0 > 0 && a.HW % np0 == 0 && (a.C1 == 0 || (st1 && np1 > 0 && a.HW % np1 == 0)),
+                 "gn_finalize: bad partial statistics (np0=%d np1=%d HW=%d)", np0, np1, a.HW);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B * a.groups), dim3(64), 0, s, a, st0, np0, st1, a.C1 ? np1 : 1);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_gn_coef(const GnArgs& a, hipStream_t s) {
     const int C = a.C0 + a.C1;
     MCVD_REQUIRE(a.groups > 0 && C % a.groups == 0, "gn: %d channels not divisible by %d groups", C, a.groups);

@@ -509,6 +509,23 @@ int mcvd_model::build_plan() {
     freqs_off = bld.alloc_packed(nf / 2);
     arena_per_sample = bld.arena;
     packed_floats = bld.packed;
+    // GroupNorm statistics come out of the producing conv's epilogue: find, for every norm, the conv that wrote each source
+    for (size_t gi = 0; gi < ops.size(); ++gi) {
+        if (ops[gi].kind != OP_GN) continue;
+        for (int side = 0; side < 2; ++side) {
+            const TRef& src = side ? ops[gi].src1 : ops[gi].src0;
+            if (src.kind != REF_ARENA) continue;
+            for (size_t pi = 0; pi < gi; ++pi) {
+                Op& p = ops[pi];
+                if (p.kind == OP_CONV && p.dst.kind == REF_ARENA && p.dst.off == src.off && p.H * p.W % 32 == 0) {
+                    if (p.stats.kind == REF_NONE) p.stats = bld.alloc_floats((int64_t)p.Cout * (p.H * p.W / 32) * 2, p.Cout);
+                    (side ? ops[gi].prod1 : ops[gi].prod0) = (int)pi;
+                }
+            }
+        }
+    }
+    arena_per_sample = bld.arena;
+    stats_np.assign(ops.size(), 0);
     if (c.noise_in_cond) {            // gamma/beta depend on the noised conditioning frames: nothing can be hoisted out of the step
         for (Op& op : ops) op.prep = false;
         has_prep = false;
@@ -591,6 +608,12 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.coef = resolve(op.coef, x, cond, out, B);
             a.B = B;
             a.HW = op.H * op.W;
+            // statistics already computed by the producers' epilogues (every source must have them), else one pass over the tensor
+            const int np0 = op.prod0 >= 0 ? stats_np[op.prod0] : 0;
+            const int np1 = a.C1 == 0 ? 1 : (op.prod1 >= 0 ? stats_np[op.prod1] : 0);
+            if (ctx->gn_stats && np0 > 0 && np1 > 0)
+                return launch_gn_finalize(a, resolve(ops[op.prod0].stats, x, cond, out, B), np0,
+                                          a.C1 ? resolve(ops[op.prod1].stats, x, cond, out, B) : nullptr, np1, s);
             return launch_gn_coef(a, s);
         }
         case OP_CONV: {
@@ -625,7 +648,17 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                 a.shape_hint = tuned_shape[oi];
                 a.cot = tuned_cot[oi];
             }
-            return ctx->naive_conv ? launch_conv_naive(a, s) : launch_conv_mfma(a, s);
+            // epilogue statistics from the 3x3 (Winograd) producers; the 1x1 GEMM's epilogue can emit them too, but its 16*COT
+            // 32-lane reductions per wave cost the NIN_3 launches more than the norms they spare save (measured): "gn_stats" = 2 only
+            a.stats = (ctx->gn_stats && op.stats.kind != REF_NONE && !ctx->naive_conv && (op.ks == 3 || ctx->gn_stats >= 2))
+                          ? resolve(op.stats, x, cond, out, B) : nullptr;
+            if (ctx->naive_conv) {
+                stats_np[oi] = 0;
+                return launch_conv_naive(a, s);
+            }
+            const int rc = launch_conv_mfma(a, s);
+            stats_np[oi] = a.stats ? last_conv_stats_np() : 0;
+            return rc;
         }
         case OP_FIR: {
             const float* gb = op.gb.kind == REF_NONE ? nullptr : resolve(op.gb, x, cond, out, B);
@@ -760,7 +793,9 @@ int mcvd_model::autotune(int B) {
                     if (int rc = time_candidate(8, op.cot)) return rc;
             }
             if (op.ks == 1 && ctx->conv_dma1) {        // 5 / 6 = all-DMA 1x1 GEMM (16 / 32 channels per chunk), cout tiles of its own
-                static const int g1_cots[] = {9, 6, 4, 3, 2, 1};
+                // small cout tiles first: the sweep of every 1x1 layer shape (profiles/r02_conv1x1_candidates.txt) has tiles 1-3 winning
+                // everywhere; 6 / 9 never did
+                static const int g1_cots[] = {2, 1, 3, 4, 6, 9};
                 for (int ck = 16; ck <= 32; ck += 16) {
                     if (!conv1x1_dma_supported(a, ck)) continue;
                     int tried = 0;

@@ -25,9 +25,11 @@ struct mcvd_ctx {
     int side_stream = 0;           // 1: run the ResBlock shortcut 1x1 convs on a second stream (measured -2 %: off by default)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int gn_stats = 1;              // GroupNorm statistics from the producing conv's epilogue (0: always one pass over the tensor)
     int autotune = 1;              // time the conv tile candidates per distinct layer shape on first use of a batch size
     int profile = 0;               // record HIP events around every op of the first forward of each sampler call
     unsigned long long* dbg = nullptr;   // conv phase-timing buffer for mcvd_op_conv2d (diagnostics)
+    float* stats_buf = nullptr;          // mcvd_op_conv2d: where the conv's GroupNorm partials go (mcvd_ctx_set_stats_buffer; tests)
     float* scratch = nullptr;      // small device scratch for stand-alone ops (kernel taps, packed weights)
     size_t scratch_bytes = 0;
     int ensure_scratch(size_t bytes);
@@ -83,6 +85,11 @@ struct Op {
     bool side = false;             // independent of the main chain until `join`: may run on the side stream
     bool join = false;             // must wait for the preceding side op
     bool prep = false;             // depends on the conditioning frames only: runs once per cond, not per step
+    // GroupNorm statistics from the producer's epilogue: a conv whose output is normalised later writes partial (sum, M2) pairs
+    // to `stats` ([C][H*W/32][2] floats per sample reserved; how many partials are used depends on the kernel that runs); a
+    // GroupNorm op names the plan ops that produce its sources (-1: not a conv of this plan)
+    TRef stats;
+    int prod0 = -1, prod1 = -1;
 };
 
 struct DenseEntry {
@@ -142,6 +149,7 @@ struct mcvd_model {
     std::vector<float> betas, alphas, alphas_prev, freqs;
 
     // conv tile choice per op for the batch size it was tuned at: (shape, cot); filled by autotune()
+    std::vector<int> stats_np;        // per op: partials per (sample, channel) its last launch wrote (0: none)
     std::vector<int> tuned_shape, tuned_cot;
     int tuned_B = 0;
     // every batch size tuned (or imported through mcvd_model_set_tuning) so far: alternating batch sizes do not re-tune

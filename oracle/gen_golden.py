@@ -421,6 +421,8 @@ def main_round2():
         gen_autoregressive("cityscapes_big", 1, 8, 100)
     if "f4" in which:
         gen_f4()
+    if "cs_spade" in which:
+        gen_forward_only("cityscapes_big_spade", 1)          # shipped config with 192-channel heads (VERDICT r01 missing item 5)
 
 
 if __name__ == "__main__":

@@ -50,6 +50,10 @@ def make_config(name):
         data.update(image_size=128, channels=3, num_frames_cond=2)
         model.update(ngf=128, n_head_channels=128, ch_mult=[1, 1, 2, 3, 4])
         sampling.update(num_frames_pred=28)
+    elif name == "cityscapes_big_spade":     # configs/cityscapes_big_spade.yml as shipped: ngf 192, 2/3/4 heads of 192 channels, SPADE dim 256
+        data.update(image_size=128, channels=3, num_frames_cond=2)
+        model.update(ngf=192, n_head_channels=192, ch_mult=[1, 1, 2, 3, 4], spade=True, spade_dim=256)
+        sampling.update(num_frames_pred=28)
     elif name == "cityscapes_big_variant":   # BASELINE.json wording: ch_mult [1,2,3,4,4], attention at 16 only
         data.update(image_size=128, channels=3, num_frames_cond=2)
         model.update(ngf=128, n_head_channels=128, ch_mult=[1, 2, 3, 4, 4], attn_resolutions=[16])

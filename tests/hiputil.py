@@ -28,6 +28,28 @@ class Ctx:
                                            P(res), scale, P(y), B, H, W), "op_conv2d")
         return y
 
+    def conv2d_stats(self, x0, w, bias, **kw):
+        """conv2d that also returns the GroupNorm partials its epilogue wrote: (y, stats [B, Cout, np, 2], np); np == 0 means the
+        kernel that ran does not emit."""
+        B, Cout, H, W = x0.shape[0], w.shape[0], x0.shape[2], x0.shape[3]
+        buf = torch.full((B * Cout * (H * W // 32) * 2,), float("nan"), device=x0.device)
+        _lib.check(_lib.lib.mcvd_ctx_set_stats_buffer(self.h, P(buf)))
+        try:
+            y = self.conv2d(x0, w, bias, **kw)
+            np_ = _lib.lib.mcvd_last_conv_stats_np()
+        finally:
+            _lib.check(_lib.lib.mcvd_ctx_set_stats_buffer(self.h, None))
+        st = buf[:B * Cout * np_ * 2].view(B, Cout, np_, 2) if np_ > 0 else None
+        return y, st, np_
+
+    def gn_finalize(self, st0, np0, groups, eps, mode, HW, st1=None, np1=1, p0=None, p1=None, emb_stride=0, emb_off=0):
+        B, C0 = st0.shape[:2]
+        C1 = st1.shape[1] if st1 is not None else 0
+        coef = torch.empty(B, C0 + C1, 2, device=st0.device)
+        _lib.check(_lib.lib.mcvd_op_gn_finalize(self.h, P(st0.contiguous()), C0, np0, P(st1.contiguous()) if st1 is not None else None, C1, np1,
+                                                groups, eps, mode, P(p0), P(p1), emb_stride, emb_off, P(coef), B, HW), "op_gn_finalize")
+        return coef
+
     def gn_coef(self, x0, groups, eps, mode, x1=None, p0=None, p1=None, emb_stride=0, emb_off=0):
         B, C0 = x0.shape[:2]
         C1 = x1.shape[1] if x1 is not None else 0

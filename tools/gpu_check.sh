@@ -27,6 +27,11 @@ graphab)
     timeout 600 python bench.py --steps 2 --warmup 1 --graph $g --no-cpu-baseline --tune-cache $TUNE > gpurun_out/bench_graph$g.json 2> gpurun_out/bench_graph$g.err
     python -c "import json;d=json.load(open('gpurun_out/bench_graph$g.json'));print('graph$g', d['value'], d['ms_per_step'])"
   done;;
+gnab)
+  for g in 0 1; do
+    MCVD_GN_STATS=$g timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_gn$g.json 2> gpurun_out/bench_gn$g.err
+    python -c "import json;d=json.load(open('gpurun_out/bench_gn$g.json'));print('gn_stats$g', d['value'], d['ms_per_step'], d['roofline']['frac'], {k:(v['launches'],v['ms']) for k,v in d['roofline']['breakdown'].items()})"
+  done;;
 bench2)
   MCVD_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 1 --warmup 1 --batch 8 --no-cpu-baseline > gpurun_out/bench_2proc.json 2> gpurun_out/bench_2proc.err
   echo "bench2 rc=$?" >> gpurun_out/bench_2proc.err; cat gpurun_out/bench_2proc.json | cut -c1-600; tail -3 gpurun_out/bench_2proc.err;;
