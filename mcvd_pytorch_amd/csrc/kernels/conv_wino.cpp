@@ -229,7 +229,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
 
     // diagnostics (mcvd_ctx_set_debug_buffer): shader-clock time the wave a.wdma spends per phase
     const bool rec = a.dbg != nullptr && wave == a.wdma;
-    unsigned long long tk0 = 0, tprev = 0, dt[2] = {0, 0};
+    unsigned long long tk0 = 0, tprev = 0, dt[2] = {0, 0}, pt[3] = {0, 0, 0};
     if (rec) tk0 = tprev = __builtin_amdgcn_s_memtime();
 #define WR_STAMP(i)                                                                                             \
     if (rec) {                                                                                                  \
@@ -262,17 +262,20 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
                 cfl = *reinterpret_cast<const f32x2*>(a.coef + ((long)(b + 1) * Cin + tid) * 2);
             if (PRO && tid < Cin) *reinterpret_cast<f32x2*>(sCo + (Cin + tid) * 2) = cfl;
         }
+        if (rec) pt[0] = __builtin_amdgcn_s_memtime() - tk0;           // index setup + load issue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ONE memory latency for everything above (the asm loads are
         WR_WAIT_A(0, A0)                                     // not tracked by the compiler: the waits are threaded through
         WR_WAIT_A(0, A1)                                     // the destination registers)
         WR_WAIT_P(0, q0)
         WR_WAIT_P(0, q1)
         WR_WAIT_P(0, pd)
+        if (rec) pt[1] = __builtin_amdgcn_s_memtime() - tk0;           // ... + memory latency
         if (PRO || G8) __syncthreads();    // coefficient table (and the zeroed halo) visible
         WR_WRITE_P(c_begin, q0)
         WR_WRITE_P(c_begin + 1, q1)
     }
     __syncthreads();                       // the first two patches visible
+    if (rec) pt[2] = __builtin_amdgcn_s_memtime() - tk0;               // ... + table barrier + two patch blocks + barrier
     WR_WRITE_V(c_begin)
     __syncthreads();                       // V of the first chunk visible
     WR_STAMP(0)
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
         const unsigned long long now = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
             unsigned long long* d = a.dbg + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
-            d[0] = dt[0]; d[1] = dt[1]; d[2] = 0; d[3] = 0; d[4] = 0;      // prologue, K loop
+            d[0] = dt[0]; d[1] = dt[1]; d[2] = pt[0]; d[3] = pt[1]; d[4] = pt[2];      // prologue, K loop, prologue sub-stamps
             d[5] = now - tprev;            // epilogue
             d[6] = (unsigned long long)(c_end - c_begin);
             d[7] = now - tk0;

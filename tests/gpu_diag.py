@@ -323,8 +323,8 @@ def wexp(f):
                 d = dbg.view(-1, 8).cpu().double()
                 d = d[d[:, 7] > 0]
                 m = d.mean(0)
-                per.append((m[0].item(), m[1].item() / max(m[6].item(), 1), m[5].item(), m[7].item()))
-            f.write(f"cin{cin} cout{cout} H{H} exp{e:4d} {lab:40s}: kernel {us:7.1f} us | wave0 pro {per[0][0]:6.0f} loop/chunk {per[0][1]:6.0f} epi {per[0][2]:6.0f} total {per[0][3]:7.0f}"
+                per.append((m[0].item(), m[1].item() / max(m[6].item(), 1), m[5].item(), m[7].item(), m[2].item(), m[3].item(), m[4].item()))
+            f.write(f"cin{cin} cout{cout} H{H} exp{e:4d} {lab:40s}: kernel {us:7.1f} us | wave0 pro {per[0][0]:6.0f} loop/chunk {per[0][1]:6.0f} epi {per[0][2]:6.0f} total {per[0][3]:7.0f} [pro: issue {per[0][4]:5.0f} +mem {per[0][5]:5.0f} +P {per[0][6]:5.0f}]"
                     f" | wave15 pro {per[1][0]:6.0f} loop/chunk {per[1][1]:6.0f} epi {per[1][2]:6.0f} total {per[1][3]:7.0f}\n")
             f.flush()
     os.environ["MCVD_WINO_EXP"] = "0"
