@@ -192,6 +192,9 @@ int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst_device
  * an injected `noise` then holds the RAW g (what Gamma(...).sample() returns in the reference). */
 int mcvd_sampler_run(mcvd_model* m, int kind, float* x_inout, const float* cond, const float* noise, uint64_t seed,
                      uint64_t sample_offset, int subsample_steps, int flags, float t_min, int B);
+/* The whole F-PNDM loop on the device (FPNDM_sampler, models/__init__.py:38-99 with models/pndm.py: Runge-Kutta for the first three
+ * steps, 4th-order Adams-Bashforth afterwards; deterministic).  flags: MCVD_FLAG_CLIP_BEFORE.  x_inout is overwritten with the last step. */
+int mcvd_fpndm_run(mcvd_model* m, float* x_inout, const float* cond, int subsample_steps, int flags, int B);
 /* One fused update (host-driven loops, final_only=False / verbose paths).  Coefficients are the fp32 scalars the
  * reference computes: x0 = c_x0a*(x - c_x0b*eps); clip; x = c_mean0*x0 + c_mean1*(ddpm: x | ddim: eps) + c_noise*z. */
 int mcvd_sampler_update(mcvd_ctx* ctx, int kind, float* x_inout, const float* eps, const float* noise, float c_x0a,

@@ -182,6 +182,8 @@ void mcvd_model_destroy(mcvd_model* m) {
     if (m->labels) (void)hipFree(m->labels);
     if (m->eps_buf) (void)hipFree(m->eps_buf);
     if (m->ksplit_buf) (void)hipFree(m->ksplit_buf);
+    if (m->labels_f) (void)hipFree(m->labels_f);
+    if (m->fp_buf) (void)hipFree(m->fp_buf);
     if (m->alphas_dev) (void)hipFree(m->alphas_dev);
     if (m->cond_z) (void)hipFree(m->cond_z);
     if (m->noise_buf) (void)hipFree(m->noise_buf);
@@ -595,6 +597,87 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
         set_cond_gamma(L - 1);
         if (int rc = m->forward(x, m->labels, cond, m->eps_buf, B)) return rc;
         if (int rc = launch_axpy_out(x, m->eps_buf, sqrtf(1.0f - al[L - 1]), n, s)) return rc;
+    }
+    return 0;
+    API_CATCH
+}
+
+// F-PNDM (FPNDM_sampler, models/__init__.py:38-99 + models/pndm.py): the whole loop on the device.  Steps run upwards 0, skip, ...,
+// t_next = the previous step (-1 first), alpha table = flipped alphas indexed by t + 1, network label = t, Runge-Kutta for the first
+// three steps (4 evaluations, midpoint label (t + t_next) / 2 as a float), 4th-order Adams-Bashforth afterwards.  The scalar
+// coefficients are evaluated in fp32, operation by operation, as torch evaluates the reference's 0-dim tensor expressions.
+int mcvd_fpndm_run(mcvd_model* m, float* x, const float* cond, int subsample_steps, int flags, int B) {
+    API_TRY
+    MCVD_REQUIRE(m && x && B > 0, "fpndm_run: bad arguments");
+    MCVD_REQUIRE(m->finalized, "fpndm_run before mcvd_model_finalize");
+    const int T = m->d.num_classes;
+    MCVD_REQUIRE(subsample_steps > 0 && subsample_steps <= T, "fpndm_run: subsample_steps=%d (the reference divides by it)", subsample_steps);
+    const int64_t per = (int64_t)m->d.channels * m->d.num_frames * m->d.image_size * m->d.image_size;
+    const int64_t n = per * B;
+    if (int rc = m->prepare_B(B)) return rc;
+    if (int rc = m->prepare_cond(cond, B)) return rc;
+    struct CacheGuard { mcvd_model* m; ~CacheGuard() { m->cond_cache_valid = false; } } guard{m};
+    hipStream_t s = m->ctx->stream;
+    if (m->fp_B < B) {
+        MCVD_HIP_CHECK(hipStreamSynchronize(s));
+        if (m->fp_buf) MCVD_HIP_CHECK(hipFree(m->fp_buf));
+        m->fp_buf = nullptr;
+        MCVD_HIP_CHECK(hipMalloc((void**)&m->fp_buf, (size_t)9 * n * sizeof(float)));
+        m->fp_B = B;
+    }
+    float* ring[4] = {m->fp_buf, m->fp_buf + n, m->fp_buf + 2 * n, m->fp_buf + 3 * n};      // eps history, oldest first after rotation
+    float* e2 = m->fp_buf + 4 * n; float* e3 = m->fp_buf + 5 * n; float* e4 = m->fp_buf + 6 * n;
+    float* xt = m->fp_buf + 7 * n; float* comb = m->fp_buf + 8 * n;
+    const int clip = (flags & MCVD_FLAG_CLIP_BEFORE) ? 1 : 0;
+    const int skip = T / subsample_steps;                                                 // :60
+    auto alpha_old = [&](int idx) { return m->alphas[T - 1 - idx]; };                     // alphas.flip(0)  :57
+    auto transfer = [&](float* out, const float* xx, float t_from, float t_to, const float* et) -> int {     // pndm.py:19-33
+        const float at = alpha_old((int)t_from + 1), an = alpha_old((int)t_to + 1);      // t.long() truncates toward zero
+        const float d = an - at;
+        const float sa = sqrtf(at);
+        const float c1 = 1.0f / (sa * (sa + sqrtf(an)));
+        const float c2 = 1.0f / (sa * (sqrtf((1.0f - an) * at) + sqrtf((1.0f - at) * an)));
+        return launch_pndm_transfer(out, xx, et, d, c1, c2, clip, n, s);
+    };
+    auto model_i = [&](const float* xx, int t, float* out) -> int {
+        if (int rc = launch_fill_labels(m->labels, t, B, s)) return rc;
+        return m->forward(xx, m->labels, cond, out, B);
+    };
+    auto model_f = [&](const float* xx, float t, float* out) -> int {
+        if (int rc = launch_fill_labels_f(m->labels_f, t, B, s)) return rc;
+        m->labels_f32 = 1;
+        const int rc = m->forward(xx, m->labels_f, cond, out, B);
+        m->labels_f32 = 0;
+        return rc;
+    };
+    int n_ets = 0;
+    int t_prev = -1;
+    for (int t = 0; t < T; t += skip) {
+        const int t_next = t_prev;                                                        // steps_next = [-1] + steps[:-1]  :62
+        const float t_mid = (float)(((double)t + (double)t_next) / 2.0);                  // pndm.py:42 (true division)
+        if (n_ets > 2) {                                                                  // gen_order_4, pndm.py:44-47
+            float* oldest = ring[0];                                                      // rotate: the oldest estimate is overwritten
+            ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3]; ring[3] = oldest;
+            if (int rc = model_i(x, t, ring[3])) return rc;
+            const float* in[4] = {ring[3], ring[2], ring[1], ring[0]};
+            const float w[4] = {55.0f, -59.0f, 37.0f, -9.0f};
+            if (int rc = launch_lincomb(comb, in, w, (float)(1.0 / 24.0), 4, n, s)) return rc;
+        } else {                                                                          // runge_kutta, pndm.py:3-17
+            float* e1 = ring[n_ets + 1 < 4 ? n_ets + 1 : 3];                              // slots 1,2,3 -> in age order once 3 are stored
+            if (int rc = model_i(x, t, e1)) return rc;
+            if (int rc = transfer(xt, x, (float)t, t_mid, e1)) return rc;
+            if (int rc = model_f(xt, t_mid, e2)) return rc;
+            if (int rc = transfer(xt, x, (float)t, t_mid, e2)) return rc;
+            if (int rc = model_f(xt, t_mid, e3)) return rc;
+            if (int rc = transfer(xt, x, (float)t, (float)t_next, e3)) return rc;
+            if (int rc = model_i(xt, t_next, e4)) return rc;
+            const float* in[4] = {e1, e2, e3, e4};
+            const float w[4] = {1.0f, 2.0f, 2.0f, 1.0f};
+            if (int rc = launch_lincomb(comb, in, w, (float)(1.0 / 6.0), 4, n, s)) return rc;
+            ++n_ets;
+        }
+        if (int rc = transfer(x, x, (float)t, (float)t_next, comb)) return rc;            // pndm.py:51 (in place: elementwise)
+        t_prev = t;
     }
     return 0;
     API_CATCH

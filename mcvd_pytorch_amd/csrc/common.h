@@ -150,6 +150,7 @@ int launch_transpose_into(const float* w, float* wt, int rows, int cols, int ld_
 
 // ------------------------------------------------------------------ sampler elementwise
 int launch_fill_labels(int64_t* labels, int64_t value, int B, hipStream_t s);
+int launch_fill_labels_f(float* labels, float value, int B, hipStream_t s);
 // kind 0 ddpm / 1 ddim.  noise may be null (then c_noise must be 0 or use_philox != 0).
 int launch_sampler_update(int kind, float* x, const float* eps, const float* noise, float c_x0a, float c_x0b,
                           float c_mean0, float c_mean1, float c_noise, int clip, int64_t n, int use_philox,

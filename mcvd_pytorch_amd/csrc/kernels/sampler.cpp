@@ -138,6 +138,16 @@ int launch_fill_labels(int64_t* labels, int64_t value, int B, hipStream_t s) {
     return 0;
 }
 
+__global__ void fill_labels_f_kernel(float* labels, float v, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) labels[i] = v;
+}
+int launch_fill_labels_f(float* labels, float value, int B, hipStream_t s) {
+    hipLaunchKernelGGL(fill_labels_f_kernel, dim3((B + 255) / 256), dim3(256), 0, s, labels, value, B);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 struct UpdArgs {
     int kind; float* x; const float* eps; const float* noise; float c_x0a, c_x0b, c_mean0, c_mean1, c_noise; int clip;
     int64_t n; int use_philox; uint64_t seed, sample_offset, draw; int64_t per_sample;

@@ -539,6 +539,8 @@ int mcvd_model::ensure_workspace(int B) {
     MCVD_HIP_CHECK(hipStreamSynchronize(s));
     if (arena) MCVD_HIP_CHECK(hipFree(arena));
     if (labels) MCVD_HIP_CHECK(hipFree(labels));
+    if (labels_f) MCVD_HIP_CHECK(hipFree(labels_f));
+    labels_f = nullptr;
     if (eps_buf) MCVD_HIP_CHECK(hipFree(eps_buf));
     if (ksplit_buf) MCVD_HIP_CHECK(hipFree(ksplit_buf));
     if (cond_z) MCVD_HIP_CHECK(hipFree(cond_z));
@@ -547,6 +549,7 @@ int mcvd_model::ensure_workspace(int B) {
     const size_t per = (size_t)d.channels * d.num_frames * d.image_size * d.image_size;
     MCVD_HIP_CHECK(hipMalloc((void**)&arena, (size_t)arena_per_sample * B * sizeof(float)));
     MCVD_HIP_CHECK(hipMalloc((void**)&labels, (size_t)B * sizeof(int64_t)));
+    MCVD_HIP_CHECK(hipMalloc((void**)&labels_f, (size_t)B * sizeof(float)));
     MCVD_HIP_CHECK(hipMalloc((void**)&eps_buf, per * B * sizeof(float)));
     size_t kfl = 0;                               // K-split Winograd candidates: 3x3 layers at 8x8 / 16x16
     for (const Op& op : ops)

@@ -144,6 +144,9 @@ struct mcvd_model {
     int arena_B = 0;
     int64_t* labels = nullptr;        // [arena_B] (sampler-owned labels)
     float* eps_buf = nullptr;         // [arena_B * C*nf*S*S] (sampler-owned eps)
+    float* labels_f = nullptr;        // [arena_B] float labels (F-PNDM midpoints)
+    float* fp_buf = nullptr;          // F-PNDM device loop: 9 state-sized buffers (4 eps history, 3 Runge-Kutta eps, x temp, combination)
+    int fp_B = 0;
     float* ksplit_buf = nullptr;      // two partial outputs of the K-split Winograd layers (H*W <= 256), sized for arena_B
 
     std::vector<float> betas, alphas, alphas_prev, freqs;

@@ -287,6 +287,20 @@ def fpndm_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, su
     if cond is not None:
         cond = cond.to(device=dev, dtype=torch.float32).contiguous()
     B, n = x.shape[0], x.numel()
+    d = net._desc
+    if x.dim() != 4 or tuple(x.shape[1:]) != (d.channels * d.num_frames, d.image_size, d.image_size):
+        raise RuntimeError(f"x_mod has shape {tuple(x.shape)}")
+    if (d.num_frames_cond > 0) != (cond is not None) or (cond is not None and tuple(cond.shape) !=
+                                                         (B, d.channels * d.num_frames_cond, d.image_size, d.image_size)):
+        raise RuntimeError("cond missing or mis-shaped")
+    if final_only and not getattr(net, "noise_in_cond", False):
+        # the whole loop inside the library (the reference never logs in this sampler, so verbose / log change nothing)
+        with torch.cuda.device(dev):
+            net._bind_stream()
+            _lib.check(_lib.lib.mcvd_fpndm_run(net._model, C.c_void_p(x.data_ptr()), C.c_void_p(cond.data_ptr()) if cond is not None else None,
+                                               int(subsample_steps), _lib.FLAG_CLIP_BEFORE if clip_before else 0, B), "fpndm_run")
+        net._cond_key = None
+        return x.unsqueeze(0)
     alphas_old = net.alphas.cpu().flip(0)                                           # :57
     T = len(alphas_old)
     skip = T // subsample_steps                                                     # :60

@@ -400,6 +400,11 @@ def test_fpndm_vs_reference_golden(golden_dir, ctx):
     assert out.device.type == "cpu" and out.shape == ref.shape
     err = (out - ref).abs().max().item()
     assert err <= 2e-4, f"max-abs err over all steps {err:.3e}"          # deterministic multistep: no noise damps rounding (cf. DDIM)
+    # final_only=True runs the whole loop inside the library (mcvd_fpndm_run): same kernels, same scalar arithmetic as the host loop
+    dev_loop = fpndm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=g["subsample"], clip_before=True)
+    assert dev_loop.is_cuda and dev_loop.shape[0] == 1
+    assert torch.equal(dev_loop[0].cpu(), out[-1]), (dev_loop[0].cpu() - out[-1]).abs().max().item()
+    assert (dev_loop[0].cpu() - ref[-1]).abs().max().item() <= 2e-4
     fin = fpndm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=g["subsample"], clip_before=False)
     assert fin.is_cuda and fin.shape == g["final_noclip"].shape
     torch.testing.assert_close(fin.cpu(), g["final_noclip"], rtol=5e-3, atol=5e-3)

@@ -106,7 +106,7 @@ def traffic(out_json):
     kernel table from the tune cache).  Forwards are counted by temb_mlp_kernel dispatches.  Also a per-instantiation table."""
     import json
     res = {"kernel_family": "conv_wino_kernel<*> + wino_ksplit_reduce_kernel", "per_instantiation": {}}
-    fam = lambda k: k.startswith("conv_wino_kernel") or k.startswith("wino_ksplit_reduce_kernel")
+    fam = lambda k: k.startswith("conv_wino_kernel") or k.startswith("wino_ksplit_reduce")
     tot = {}
     for key, dirname, counter in (("fetch", "pmc_fetch", "FETCH_SIZE"), ("write", "pmc_write", "WRITE_SIZE")):
         per = defaultdict(lambda: [0, 0.0])
