@@ -1,5 +1,6 @@
 // extern "C" surface of libmcvd_hip.so (see include/mcvd_hip.h).  Nothing here throws.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -652,7 +653,11 @@ int mcvd_fpndm_run(mcvd_model* m, float* x, const float* cond, int subsample_ste
     };
     int n_ets = 0;
     int t_prev = -1;
-    for (int t = 0; t < T; t += skip) {
+    const char* ms_env = getenv("MCVD_FPNDM_MAXSTEPS");          // diagnostics: stop after this many steps
+    int steps_left = ms_env ? atoi(ms_env) : (1 << 30);
+    for (int t = 0; t < T && steps_left > 0; t += skip, --steps_left) {
+        MCVD_REQUIRE(t + 1 < T, "fpndm_run: index %d is out of bounds for the alpha table of size %d (the reference fails the same way "
+                     "when num_classes is not a multiple of subsample_steps)", t + 1, T);
         const int t_next = t_prev;                                                        // steps_next = [-1] + steps[:-1]  :62
         const float t_mid = (float)(((double)t + (double)t_next) / 2.0);                  // pndm.py:42 (true division)
         if (n_ets > 2) {                                                                  // gen_order_4, pndm.py:44-47

@@ -62,6 +62,10 @@ def make_config(name):
         data.update(image_size=32, num_frames=2, num_frames_cond=2)
         model.update(ngf=32, n_head_channels=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8, 16])
         sampling.update(subsample=10)
+    elif name == "tiny_uncond":              # no conditioning frames at all (conditioning_fn(..., conditional=False), ncsn_runner.py:109-110)
+        data.update(image_size=32, num_frames=2, num_frames_cond=0)
+        model.update(ngf=32, n_head_channels=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8, 16])
+        sampling.update(subsample=10)
     elif name == "tiny_cosine":              # `tiny` with the cosine alpha-bar schedule (models/__init__.py:28-32)
         data.update(image_size=32, num_frames=2, num_frames_cond=2)
         model.update(ngf=32, n_head_channels=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8, 16],
