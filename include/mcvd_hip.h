@@ -202,6 +202,9 @@ int mcvd_sampler_update(mcvd_ctx* ctx, int kind, float* x_inout, const float* ep
 /* z ~ N(0,1) from the same Philox stream mcvd_sampler_run uses: out:[B, per_sample]. */
 int mcvd_randn(mcvd_ctx* ctx, float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B,
                int64_t per_sample);
+/* uint8 frame packing of the result side (runners/ncsn_runner.py:2019-2062: each frame BCHW -> HWC, `(frame * 255).astype('uint8')`):
+ * frames01:[B, T*C, H, W] fp32 in [0, 1] (inverse_data_transform's output, frame-major channels) -> out:[B, T, H, W, C] uint8. */
+int mcvd_pack_frames_u8(mcvd_ctx* ctx, const float* frames01, uint8_t* out, int B, int T, int C, int H, int W);
 /* Standardised gamma noise of the `gamma=True` samplers (models/__init__.py:273-276, :319-322): out = (g - kt) / sd, g = raw[i]
  * when raw != NULL (a Gamma(k, rate 1/theta).sample() drawn elsewhere) else theta * Gamma(k) from the library's Philox stream;
  * kt = k * theta and sd = sqrt(1 - alpha_i) are passed as the fp32 scalars the reference computes.  out:[B, per_sample]. */

@@ -9,8 +9,8 @@ from .config import desc_from_config, dict2namespace, load_config  # noqa: F401
 from .samplers import ddim_sampler, ddpm_sampler, fpndm_sampler, get_sampler  # noqa: F401
 from .scorenet import HipScoreNet, get_model  # noqa: F401
 from .checkpoint import load_model, load_states_into  # noqa: F401
-from .runner import conditioning_fn, data_transform, inverse_data_transform, save_video_pred, video_gen  # noqa: F401
+from .runner import conditioning_fn, data_transform, frames_to_uint8, inverse_data_transform, save_video_pred, video_gen  # noqa: F401
 
 __all__ = ["HipScoreNet", "get_model", "ddpm_sampler", "ddim_sampler", "fpndm_sampler", "get_sampler", "dict2namespace", "load_config",
            "desc_from_config", "load_model", "load_states_into", "conditioning_fn", "data_transform",
-           "inverse_data_transform", "video_gen", "save_video_pred"]
+           "inverse_data_transform", "video_gen", "save_video_pred", "frames_to_uint8"]

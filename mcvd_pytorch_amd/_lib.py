@@ -71,6 +71,7 @@ _PROTOS = {
     "mcvd_fpndm_run": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "mcvd_sampler_update": (_i, [_vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _i64]),
     "mcvd_randn": (_i, [_vp, _vp, _u64, _u64, _u64, _i, _i64]),
+    "mcvd_pack_frames_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "mcvd_gamma_noise": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _u64, _u64, _u64, _i, _i64]),
     "mcvd_lincomb": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _i64]),
     "mcvd_pndm_transfer": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _i64]),

@@ -695,6 +695,11 @@ int mcvd_sampler_update(mcvd_ctx* ctx, int kind, float* x, const float* eps, con
                                  ctx->stream);
 }
 
+int mcvd_pack_frames_u8(mcvd_ctx* ctx, const float* frames01, uint8_t* out, int B, int T, int C, int H, int W) {
+    MCVD_REQUIRE(ctx, "pack_frames_u8: NULL ctx");
+    return launch_pack_frames_u8(frames01, out, B, T, C, H * W, ctx->stream);
+}
+
 int mcvd_gamma_noise(mcvd_ctx* ctx, float* out, const float* raw, float k, float theta, float kt, float sd, uint64_t seed,
                      uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample) {
     MCVD_REQUIRE(ctx && out, "gamma_noise: NULL argument");

@@ -128,6 +128,27 @@ int launch_cond_noise(const float* cond, const float* z, const float* alphas_dev
     return 0;
 }
 
+// [B, T*C, H, W] float in [0, 1] (after inverse_data_transform) -> [B, T, H, W, C] uint8, `(frame * 255).astype('uint8')`
+// (runners/ncsn_runner.py:2019-2062: BCHW -> permute(0, 2, 3, 1) -> * 255 -> astype uint8, truncation toward zero)
+__global__ __launch_bounds__(256) void pack_frames_u8_kernel(const float* in, uint8_t* out, int T, int C, int HW, int64_t n) {
+    for (int64_t i = blockIdx.x * 256L + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t r = i / C;
+        const int p = (int)(r % HW);
+        const int64_t bt = r / HW;                        // b * T + t
+        const float v = in[(bt * C + c) * HW + p] * 255.0f;
+        out[i] = (uint8_t)(int)fminf(fmaxf(v, 0.0f), 255.0f);
+    }
+}
+int launch_pack_frames_u8(const float* in, uint8_t* out, int B, int T, int C, int HW, hipStream_t s) {
+    MCVD_REQUIRE(in && out && B > 0 && T > 0 && C > 0 && HW > 0, "pack_frames_u8: bad arguments");
+    const int64_t n = (int64_t)B * T * C * HW;
+    const int grid = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_frames_u8_kernel, dim3(grid), dim3(256), 0, s, in, out, T, C, HW, n);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 __global__ void fill_labels_kernel(int64_t* labels, int64_t v, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) labels[i] = v;

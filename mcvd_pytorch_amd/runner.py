@@ -147,6 +147,25 @@ def video_gen(config, scorenet, cond, num_frames_pred=None, init_noise_fn=None, 
     return torch.cat(preds, dim=1)[:, :C * nfp]                                         # :1569
 
 
+def frames_to_uint8(scorenet, frames01, channels):
+    """[B, T*C, H, W] frames in [0, 1] (after `inverse_data_transform`) -> uint8 [B, T, H, W, C] on the device: the packing the
+    reference applies to every frame before it writes GIFs / PNGs (`(frame * 255).astype('uint8')` on the HWC view,
+    runners/ncsn_runner.py:2019-2062).  The grid / caption drawing around it (torchvision make_grid, cv2.putText) is host-side
+    presentation and stays with the caller."""
+    import ctypes as C
+    from . import _lib
+    f = frames01.to(device=scorenet.device, dtype=torch.float32).contiguous()
+    B, TC, H, W = f.shape
+    if TC % channels:
+        raise ValueError(f"{TC} channels is not a multiple of {channels}")
+    out = torch.empty((B, TC // channels, H, W, channels), dtype=torch.uint8, device=f.device)
+    with torch.cuda.device(f.device):
+        scorenet._bind_stream()
+        _lib.check(_lib.lib.mcvd_pack_frames_u8(scorenet._ctx, C.c_void_p(f.data_ptr()), C.c_void_p(out.data_ptr()), B, TC // channels,
+                                                channels, H, W), "pack_frames_u8")
+    return out
+
+
 def save_video_pred(path, cond, pred, real):
     """The on-disk result of NCSNRunner.video_gen: torch.save({"cond", "pred", "real"}) of the [0,1]-range CPU tensors
     (runners/ncsn_runner.py:2106-2112, `videos_pred_<ckpt>.pt`), so downstream metric scripts read our output unchanged."""

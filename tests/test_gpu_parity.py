@@ -966,3 +966,19 @@ def test_video_gen_unconditional_bootstrap_and_data_init():
     sampler, blk = _vg_sampler(noises)
     with pytest.raises(RuntimeError):
         video_gen(config, net, None, num_frames_pred=4, sampler=sampler, batch_size=B, init_noise_fn=lambda i, shp, dev: inits[i].to(dev))
+
+
+def test_uint8_frame_packing():
+    """frames_to_uint8 == the reference's per-frame `(frame.permute(0, 2, 3, 1).numpy() * 255).astype('uint8')`
+    (runners/ncsn_runner.py:2019-2062) on inverse_data_transform's output."""
+    from mcvd_pytorch_amd import frames_to_uint8, inverse_data_transform
+    config, sd, net = _net("tiny_spade")                  # channels = 3
+    C = config.data.channels
+    x = torch.randn(3, 4 * C, 32, 32, generator=_g(8)) * 0.8
+    x[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, 0.999999, 1.0 - 2.0 / 255])      # clamp edges, 255 and a value just below a step
+    f01 = inverse_data_transform(config, x)
+    got = frames_to_uint8(net, f01.cuda(), C).cpu()
+    want = torch.stack([torch.from_numpy((f01[:, t * C:(t + 1) * C].permute(0, 2, 3, 1).numpy() * 255).astype("uint8"))
+                        for t in range(4)], dim=1)
+    assert got.shape == want.shape == (3, 4, 32, 32, C) and got.dtype == torch.uint8
+    assert torch.equal(got, want)
