@@ -397,7 +397,7 @@ int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* co
     MCVD_REQUIRE(n == (int)m->ops.size(), "set_tuning: %d entries for a plan of %d ops (tuning of another model?)", n, (int)m->ops.size());
     for (int i = 0; i < n; ++i) {
         const bool conv = m->ops[i].kind == OP_CONV;
-        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 8 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
+        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 9 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
                      "set_tuning: entry %d (shape %d, cout tile %d) does not fit op kind %d", i, shapes[i], cots[i], (int)m->ops[i].kind);
     }
     m->tuned_cache[B] = {std::vector<int>(shapes, shapes + n), std::vector<int>(cots, cots + n)};
@@ -755,7 +755,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.wp = ctx->scratch;
     a.bias = ctx->scratch + wfloats;
     a.shape_hint = ctx->conv_shape;
-    if ((ctx->conv_shape == 5 || ctx->conv_shape == 6) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
+    if ((ctx->conv_shape == 5 || ctx->conv_shape == 6 || ctx->conv_shape == 9) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
     a.wdma = ctx->conv_wdma;
     a.dbg = ctx->dbg;
     a.stats = ctx->naive_conv ? nullptr : ctx->stats_buf;

@@ -92,9 +92,9 @@ int conv_wino_cout_tile(int Cout);
 bool conv_wino_usable(const ConvArgs& a);            // shape id 4 applies to this launch
 int launch_conv_wino(const ConvArgs& a, hipStream_t s);
 // all-DMA 1x1 GEMM (conv1x1_dma.cpp): tile shape ids 5 / 6; cot_req <= 0 picks the default cout tile
-bool conv1x1_dma_supported(const ConvArgs& a, int ck);     // ck: channels per chunk, 16 (shape id 5) or 32 (shape id 6)
+bool conv1x1_dma_supported(const ConvArgs& a, int ck, int pxw = 1);     // ck: channels per chunk, 16 (shape id 5) or 32 (shape id 6); pxw = 2: 256-pixel tiles (shape id 9, ck 16)
 int conv1x1_dma_cout_tile(int CoutP);
-int launch_conv1x1_dma(const ConvArgs& a, int cot_req, int ck, hipStream_t s);
+int launch_conv1x1_dma(const ConvArgs& a, int cot_req, int ck, hipStream_t s, int pxw = 1);
 // [Cout][Cin][3][3] -> operand-major transformed weights (zero-filled destination of CinP*16*CoutP floats)
 int launch_pack_wino_weight(const float* w, float* up, int Cout, int Cin, int CinP, int CoutP, hipStream_t s);
 // repack reference-layout weights [Cout][Cin][ks][ks] (or NIN [Cin][Cout] when nin=1) -> packed layout above

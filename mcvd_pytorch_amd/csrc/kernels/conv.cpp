@@ -50,6 +50,7 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if ((a.shape_hint == 4 || a.shape_hint == 8) && conv_wino_usable(a)) { g_last_conv_kernel = 4; return launch_conv_wino(a, s); }   // Winograd F(2x2,3x3)
     if (a.shape_hint == 5 && conv1x1_dma_supported(a, 16)) { g_last_conv_kernel = 5; return launch_conv1x1_dma(a, a.cot, 16, s); }   // all-DMA 1x1 GEMM
     if (a.shape_hint == 6 && conv1x1_dma_supported(a, 32) && a.cot != 9) { g_last_conv_kernel = 6; return launch_conv1x1_dma(a, a.cot, 32, s); }
+    if (a.shape_hint == 9 && conv1x1_dma_supported(a, 16, 2)) { g_last_conv_kernel = 9; return launch_conv1x1_dma(a, a.cot, 16, s, 2); }   // 64 pixels per wave
     if (a.cot < 1 || a.cot > 4 || a.CoutP % (32 * a.cot) != 0) {   // a cout tile meant for another kernel: use this one's
         ConvArgs b = a;
         b.cot = conv_cout_tile(a.Cout);

@@ -23,10 +23,14 @@ constexpr int G1_PT = 128;       // pixels per workgroup
 constexpr int G1_MAXIMG = 4;     // images a pixel tile may span (HW >= 32)
 
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU;  CK: input channels per chunk (16 or 32)
-template <int COT, int PRO, int CK>
+// PXW: 32-pixel blocks per wave (1 or 2).  PXW = 2: a workgroup covers 256 pixels, every weight operand read from the LDS feeds
+// two MFMAs and a chunk holds 2*8*COT MFMAs per wave between barriers instead of 8*COT (tile shape id 9).
+template <int COT, int PRO, int CK, int PXW = 1>
 // second launch bound: 4 waves/SIMD (128 registers) up to cout tile 3, where accumulators + staging fit without spills
-__global__ __launch_bounds__(256, COT <= 3 ? 4 : 1) void conv1x1_dma_kernel(ConvArgs a, int ptiles, int nct) {
-    constexpr int PT = G1_PT, BCO = 32 * COT;
+__global__ __launch_bounds__(256, COT * PXW <= 3 ? 4 : (COT * PXW <= 4 ? 3 : 1)) void conv1x1_dma_kernel(ConvArgs a, int ptiles, int nct) {
+    constexpr int PT = G1_PT * PXW, BCO = 32 * COT;
+    constexpr int PPR = PT / 4;               // 16-byte pieces per channel row of the pixel tile
+    constexpr int RPS = 256 / PPR;            // channel rows one 256-thread DMA step covers (8 at 128 pixels, 4 at 256)
     constexpr int WSZ = CK * BCO, XSZ = CK * PT;
     constexpr int WPIECES = WSZ / 4, XPIECES = XSZ / 4;          // 16-byte pieces per chunk
     constexpr int MAXW = (WPIECES + 255) / 256, MAXX = XPIECES / 256;
@@ -45,11 +49,11 @@ __global__ __launch_bounds__(256, COT <= 3 ? 4 : 1) void conv1x1_dma_kernel(Conv
     const long NPX = (long)a.B * HW;
     const long gp0 = (long)ptile * PT;
 
-    // ---- x DMA role: piece e = s*256 + tid -> (channel-in-chunk e>>5, 4 pixels (e&31)*4); pixel part is slot invariant
-    long xg = gp0 + (tid & 31) * 4;
+    // ---- x DMA role: piece e = s*256 + tid -> (channel-in-chunk e / PPR, 4 pixels (e % PPR)*4); pixel part is slot invariant
+    long xg = gp0 + (tid % PPR) * 4;
     if (xg > NPX - 4) xg = NPX - 4;           // ragged last tile: fetch valid data, the stores are predicated
     const int xb = (int)(xg / HW), xp = (int)(xg - (long)xb * HW);
-    const int x_ci = tid >> 5;                // + 8*s
+    const int x_ci = tid / PPR;               // + RPS*s
     const int voff0 = (xb * a.C0 + x_ci) * HW + xp;               // offset inside x0 (without the chunk base)
     const int voff1 = (xb * a.C1 + x_ci) * HW + xp;               // offset inside x1
 
@@ -67,7 +71,10 @@ __global__ __launch_bounds__(256, COT <= 3 ? 4 : 1) void conv1x1_dma_kernel(Conv
     const int nimg = HW >= PT ? 1 : PT / HW;
     const int c_img = min(b_first + tid / CK, a.B - 1), c_ci = tid % CK;
     const bool c_role = PRO != 0 && tid < nimg * CK;
-    const int my_img = HW >= PT ? 0 : (wave * 32) / HW;            // image (within the tile) of this wave's pixels
+    // image (within the tile) of this wave's pixel block j: pixels wave*32*PXW + 32*j .. +31
+    int my_img[PXW];
+#pragma unroll
+    for (int j = 0; j < PXW; ++j) my_img[j] = HW >= PT ? 0 : (wave * 32 * PXW + 32 * j) / HW;
     f32x2 cf_next = {1.0f, 0.0f};
 
 #define G1_DMA(ch)                                                                                              \
@@ -86,18 +93,20 @@ __global__ __launch_bounds__(256, COT <= 3 ? 4 : 1) void conv1x1_dma_kernel(Conv
         float* xdst = sX + (((ch) & 1) ? XSZ : 0);                                                              \
         _Pragma("unroll") for (int s = 0; s < MAXX; ++s)                                                        \
             __builtin_amdgcn_global_load_lds(                                                                   \
-                (const __attribute__((address_space(1))) void*)(xsrc + (long)s * 8 * HW + voff),                \
+                (const __attribute__((address_space(1))) void*)(xsrc + (long)s * RPS * HW + voff),              \
                 (__attribute__((address_space(3))) void*)(xdst + (s * 256 + wave * 64) * 4), 16, 0, 0);         \
         if (c_role) cf_next = *reinterpret_cast<const f32x2*>(a.coef + ((long)c_img * Cin + cb + c_ci) * 2);    \
     }
 #define G1_WRITE_C(ch)                                                                                          \
     if (c_role) *reinterpret_cast<f32x2*>(sC + (((ch) & 1) ? G1_MAXIMG * CK * 2 : 0) + tid * 2) = cf_next;
 
-    f32x16 acc[COT];
+    f32x16 acc[PXW][COT];
 #pragma unroll
-    for (int ct = 0; ct < COT; ++ct)
+    for (int j = 0; j < PXW; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+        for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][ct][r] = 0.0f;
 
     const int nchunks = Cin / CK;          // Cin % CK == 0 (launch check): the zero rows that pad wp to CinP are never staged
     G1_DMA(0);
@@ -108,20 +117,27 @@ __global__ __launch_bounds__(256, COT <= 3 ? 4 : 1) void conv1x1_dma_kernel(Conv
         const bool more = ch + 1 < nchunks;
         if (more) G1_DMA(ch + 1);
         const float* sWc = sW + ((ch & 1) ? WSZ : 0);
-        const float* sXc = sX + ((ch & 1) ? XSZ : 0) + wave * 32 + l31;
-        const float* sCc = sC + ((ch & 1) ? G1_MAXIMG * CK * 2 : 0) + my_img * CK * 2;
+        const float* sXc = sX + ((ch & 1) ? XSZ : 0) + wave * 32 * PXW + l31;
+        const float* sCb = sC + ((ch & 1) ? G1_MAXIMG * CK * 2 : 0);
 #pragma unroll
         for (int kp = 0; kp < CK / 2; ++kp) {
             const int row = 2 * kp + half;
-            float bv = sXc[row * PT];
-            if (PRO != 0) {
-                const f32x2 cf = *reinterpret_cast<const f32x2*>(sCc + row * 2);
-                bv = bv * cf.x + cf.y;
-                if (PRO == 2) bv = silu_g(bv);
+            float bv[PXW];
+#pragma unroll
+            for (int j = 0; j < PXW; ++j) {
+                bv[j] = sXc[row * PT + 32 * j];
+                if (PRO != 0) {
+                    const f32x2 cf = *reinterpret_cast<const f32x2*>(sCb + my_img[j] * CK * 2 + row * 2);
+                    bv[j] = bv[j] * cf.x + cf.y;
+                    if (PRO == 2) bv[j] = silu_g(bv[j]);
+                }
             }
 #pragma unroll
-            for (int ct = 0; ct < COT; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(sWc[row * BCO + ct * 32 + l31], bv, acc[ct], 0, 0, 0);
+            for (int ct = 0; ct < COT; ++ct) {
+                const float av = sWc[row * BCO + ct * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j][ct], 0, 0, 0);
+            }
         }
         if (more) G1_WRITE_C(ch + 1);
         __syncthreads();                       // chunk ch consumed by every wave; the DMA of chunk ch+1 has landed
@@ -129,40 +145,43 @@ __global__ __launch_bounds__(256, COT <= 3 ? 4 : 1) void conv1x1_dma_kernel(Conv
 #undef G1_DMA
 #undef G1_WRITE_C
 
-    // ---- epilogue: lane (l31, half) holds pixel gp0 + 32*wave + l31, couts ct*32 + (r&3) + 8*(r>>2) + 4*half
-    const long gp = gp0 + wave * 32 + l31;
-    if (gp >= NPX) return;
-    const int ob = (int)(gp / HW), op = (int)(gp - (long)ob * HW);
-    const long obase = (long)ob * a.Cout * HW + op;
+    // ---- epilogue: lane (l31, half) holds pixels gp0 + 32*PXW*wave + 32*j + l31, couts ct*32 + (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
-    for (int ct = 0; ct < COT; ++ct) {
-        float rv[16];
+    for (int j = 0; j < PXW; ++j) {
+        const long gp = gp0 + wave * 32 * PXW + 32 * j + l31;
+        if (gp >= NPX) continue;                  // NPX % 32 == 0: a 32-pixel block is valid or invalid as a whole
+        const int ob = (int)(gp / HW), op = (int)(gp - (long)ob * HW);
+        const long obase = (long)ob * a.Cout * HW + op;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int coc = min(co, a.Cout - 1);
-            rv[r] = a.res ? a.res[obase + (long)coc * HW] : 0.0f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int ct = 0; ct < COT; ++ct) {
+            float rv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float v = (acc[ct][r] + a.bias[co] + rv[r]) * a.out_scale;     // bias is zero-padded to CoutP
-            if (co < a.Cout) a.y[obase + (long)co * HW] = v;
-            if (a.stats) {
-                // GroupNorm partials for the next norm (ConvArgs::stats): the 32 lanes of a half-wave hold 32 consecutive pixels
-                // of ONE image (HW % 32 == 0) for this cout -> (sum, M2 about their mean), partial index = pixel block op / 32
-                float sm = v;
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int coc = min(co, a.Cout - 1);
+                rv[r] = a.res ? a.res[obase + (long)coc * HW] : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int o2 = 16; o2 > 0; o2 >>= 1) sm += __shfl_xor(sm, o2);
-                const float d = v - sm * (1.0f / 32.0f);
-                float m2 = d * d;
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v = (acc[j][ct][r] + a.bias[co] + rv[r]) * a.out_scale;     // bias is zero-padded to CoutP
+                if (co < a.Cout) a.y[obase + (long)co * HW] = v;
+                if (a.stats) {
+                    // GroupNorm partials for the next norm (ConvArgs::stats): the 32 lanes of a half-wave hold 32 consecutive pixels
+                    // of ONE image (HW % 32 == 0) for this cout -> (sum, M2 about their mean), partial index = pixel block op / 32
+                    float sm = v;
 #pragma unroll
-                for (int o2 = 16; o2 > 0; o2 >>= 1) m2 += __shfl_xor(m2, o2);
-                if (l31 == 0 && co < a.Cout) {
-                    float* q = a.stats + (((long)ob * a.Cout + co) * (HW >> 5) + (op >> 5)) * 2;
-                    q[0] = sm;
-                    q[1] = m2;
+                    for (int o2 = 16; o2 > 0; o2 >>= 1) sm += __shfl_xor(sm, o2);
+                    const float d = v - sm * (1.0f / 32.0f);
+                    float m2 = d * d;
+#pragma unroll
+                    for (int o2 = 16; o2 > 0; o2 >>= 1) m2 += __shfl_xor(m2, o2);
+                    if (l31 == 0 && co < a.Cout) {
+                        float* q = a.stats + (((long)ob * a.Cout + co) * (HW >> 5) + (op >> 5)) * 2;
+                        q[0] = sm;
+                        q[1] = m2;
+                    }
                 }
             }
         }
@@ -180,11 +199,11 @@ int conv1x1_dma_cout_tile(int CoutP) {
     return 1;
 }
 
-bool conv1x1_dma_supported(const ConvArgs& a, int ck) {
+bool conv1x1_dma_supported(const ConvArgs& a, int ck, int pxw) {
     const int HW = a.H * a.W;
-    const int G1_CK = ck;
-    if (a.ks != 1 || HW % 32 != 0) return false;
-    if (!(HW % G1_PT == 0 || (HW < G1_PT && G1_PT % HW == 0 && G1_PT / HW <= G1_MAXIMG))) return false;
+    const int G1_CK = ck, PT = G1_PT * pxw;
+    if (a.ks != 1 || HW % 32 != 0 || (pxw != 1 && pxw != 2) || (pxw == 2 && ck != 16)) return false;
+    if (!(HW % PT == 0 || (HW < PT && PT % HW == 0 && PT / HW <= G1_MAXIMG))) return false;
     if (a.Cin % G1_CK != 0 || a.CinP % G1_CK != 0) return false;            // no partial chunk: every staged row is real data
     if (a.C1 > 0 && a.C0 % G1_CK != 0) return false;                        // a chunk never straddles the concat seam
     if ((long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * HW >= (1L << 31)) return false;   // 32-bit lane offsets
@@ -192,30 +211,30 @@ bool conv1x1_dma_supported(const ConvArgs& a, int ck) {
     return true;
 }
 
-template <int COT, int G1_CK>
+template <int COT, int G1_CK, int PXW = 1>
 static int g1_launch(const ConvArgs& a, hipStream_t s) {
     const int HW = a.H * a.W;
     const long NPX = (long)a.B * HW;
-    const int ptiles = (int)((NPX + G1_PT - 1) / G1_PT);
+    const int ptiles = (int)((NPX + G1_PT * PXW - 1) / (G1_PT * PXW));
     const int nct = a.CoutP / (32 * COT);
-    const size_t lds = (size_t)(2 * G1_CK * 32 * COT + 2 * G1_CK * G1_PT + 2 * G1_MAXIMG * G1_CK * 2) * sizeof(float);
+    const size_t lds = (size_t)(2 * G1_CK * 32 * COT + 2 * G1_CK * G1_PT * PXW + 2 * G1_MAXIMG * G1_CK * 2) * sizeof(float);
     const dim3 grid(((ptiles + 7) / 8) * 8 * nct);
     static PerDeviceOnce raised;
     if (lds > 48 * 1024 && raised.first_use()) {
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 0, G1_CK>),
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 0, G1_CK, PXW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 1, G1_CK>),
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 1, G1_CK, PXW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 2, G1_CK>),
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_dma_kernel<COT, 2, G1_CK, PXW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised.done();
     }
     if (!a.coef)
-        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 0, G1_CK>), grid, dim3(256), lds, s, a, ptiles, nct);
+        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 0, G1_CK, PXW>), grid, dim3(256), lds, s, a, ptiles, nct);
     else if (!a.act)
-        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 1, G1_CK>), grid, dim3(256), lds, s, a, ptiles, nct);
+        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 1, G1_CK, PXW>), grid, dim3(256), lds, s, a, ptiles, nct);
     else
-        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 2, G1_CK>), grid, dim3(256), lds, s, a, ptiles, nct);
+        hipLaunchKernelGGL((conv1x1_dma_kernel<COT, 2, G1_CK, PXW>), grid, dim3(256), lds, s, a, ptiles, nct);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -233,7 +252,15 @@ static int g1_dispatch(const ConvArgs& a, int cot, hipStream_t s) {
 }
 
 // cot_req: requested cout tile (32-channel units); <= 0 or unsupported -> the default rule.  ck: channels per chunk, 16 or 32.
-int launch_conv1x1_dma(const ConvArgs& a, int cot_req, int ck, hipStream_t s) {
+int launch_conv1x1_dma(const ConvArgs& a, int cot_req, int ck, hipStream_t s, int pxw) {
+    if (pxw == 2) {                            // 64 pixels per wave: cout tiles 1 and 2 (64 / 128 accumulator registers... 32 / 64)
+        MCVD_REQUIRE(ck == 16 && conv1x1_dma_supported(a, 16, 2), "conv1x1 dma (256-pixel tile): unsupported shape (H=%d W=%d Cin=%d C0=%d)", a.H, a.W, a.Cin, a.C0);
+        const int n32 = a.CoutP / 32;
+        const int cot = (cot_req == 2 && n32 % 2 == 0) ? 2 : 1;
+        const int rc = cot == 2 ? g1_launch<2, 16, 2>(a, s) : g1_launch<1, 16, 2>(a, s);
+        if (rc == 0 && a.stats) set_last_conv_stats_np(a.H * a.W / 32);
+        return rc;
+    }
     MCVD_REQUIRE((ck == 16 || ck == 32) && conv1x1_dma_supported(a, ck), "conv1x1 dma: unsupported shape (ks=%d H=%d W=%d Cin=%d C0=%d ck=%d)",
                  a.ks, a.H, a.W, a.Cin, a.C0, ck);
     const int n32 = a.CoutP / 32;

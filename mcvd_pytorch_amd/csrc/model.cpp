@@ -808,6 +808,11 @@ int mcvd_model::autotune(int B) {
                         if (int rc = time_candidate(ck == 16 ? 5 : 6, c)) return rc;
                     }
                 }
+                if (conv1x1_dma_supported(a, 16, 2)) {      // 9 = the same GEMM with 64 pixels per wave (256-pixel tiles), cout tiles 1 / 2
+                    if (int rc = time_candidate(9, 1)) return rc;
+                    if ((op.CoutP / 32) % 2 == 0)
+                        if (int rc = time_candidate(9, 2)) return rc;
+                }
             }
             it = best.emplace(k, choice).first;
         }

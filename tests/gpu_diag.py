@@ -247,10 +247,12 @@ def sweep1(f):
         byts = 4.0 * B * H * H * (cin + cout * (2 if use_res else 1))
         line = f"{cin:4d} {cout:4d} {H:3d} c{use_coef} r{use_res} |"
         best = (1e9, "")
-        cands = [(0, 0), (1, 0), (2, 0)] + [(5, c) for c in (9, 6, 4, 3, 2, 1)] + [(6, c) for c in (6, 4, 3, 2, 1)]
+        cands = [(1, 0), (2, 0)] + [(5, c) for c in (3, 2, 1)] + [(6, c) for c in (2, 1)] + [(9, 1), (9, 2)]
         for shape, cot in cands:
             n32 = -(-cout // 32)
             if shape >= 5 and n32 % cot != 0:
+                continue
+            if shape == 9 and cot == 2 and n32 % 2 != 0:
                 continue
             ctx.opt("conv_shape", shape)
             ctx.opt("conv_cot", cot)

@@ -83,6 +83,10 @@ CONV_CASES = [
     (2, 192, 0, 576, 32, 1, True, 0, False, 6 + 16 * 3),   # all-DMA, 32-channel chunks
     (2, 96, 96, 192, 32, 1, False, 0, False, 6 + 16 * 6),  # ... over a concat, cout tile 6 (82 KiB of LDS)
     (3, 288, 0, 288, 8, 1, True, 1, True, 6 + 16 * 1),     # ... two images per pixel tile, affine + SiLU, residual
+    (2, 96, 96, 192, 32, 1, False, 0, False, 9 + 16 * 2),  # all-DMA, 64 pixels per wave (256-pixel tiles), concat, cout tile 64
+    (3, 192, 0, 576, 32, 1, True, 0, False, 9 + 16 * 1),   # ... q|k|v with the GN affine, cout tile 32, B*HW not a multiple of 256? (3*1024 is)
+    (5, 288, 0, 288, 8, 1, True, 1, True, 9 + 16 * 1),     # ... four 8x8 images per pixel tile, ragged last tile (5 images), affine + SiLU, residual
+    (1, 96, 0, 96, 16, 1, False, 0, True, 9 + 16 * 1),     # ... exactly one 256-pixel tile
 ]
 
 
@@ -102,6 +106,8 @@ def _expected_kernel(case):
         return 4
     if fam in (5, 6):
         return fam if Cin % (16 if fam == 5 else 32) == 0 else "direct"
+    if fam == 9:
+        return 9
     return None
 
 
