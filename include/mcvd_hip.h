@@ -92,7 +92,8 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  * kernel to the autotuner), "conv_cot" (with conv_shape 5: cout tile, in 32-channel units, that mcvd_op_conv2d requests), "conv_wdma" (1: weight
  * chunks by LDS-DMA, 0: register staging), "autotune" (1: time the conv tile candidates per layer shape on first use of a batch
  * size and keep the fastest), "side_stream" (1: ResBlock shortcut convs run on a second HIP stream concurrently with Conv_0; default 0, it measured slower), "profile" (0/1, see
- * mcvd_model_profile_read), "gn_stats" (1: GroupNorm statistics come out of the producing conv's epilogue where the kernel supports it, 0: always one pass
+ * mcvd_model_profile_read), "spade_fuse" (1: the SPADE modulation of a norm is applied inside the Winograd conv loader -- gamma | beta by LDS-DMA -- where that
+ * kernel runs the conv, 0 (default: the fused form measured 3.5 % slower end to end): materialised by spade_apply), "gn_stats" (1: GroupNorm statistics come out of the producing conv's epilogue where the kernel supports it, 0: always one pass
  * over the normalised tensor), "graph" (0/1: replay each UNet forward as ONE hipGraph launch instead of ~190 kernel launches -- a forward is
  * run eagerly the first time a (x, labels, cond, eps, B) pointer set is seen, captured on a private stream the second time and
  * replayed afterwards; mcvd_sampler_run presents the same set on every step.  Any option change, re-tune, workspace growth or
@@ -235,6 +236,11 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
  * implicit-GEMM tile shapes, 4 Winograd F(2x2,3x3), 8 Winograd with the 2-way K split, 5 / 6 all-DMA 1x1 GEMM; -1 none yet.  A forced
  * "conv_shape" that does not apply to a launch falls back to the direct kernel -- tests use this to assert what really ran. */
 int mcvd_last_conv_kernel(void);
+/* SPADE prologue of the Winograd conv kernel (layerspp.py:164-171, :530-535): while set (non-NULL gb), mcvd_op_conv2d computes
+ * conv(silu(((A x + B)(1 + gamma) + beta) * s1 + b2)) with (A, B) = coef, gamma | beta = gb:[B, 2*Cin, H, W] and (s1, b2) =
+ * coef2:[B, Cin, 2] (NULL: (1, 0)); needs conv_shape 4 or 8, ks 3, coef and act.  Inside a model forward this is what a SPADE net's
+ * non-resampling norms use (ctx option "spade_fuse"). */
+int mcvd_ctx_set_spade_inputs(mcvd_ctx* ctx, const float* gb, const float* coef2);
 /* GroupNorm statistics from the producing conv's epilogue.  When a buffer is set (device floats, >= B*Cout*(H*W/32)*2; NULL
  * disables), mcvd_op_conv2d's MFMA kernels also write, for every (sample, cout), np partial pairs (sum, M2 about the partial's own
  * mean) over disjoint sets of H*W/np output pixels: stats[((b*Cout + co)*np + p)*2 + {0,1}].  np depends on the kernel family that

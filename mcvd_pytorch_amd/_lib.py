@@ -63,6 +63,7 @@ _PROTOS = {
     "mcvd_last_conv_kernel": (_i, []),
     "mcvd_last_conv_stats_np": (_i, []),
     "mcvd_ctx_set_stats_buffer": (_i, [_vp, _vp]),
+    "mcvd_ctx_set_spade_inputs": (_i, [_vp, _vp, _vp]),
     "mcvd_op_gn_finalize": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _i, _i, _vp, _i, _i]),
     "mcvd_model_profile_read": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "mcvd_model_op_info": (_i, [_vp, _i, C.POINTER(_i)]),

@@ -48,6 +48,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     if (const char* t = getenv("MCVD_CONV_DMA1")) c->conv_dma1 = atoi(t);
     if (const char* t = getenv("MCVD_GRAPH")) c->graph = atoi(t);
     if (const char* t = getenv("MCVD_GN_STATS")) c->gn_stats = atoi(t);
+    if (const char* t = getenv("MCVD_SPADE_FUSE")) c->spade_fuse = atoi(t);
     const char* e = getenv("MCVD_NAIVE");
     if (e) {
         const int v = atoi(e);
@@ -81,6 +82,13 @@ int mcvd_ctx_set_debug_buffer(mcvd_ctx* ctx, void* device_u64) {
     return 0;
 }
 
+int mcvd_ctx_set_spade_inputs(mcvd_ctx* ctx, const float* gb, const float* coef2) {
+    MCVD_REQUIRE(ctx, "ctx is NULL");
+    ctx->spade_gb = gb;
+    ctx->spade_coef2 = coef2;
+    return 0;
+}
+
 int mcvd_ctx_set_stats_buffer(mcvd_ctx* ctx, float* device_floats) {
     MCVD_REQUIRE(ctx, "ctx is NULL");
     ctx->stats_buf = device_floats;
@@ -102,6 +110,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "conv_dma1")) ctx->conv_dma1 = value;
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
     else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
+    else if (!strcmp(key, "spade_fuse")) ctx->spade_fuse = value;
     else {
         set_error("unknown option '%s'", key);
         return MCVD_EINVAL;
@@ -759,6 +768,15 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.wdma = ctx->conv_wdma;
     a.dbg = ctx->dbg;
     a.stats = ctx->naive_conv ? nullptr : ctx->stats_buf;
+    if (ctx->spade_gb) {
+        MCVD_REQUIRE(wino && !ctx->naive_conv && coef && act, "op_conv2d: the SPADE prologue exists in the Winograd kernel only (conv_shape 4 / 8, "
+                     "3x3, coef and act given)");
+        a.gb = ctx->spade_gb;
+        a.coef2 = ctx->spade_coef2;
+        ConvArgs t = a;
+        t.ksplit = ctx->conv_shape == 8 ? 2 : 0;
+        MCVD_REQUIRE(conv_wino_usable(t) || (t.ksplit = 0, conv_wino_usable(t)), "op_conv2d: shape not served by the Winograd kernel");
+    }
     return ctx->naive_conv ? launch_conv_naive(a, ctx->stream) : launch_conv_mfma(a, ctx->stream);
     API_CATCH
 }

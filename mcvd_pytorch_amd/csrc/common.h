@@ -78,6 +78,10 @@ struct ConvArgs {
     // each, stats[((b * Cout + co) * np + p) * 2 + {0, 1}], of the FINAL output values.  np depends on the kernel that runs
     // (last_conv_stats_np() reports it; 0 = this kernel does not emit, the consumer then reads the tensor itself).
     float* stats;
+    // SPADE prologue (Winograd kernel only): gamma | beta maps [B][2*Cin][H][W] of the conditioning frames and the temb pair
+    // (1 + scale, shift) [B][Cin][2] (may be null); requires coef (plain GroupNorm coefficients) and act
+    const float* gb;
+    const float* coef2;
 };
 void set_last_conv_stats_np(int np);          // (launchers)
 int last_conv_stats_np();                     // partials per (sample, channel) the thread's last conv launch wrote to a.stats; 0 = none

@@ -53,7 +53,11 @@ constexpr int WR_NT = 1024;
 // 2-way conflict on half the lanes: SQ_LDS_BANK_CONFLICT 29 % of the LDS-active cycles, profiles/r01_pmc_sq_wave_states.txt).
 constexpr int WR_PP = 24;
 
-// PRO: 0 raw input, 1 affine, 2 affine + SiLU.
+// PRO: 0 raw input, 1 affine, 2 affine + SiLU, 3 SPADE: silu(((A x + B)(1 + gamma) + beta) * s1 + b2) with the per-pixel gamma | beta maps
+//     of the conditioning frames (a.gb: [B][2*Cin][H][W], layerspp.py:164-171) and the temb pair (s1, b2) = (1 + scale, shift) of
+//     a.coef2 ([B][Cin][2], NULL for the final norm: layerspp.py:530-535).  The maps never pass through registers: each thread's
+//     gamma and beta of the patch elements it activates are fetched by LDS-DMA (global_load_lds_dword) into a wave-private LDS
+//     slab, one chunk ahead like the patch itself, and read back by the same thread.
 // G8: 8x8 images -- the 32 tiles of a workgroup are TWO whole images (16 tiles each); every halo element is zero padding, so
 //     only the 2 x 64 interior pixels per channel are loaded (2 per thread and chunk) and the halo is zeroed once.
 // a.ksplit == 2 (grid.y = 2): the workgroup contracts one half of the input channels and stores its raw partial result to
@@ -74,11 +78,13 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     constexpr int PCOUNT = G8 ? CK * 2 * 64 : CK * 10 * 18;     // patch elements loaded per chunk
     constexpr int MAXP = (PCOUNT + NT - 1) / NT;                // 3 (2 for G8) loads per thread and chunk
     constexpr int VM_P = COT;                                   // vmcnt counts of the K loop, derived where they are used
-    constexpr int VM_A = COT + MAXP;
+    constexpr int VM_A = COT + MAXP * (PRO == 3 ? 3 : 1);       // PRO 3: + 2*MAXP gamma | beta DMA operations behind every patch load group
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sV = smem;                           // [2][VSZ]
     float* sP = smem + 2 * VSZ;                 // [2][PBUF]
     float* sCo = sP + 2 * PBUF;                 // [Cin][2] prologue coefficients (A_c, B_c) of this sample (PRO only)
+    float* sC2 = sCo + (G8 ? 4 : 2) * a.Cin;    // PRO 3: [Cin][2] (s1, b2) of this sample (G8: + the second sample's)
+    float* sGB = sC2 + (G8 ? 4 : 2) * a.Cin;    // PRO 3: [2][MAXP][NT] gamma | beta of the patch elements of ONE chunk, element e = sl*NT + tid
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int H = a.H, W = a.W, HW = H * W, Cin = a.Cin;
@@ -170,6 +176,21 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
             asm volatile("global_load_dword %0, %1, %2" : "=v"(D[sl]) : "v"(off), "s"(srcb) : "memory");        \
         }                                                                                                       \
     }
+    /* PRO 3: gamma | beta of the patch elements of chunk `ch`, same clamped offsets as the patch, by LDS-DMA into this wave's slab \
+       (2 * MAXP VMEM operations, counted by the vmcnt waits like the register loads) */                                    \
+#define WR_LOAD_GB(ch)                                                                                          \
+    if (PRO == 3) {                                                                                             \
+        const int cb = min((ch) * CK, Cin - 1);                                                                 \
+        const int cmax = Cin - 1 - cb;                                                                          \
+        const float* gsrc = a.gb + ((long)b * 2 * Cin + cb) * HW;                                               \
+        _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
+            const long off = (long)min(p_ci[sl] & (CK - 1), cmax) * HW + p_goff[sl] + (G8 ? (long)p_img[sl] * 2 * Cin * HW : 0); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + off),       \
+                                             (__attribute__((address_space(3))) void*)(sGB + sl * NT + wave_u * 64), 4, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (long)Cin * HW + off), \
+                                             (__attribute__((address_space(3))) void*)(sGB + (MAXP + sl) * NT + wave_u * 64), 4, 0, 0); \
+        }                                                                                                       \
+    }
 #define WR_WAIT_P(N, D)                                                                                         \
     {                                                                                                           \
         if (MAXP == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(D[0]), "+v"(D[1]) : "n"(N) : "memory");        \
@@ -189,10 +210,21 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
             }                                                                                                   \
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cfv[0]), "+v"(cfv[1]), "+v"(cfv[MAXP > 2 ? 2 : 0]) :: "memory"); \
         }                                                                                                       \
+        f32x2 c2v[MAXP];                                                                                        \
+        float gmv[MAXP], btv[MAXP];                                                                             \
+        if (PRO == 3) {                                                                                         \
+            _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                               \
+                const int cch = min((ch) * CK + (p_ci[sl] & (CK - 1)), Cin - 1) + (G8 ? p_img[sl] * Cin : 0);   \
+                c2v[sl] = *reinterpret_cast<const f32x2*>(sC2 + cch * 2);                                       \
+                gmv[sl] = sGB[sl * NT + tid];                                                                   \
+                btv[sl] = sGB[(MAXP + sl) * NT + tid];                                                          \
+            }                                                                                                   \
+        }                                                                                                       \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
             float v = D[sl];                                                                                    \
             if (PRO >= 1) v = v * cfv[sl].x + cfv[sl].y;                                                        \
-            if (PRO == 2) v = silu_wr(v);                                                                       \
+            if (PRO == 3) v = (v * (1.0f + gmv[sl]) + btv[sl]) * c2v[sl].x + c2v[sl].y;   /* spade_apply_kernel's order */ \
+            if (PRO >= 2) v = silu_wr(v);                                                                       \
             sPw[p_lds[sl]] = (p_ci[sl] < min(nvalid, CK)) ? v : 0.0f;                                           \
         }                                                                                                       \
     }
@@ -254,8 +286,18 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
         WR_LOAD_P(c_begin, q0)
         WR_LOAD_P(c_begin + 1, q1)
         WR_LOAD_P(c_begin + 2, pd)
+        WR_LOAD_GB(c_begin)
         if (PRO && a.coef && tid < Cin) cfl = *reinterpret_cast<const f32x2*>(a.coef + ((long)b * Cin + tid) * 2);
         if (PRO && tid < Cin) *reinterpret_cast<f32x2*>(sCo + tid * 2) = cfl;
+        if (PRO == 3 && tid < Cin) {           // (s1, b2): the temb pair, (1, 0) where the norm has none (final SPADE norm)
+            f32x2 c2 = {1.0f, 0.0f};
+            if (a.coef2) c2 = *reinterpret_cast<const f32x2*>(a.coef2 + ((long)b * Cin + tid) * 2);
+            *reinterpret_cast<f32x2*>(sC2 + tid * 2) = c2;
+            if (G8) {
+                if (a.coef2 && b + 1 < a.B) c2 = *reinterpret_cast<const f32x2*>(a.coef2 + ((long)(b + 1) * Cin + tid) * 2);
+                *reinterpret_cast<f32x2*>(sC2 + (Cin + tid) * 2) = c2;
+            }
+        }
         if (G8) {                          // the halo of both patch buffers is zero padding for the whole kernel
             for (int i = tid; i < 2 * PBUF; i += NT) sP[i] = 0.0f;
             if (PRO && a.coef && tid < Cin && b + 1 < a.B)     // second sample's coefficients: table rows Cin .. 2*Cin-1
@@ -272,12 +314,18 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
         if (rec) pt[1] = __builtin_amdgcn_s_memtime() - tk0;           // ... + memory latency
         if (PRO || G8) __syncthreads();    // coefficient table (and the zeroed halo) visible
         WR_WRITE_P(c_begin, q0)
+        if (PRO == 3) {                    // the gamma | beta slab holds ONE chunk: fetch the second chunk's now (one exposed latency
+            WR_LOAD_GB(c_begin + 1)        // per workgroup), the third's behind it for the first loop iteration
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         WR_WRITE_P(c_begin + 1, q1)
+        WR_LOAD_GB(c_begin + 2)
     }
     __syncthreads();                       // the first two patches visible
     if (rec) pt[2] = __builtin_amdgcn_s_memtime() - tk0;               // ... + table barrier + two patch blocks + barrier
     WR_WRITE_V(c_begin)
     __syncthreads();                       // V of the first chunk visible
+    if (PRO == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the loop's first wait leaves COT operations in flight
     WR_STAMP(0)
 
     // ---- K loop.  VMEM issue order of a wave in chunk c (in-order vmcnt counter; nothing else is outstanding):
@@ -349,6 +397,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
         WR_WRITE_P(c + 2, pd)
         WR_LOAD_A(2 * c + 1, A1)
         WR_LOAD_P(c + 3, pd)
+        WR_LOAD_GB(c + 3)
         if (grp == 3) WR_WRITE_V(c + 1)    // slot T
         WR_WAIT_A(VM_A, A0)
         WR_DO_MFMA(0, xb, A0)              // g0
@@ -504,6 +553,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
 #undef WR_LOAD_A
 #undef WR_WAIT_A
 #undef WR_LOAD_P
+#undef WR_LOAD_GB
 #undef WR_WAIT_P
 #undef WR_WRITE_P
 #undef WR_WRITE_V
@@ -555,8 +605,10 @@ __global__ __launch_bounds__(256) void wino_ksplit_reduce_stats_kernel(const flo
     }
 }
 
-static size_t wino_lds_bytes(int Cin, bool g8) {
-    const size_t k = (size_t)(2 * WR_CK * 16 * WR_T + 2 * (WR_CK * 10 * WR_PP + 4) + (g8 ? 4 : 2) * Cin) * sizeof(float);
+static size_t wino_lds_bytes(int Cin, bool g8, bool spade = false) {
+    const int maxp = g8 ? 2 : 3;               // MAXP of the kernel
+    const size_t k = (size_t)(2 * WR_CK * 16 * WR_T + 2 * (WR_CK * 10 * WR_PP + 4) + (g8 ? 4 : 2) * Cin * (spade ? 2 : 1) +
+                              (spade ? 2 * maxp * WR_NT : 0)) * sizeof(float);
     const size_t epi = (size_t)16 * 32 * WR_T * sizeof(float);        // sM of the epilogue
     return k > epi ? k : epi;
 }
@@ -600,7 +652,7 @@ static int wino_launch_exp(int e, const ConvArgs& k, dim3 grid, size_t lds, hipS
 template <int COT, int PRO, bool G8>
 static int wino_launch3(const ConvArgs& a, hipStream_t s) {
     constexpr int BCO = 32 * COT;
-    const size_t lds = wino_lds_bytes(a.Cin, G8);
+    const size_t lds = wino_lds_bytes(a.Cin, G8, PRO == 3);
     static PerDeviceOnce raised;
     if (raised.first_use()) {
         MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<COT, PRO, G8>),
@@ -653,6 +705,10 @@ static int wino_launch2(const ConvArgs& a, hipStream_t s) {
 
 template <int COT>
 static int wino_launch(const ConvArgs& a, hipStream_t s) {
+    if (a.gb) {
+        MCVD_REQUIRE(a.coef && a.act, "winograd conv: the SPADE prologue needs the GroupNorm coefficients and SiLU");
+        return wino_launch2<COT, 3>(a, s);
+    }
     if (!a.coef && !a.act) return wino_launch2<COT, 0>(a, s);
     if (!a.act) return wino_launch2<COT, 1>(a, s);
     return wino_launch2<COT, 2>(a, s);
@@ -672,7 +728,7 @@ bool conv_wino_usable(const ConvArgs& a) {
     return conv_wino_supported(a.ks, a.H, a.W) && a.wpw && a.Cin <= 1024 && a.CinP % WR_CK == 0 &&
            (a.C1 == 0 || a.C0 % WR_CK == 0) &&                                       // a chunk never straddles the concat seam
            (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) &&      // 32-bit byte offsets of the patch loads
-           wino_lds_bytes(a.Cin, a.H == 8 && a.W == 8) <= 160 * 1024 &&
+           wino_lds_bytes(a.Cin, a.H == 8 && a.W == 8, a.gb != nullptr) <= 160 * 1024 &&
            (a.ksplit != 2 || ((a.CinP / WR_CK) % 2 == 0 && a.CinP / WR_CK >= 4 && a.part != nullptr));
 }
 

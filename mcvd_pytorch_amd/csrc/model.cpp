@@ -135,12 +135,13 @@ struct Builder {
         TRef seg = seg_for(R);
         TRef sh = alloc(sd, R);
         Op c1{};
-        c1.kind = OP_CONV; c1.module = module; c1.prep = true; c1.src0 = seg; c1.H = c1.W = R; c1.dst = sh;
+        (void)module;                      // the modulation convs are not a reference module's output: keep them out of module_output()
+        c1.kind = OP_CONV; c1.module = -1; c1.prep = true; c1.src0 = seg; c1.H = c1.W = R; c1.dst = sh;
         conv_pack(c1, {N + ".mlp_shared.0.weight"}, {N + ".mlp_shared.0.bias"}, sd, cond_ch, 3, 0);
         m.ops.push_back(c1);
         TRef gb = alloc(2 * ch, R);
         Op c2{};
-        c2.kind = OP_CONV; c2.module = module; c2.prep = true; c2.src0 = sh; c2.H = c2.W = R; c2.act = 1; c2.dst = gb;   // silu(mlp_shared) :148
+        c2.kind = OP_CONV; c2.module = -1; c2.prep = true; c2.src0 = sh; c2.H = c2.W = R; c2.act = 1; c2.dst = gb;   // silu(mlp_shared) :148
         conv_pack(c2, {N + ".mlp_gamma.weight", N + ".mlp_beta.weight"}, {N + ".mlp_gamma.bias", N + ".mlp_beta.bias"}, ch, sd, 3, 0);
         m.ops.push_back(c2);
         m.has_prep = true;
@@ -264,15 +265,10 @@ struct Builder {
             emit_shortcut();
             Op c{};
             c.kind = OP_CONV; c.module = idx; c.H = c.W = H; c.dst = h1.a;
-            if (spade) {                         // modulated + activated tensor is materialised, conv reads it plainly
-                TRef t = alloc(cin, H);
-                Op ap{};
-                ap.kind = OP_APPLY; ap.module = idx; ap.src0 = x.a; ap.src1 = x.b; ap.H = ap.W = H; ap.coef = coef0; ap.gb = gb0;
-                ap.coef2 = c2_0; ap.dst = t;
-                m.ops.push_back(ap);
-                c.src0 = t;
-            } else {
-                c.src0 = x.a; c.src1 = x.b; c.coef = coef0; c.act = 1;
+            c.src0 = x.a; c.src1 = x.b; c.coef = coef0; c.act = 1;
+            if (spade) {                         // SPADE modulation in the conv loader (Winograd kernel); `tmp` serves the kernels
+                c.gb = gb0; c.coef2 = c2_0;      // that cannot take it: spade_apply materialises the activated tensor there
+                c.tmp = alloc(cin, H);
             }
             conv_pack(c, {P + ".Conv_0.weight"}, {P + ".Conv_0.bias"}, cout, cin, 3, 0);
             m.ops.push_back(c);
@@ -280,15 +276,11 @@ struct Builder {
         // ---- actnorm1
         TRef coef1 = alloc_floats(2 * cout, cout);
         TRef conv1_src = h1.a;
+        TRef c2_1;
         if (spade) {
             m.ops.push_back(gn_op(idx, h1, 1e-6f, 0, 0, -1, -1, coef1));
-            TRef c2_1 = alloc_floats(2 * cout, cout);
+            c2_1 = alloc_floats(2 * cout, cout);
             m.ops.push_back(coef2_op(idx, e1, cout, c2_1));
-            TRef t = alloc(cout, Ho);
-            Op ap{};
-            ap.kind = OP_APPLY; ap.module = idx; ap.src0 = h1.a; ap.H = ap.W = Ho; ap.coef = coef1; ap.gb = gb1; ap.coef2 = c2_1; ap.dst = t;
-            m.ops.push_back(ap);
-            conv1_src = t;
         } else {
             m.ops.push_back(gn_op(idx, h1, 1e-5f, 1, e1, -1, -1, coef1));
         }
@@ -299,7 +291,8 @@ struct Builder {
         Op c{};
         c.kind = OP_CONV; c.module = idx; c.src0 = conv1_src; c.H = c.W = Ho; c.res = res; c.out_scale = rs2; c.dst = out->a;
         c.join = conv2;
-        if (!spade) { c.coef = coef1; c.act = 1; }
+        c.coef = coef1; c.act = 1;
+        if (spade) { c.gb = gb1; c.coef2 = c2_1; c.tmp = alloc(cout, Ho); }
         conv_pack(c, {P + ".Conv_1.weight"}, {P + ".Conv_1.bias"}, cout, cout, 3, 0);
         m.ops.push_back(c);
         return 0;
@@ -479,11 +472,8 @@ int mcvd_model::build_plan() {
         if (c.spade) {
             TRef gb = bld.spade_prep(idx, P, in_ch, h.H);
             ops.push_back(bld.gn_op(idx, h, 1e-6f, 0, 0, -1, -1, coef));
-            TRef t = bld.alloc(in_ch, h.H);
-            Op ap{};
-            ap.kind = OP_APPLY; ap.module = idx; ap.src0 = h.a; ap.H = ap.W = h.H; ap.coef = coef; ap.gb = gb; ap.dst = t;
-            ops.push_back(ap);
-            cv.src0 = t;
+            cv.src0 = h.a; cv.coef = coef; cv.act = 1; cv.gb = gb;          // no temb pair here (ncsnpp_more.py:584-585)
+            cv.tmp = bld.alloc(in_ch, h.H);
         } else {
             const int gw = add_param(P + ".Norm_0.weight", {in_ch});
             const int gb = add_param(P + ".Norm_0.bias", {in_ch});
@@ -653,6 +643,24 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             }
             // epilogue statistics from the 3x3 (Winograd) producers; the 1x1 GEMM's epilogue can emit them too, but its 16*COT
             // 32-lane reductions per wave cost the NIN_3 launches more than the norms they spare save (measured): "gn_stats" = 2 only
+            if (op.gb.kind != REF_NONE) {
+                // SPADE norm in front of this conv: fused into the Winograd loader where that kernel takes the launch, otherwise
+                // spade_apply materialises silu(((A x + B)(1 + gamma) + beta) s1 + b2) and the conv reads it plainly
+                a.gb = resolve(op.gb, x, cond, out, B);
+                a.coef2 = op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B);
+                ConvArgs t = a;
+                t.shape_hint = (a.shape_hint == 8) ? 8 : 4;
+                t.ksplit = t.shape_hint == 8 ? 2 : 0;
+                bool fused = ctx->spade_fuse && !ctx->naive_conv && ctx->winograd && conv_wino_usable(t);
+                if (!fused && t.ksplit == 2) { t.ksplit = 0; t.shape_hint = 4; fused = ctx->spade_fuse && !ctx->naive_conv && ctx->winograd && conv_wino_usable(t); }
+                if (fused) {
+                    a.shape_hint = t.shape_hint;
+                } else {
+                    float* tmp = resolve(op.tmp, x, cond, out, B);
+                    if (int rc = launch_spade_apply(a.x0, a.C0, a.x1, a.C1, a.coef, a.gb, a.coef2, tmp, B, op.H * op.W, s)) return rc;
+                    a.x0 = tmp; a.x1 = nullptr; a.C0 = a.Cin; a.C1 = 0; a.coef = nullptr; a.act = 0; a.gb = nullptr; a.coef2 = nullptr;
+                }
+            }
             a.stats = (ctx->gn_stats && op.stats.kind != REF_NONE && !ctx->naive_conv && (op.ks == 3 || ctx->gn_stats >= 2))
                           ? resolve(op.stats, x, cond, out, B) : nullptr;
             if (ctx->naive_conv) {
@@ -742,7 +750,8 @@ int mcvd_model::autotune(int B) {
         const Op& op = ops[i];
         if (op.kind != OP_CONV) continue;
         const int cin = op.src0.C + (op.src1.kind == REF_NONE ? 0 : op.src1.C);
-        Key k{op.ks, op.H, cin, op.Cout, op.coef.kind != REF_NONE, op.res.kind != REF_NONE};
+        Key k{op.ks, op.H, cin, op.Cout, (op.coef.kind != REF_NONE ? 1 : 0) + (op.gb.kind != REF_NONE ? 2 : 0) + (op.coef2.kind != REF_NONE ? 4 : 0),
+              op.res.kind != REF_NONE};
         auto it = best.find(k);
         if (it == best.end()) {
             ConvArgs a{};
@@ -761,6 +770,14 @@ int mcvd_model::autotune(int B) {
             a.B = B; a.Cin = cin; a.CinP = op.CinP; a.Cout = op.Cout; a.CoutP = op.CoutP; a.H = op.H; a.W = op.W; a.ks = op.ks;
             a.wdma = ctx->conv_wdma;
             a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
+            const bool spade_fused = op.gb.kind != REF_NONE && ctx->spade_fuse && ctx->winograd;
+            if (spade_fused) {
+                a.gb = resolve(op.gb, scratch_io, scratch_io, scratch_io, B);
+                a.coef2 = op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, scratch_io, scratch_io, scratch_io, B);
+            } else if (op.gb.kind != REF_NONE) {           // unfused: the conv sees the materialised tensor
+                a.x0 = resolve(op.tmp, scratch_io, scratch_io, scratch_io, B);
+                a.x1 = nullptr; a.C0 = cin; a.C1 = 0; a.coef = nullptr; a.act = 0;
+            }
             float best_ms = 1e30f;
             std::pair<int, int> choice{-1, op.cot};
             auto time_candidate = [&](int shape, int cot) -> int {
@@ -780,6 +797,7 @@ int mcvd_model::autotune(int B) {
             const int cots[2] = {op.cot, 1};
             for (int ci = 0; ci < (op.cot == 1 ? 1 : 2); ++ci) {
                 for (int shape = 0; shape < 5; ++shape) {
+                    if (spade_fused && conv_wino_usable(a) && shape != 4) continue;   // SPADE prologue: the Winograd kernel only
                     if (shape == 3 && (op.ks != 3 || !ctx->conv_wdma)) continue;      // 3 = split-K with double-buffered weights
                     if (shape == 4 && (ci > 0 || !ctx->winograd || !conv_wino_usable(a))) continue;   // 4 = Winograd F(2x2,3x3), own cout tile
                     const int bpx = shape == 0 ? 256 : shape == 1 ? 128 : 64;

@@ -25,10 +25,14 @@ struct mcvd_ctx {
     int side_stream = 0;           // 1: run the ResBlock shortcut 1x1 convs on a second stream (measured -2 %: off by default)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int spade_fuse = 0;            // 1: SPADE modulation inside the Winograd conv loader (gamma | beta by LDS-DMA); 0: through spade_apply.
+                                   //    Off by default: measured 3.5 % SLOWER end to end (profiles/r02_spade_fusion_ab.txt)
     int gn_stats = 1;              // GroupNorm statistics from the producing conv's epilogue (0: always one pass over the tensor)
     int autotune = 1;              // time the conv tile candidates per distinct layer shape on first use of a batch size
     int profile = 0;               // record HIP events around every op of the first forward of each sampler call
     unsigned long long* dbg = nullptr;   // conv phase-timing buffer for mcvd_op_conv2d (diagnostics)
+    const float* spade_gb = nullptr;     // mcvd_op_conv2d: SPADE prologue inputs of the next convs (mcvd_ctx_set_spade_inputs; tests)
+    const float* spade_coef2 = nullptr;
     float* stats_buf = nullptr;          // mcvd_op_conv2d: where the conv's GroupNorm partials go (mcvd_ctx_set_stats_buffer; tests)
     float* scratch = nullptr;      // small device scratch for stand-alone ops (kernel taps, packed weights)
     size_t scratch_bytes = 0;
@@ -81,6 +85,7 @@ struct Op {
     int heads = 0;
     // SPADE: gb = cached [2C] (gamma | beta) maps, coef2 = (1 + scale, shift) per (sample, channel)
     TRef gb, coef2;
+    TRef tmp;                      // conv with a SPADE norm in front: where spade_apply materialises its input when the kernel cannot fuse it
     TRef dst2;                     // FIR: second output (raw-input resampling for the shortcut path)
     bool side = false;             // independent of the main chain until `join`: may run on the side stream
     bool join = false;             // must wait for the preceding side op

@@ -229,6 +229,74 @@ def test_conv_epilogue_group_norm_statistics(ctx, case):
         torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("case", [
+    # (B, C0, C1, Cout, H, coef2, res, shape)
+    (2, 96, 0, 96, 64, True, True, 4),           # ResBlock Conv_1 at 64x64
+    (3, 64, 32, 64, 32, True, False, 4),         # up-path Conv_0 over a virtual concat
+    (5, 48, 16, 96, 8, True, True, 4),           # 8x8 images: two samples per workgroup, B odd
+    (4, 288, 0, 288, 8, True, True, 8),          # ... with the K split
+    (2, 96, 0, 6, 64, False, False, 4),          # final SPADE norm: no temb pair, Cout = C*nf
+    (2, 40, 0, 64, 16, True, False, 4),          # Cin not a multiple of the 16-channel chunk
+], ids=lambda c: "c{}+{}_o{}_H{}_s{}".format(c[1], c[2], c[3], c[4], c[7]))
+def test_conv_spade_prologue(ctx, case):
+    """SPADE in the conv loader (layerspp.py:164-171, :530-535): conv(silu(((A x + B)(1 + gamma) + beta)(s1) + b2)) with the
+    gamma | beta maps fetched by LDS-DMA, vs the same expression in torch."""
+    from mcvd_pytorch_amd import _lib
+    from tests.hiputil import P
+    B, C0, C1, Cout, H, use_c2, use_res, shape = case
+    g = _g(31)
+    Cin = C0 + C1
+    x0 = torch.randn(B, C0, H, H, generator=g)
+    x1 = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = 0.1 * torch.randn(Cout, generator=g)
+    coef = torch.stack([1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], dim=-1)
+    gb = 0.5 * torch.randn(B, 2 * Cin, H, H, generator=g)
+    coef2 = torch.stack([1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], dim=-1) if use_c2 else None
+    res = torch.randn(B, Cout, H, H, generator=g) if use_res else None
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    h = xin * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]
+    h = h * (1 + gb[:, :Cin]) + gb[:, Cin:]
+    if use_c2:
+        h = h * coef2[..., 0][:, :, None, None] + coef2[..., 1][:, :, None, None]
+    want = F.conv2d(unet_ref.silu(h), w, bias, padding=1)
+    if use_res:
+        want = (want + res) * 0.70710678
+    dev = lambda t: t.cuda().contiguous() if t is not None else None
+    gbd, c2d = dev(gb), dev(coef2)
+    ctx.opt("conv_shape", shape)
+    _lib.check(_lib.lib.mcvd_ctx_set_spade_inputs(ctx.h, P(gbd), P(c2d)))
+    try:
+        got = ctx.conv2d(dev(x0), dev(w), dev(bias), x1=dev(x1), coef=dev(coef), act=1, res=dev(res), scale=0.70710678 if use_res else 1.0)
+        ran = _lib.lib.mcvd_last_conv_kernel()
+    finally:
+        _lib.check(_lib.lib.mcvd_ctx_set_spade_inputs(ctx.h, None, None))
+        ctx.opt("conv_shape", -1)
+    assert ran == shape, ran
+    _close(got, want, what=f"spade conv {case}")
+
+
+def test_spade_fused_and_materialised_paths_agree():
+    """A SPADE net with the modulation in the conv loader (option spade_fuse) vs through spade_apply (default): same eps to fp32
+    rounding, and a whole sampler call with the fused loader against the reference fixture."""
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    config, sd, net = _net("tiny_spade")
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    t = torch.tensor([700, 20]).cuda()
+    b = net(x.cuda(), t, cond=cond.cuda()).clone()
+    net.set_option("spade_fuse", 1)
+    a = net(x.cuda(), t, cond=cond.cuda()).clone()
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_spade_b2.pt"), weights_only=False)
+    out = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10, noise=synth.make_noise(config, 2, 11, seed=2).cuda())
+    assert (out.cpu() - g["sampler_ddpm_10"]["result"]).abs().max().item() <= 1e-4
+    net.set_option("spade_fuse", 0)
+    assert not torch.equal(a, b)
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t.cpu(), cond)
+    assert (a.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
 def test_gn_statistics_paths_agree_on_a_forward():
     """Whole forward with statistics from the epilogues (default) vs with a pass over every normalised tensor: same eps to fp32
     rounding, and the epilogue path really is used (fewer tensor-reading norm launches is asserted through the op table)."""

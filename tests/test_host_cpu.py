@@ -112,6 +112,9 @@ def test_winograd_isa_checker_flags_violations():
                "\ts_cbranch_scc1 .LBB0_1\n.LBB0_2:\n\ts_endpgm\n.Lfunc_end0:\n")
     others = "".join(f"_ZN4mcvd16conv_wino_kernelILi{a}ELi{b}ELb0EEEvNS_8ConvArgsE: ; @x\n" + loop_ok.replace("LBB0", f"LBB{a}{b}")
                      for a, b in [(1, 1), (1, 2)])
+    spade_loop = loop_ok.replace("\tglobal_load_dwordx4 v[24:27], v30, s[2:3]\n",
+                                 "".join("\tglobal_load_lds_dword v[60:61], off\n" for _ in range(6)) + "\tglobal_load_dwordx4 v[24:27], v30, s[2:3]\n")
+    others += "_ZN4mcvd16conv_wino_kernelILi1ELi3ELb0EEEvNS_8ConvArgsE: ; @x\n" + spade_loop.replace("LBB0", "LBB13")
     def problems(loop):
         return [p for p in c.check(head + loop + others) if "ILi1ELi0ELb0" in p]
     assert problems(loop_ok) == []
@@ -119,6 +122,8 @@ def test_winograd_isa_checker_flags_violations():
     assert any("touches the destination" in p for p in problems(bad_copy))
     bad_spill = loop_ok.replace("\tv_add_u32_e32 v50, v51, v52\n", "\tscratch_store_dword off, v50, off\n")
     assert any("spill" in p for p in problems(bad_spill))
+    assert not [p for p in c.check(head + loop_ok + others) if "ILi1ELi3ELb0" in p]          # PRO 3: six LDS-DMA loads are expected
+    assert any("LDS-DMA" in p for p in c.check(head + spade_loop + others) if "ILi1ELi0ELb0" in p)   # ... and rejected elsewhere
 
 
 def test_product_never_touches_the_oracle():

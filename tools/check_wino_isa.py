@@ -6,7 +6,8 @@ the destination registers of those loads are pending.  That is only sound if, in
   1. nothing reads or overwrites a destination register between the load and a following `s_waitcnt vmcnt` (no copies, no
      spills, no reuse as a temporary), following the loop's layout order and wrapping around the back edge;
   2. the loop contains no scratch (spill) instructions: they are VMEM operations and would break the counts;
-  3. the loop's VMEM instructions are exactly the asm loads (COT weight loads twice per chunk + 3 patch loads, 2 for the 8x8 form).
+  3. the loop's VMEM instructions are exactly the asm loads (COT weight loads twice per chunk + 3 patch loads, 2 for the 8x8 form)
+     plus, in the SPADE-prologue instantiations (PRO 3), two LDS-DMA loads per patch load (gamma | beta), which the vmcnt counts include.
 This script compiles the file to gfx950 assembly and verifies 1-3 for every instantiation of conv_wino_kernel.
 """
 import os
@@ -30,8 +31,9 @@ def _regs(text):
 def check(asm_text):
     problems, seen = [], 0
     for m in re.finditer(r"^(_ZN4mcvd16conv_wino_kernelILi(\d)ELi(\d)ELb(\d)E(?:Li0E)?EEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
-        name, cot, g8, body = m.group(1), int(m.group(2)), int(m.group(4)), m.group(5)
+        name, cot, pro, g8, body = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), m.group(5)
         npatch = 2 if g8 else 3                                        # patch loads per thread and chunk (MAXP)
+        ndma = 2 * npatch if pro == 3 else 0                           # SPADE prologue: gamma | beta of every patch element by LDS-DMA
         seen += 1
         lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
         starts = [i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l) and "Loop" in l]
@@ -46,8 +48,10 @@ def check(asm_text):
         if any(l.startswith("scratch_") for l in vmem):
             problems.append(f"{name}: spill code inside the K loop")
         loads = [l for l in vmem if re.match(r"^global_load_dword(x4)? v", l)]
-        if len(loads) != len(vmem) or len(loads) != 2 * cot + npatch:
-            problems.append(f"{name}: expected {2 * cot + npatch} asm loads and no other VMEM in the loop, found {len(loads)} of {len(vmem)}")
+        dmas = [l for l in vmem if re.match(r"^global_load_lds_dword ", l)]
+        if len(loads) + len(dmas) != len(vmem) or len(loads) != 2 * cot + npatch or len(dmas) != ndma:
+            problems.append(f"{name}: expected {2 * cot + npatch} asm loads + {ndma} LDS-DMA loads and no other VMEM in the loop, "
+                            f"found {len(loads)} + {len(dmas)} of {len(vmem)}")
         n = len(loop)
         for i, l in enumerate(loop):
             mm = re.match(r"^global_load_dword(?:x4)? (v\d+|v\[\d+:\d+\]),", l)
@@ -62,8 +66,8 @@ def check(asm_text):
                 if len(ops) > 1 and _regs(ops[1]) & dest:
                     problems.append(f"{name}: `{nxt}` touches the destination of `{l}` before any vmcnt wait")
                     break
-    if seen != 18:
-        problems.append(f"expected 18 instantiations of conv_wino_kernel, found {seen}")
+    if seen != 24:
+        problems.append(f"expected 24 instantiations of conv_wino_kernel, found {seen}")
     return problems
 
 
