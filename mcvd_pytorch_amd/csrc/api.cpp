@@ -270,8 +270,15 @@ int mcvd_model_finalize(mcvd_model* m) {
             if (int rc = launch_pack_conv_weight(m->blob + w.off, m->packed + p.wp, p.Cout_each, p.Cin, p.ks, p.CinP, p.CoutP,
                                                  p.nin, (int)j * p.Cout_each, s))
                 return rc;
-            MCVD_HIP_CHECK(hipMemcpyAsync(m->packed + p.bias + j * p.Cout_each, m->blob + b.off,
-                                          (size_t)p.Cout_each * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (!p.zero_bias)
+                MCVD_HIP_CHECK(hipMemcpyAsync(m->packed + p.bias + j * p.Cout_each, m->blob + b.off,
+                                              (size_t)p.Cout_each * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (!p.extra_bias.empty()) {          // packed bias += the up-block shortcut's bias (model.cpp: res_block)
+                const ParamInfo& e = m->params[m->find_param(p.extra_bias.c_str())];
+                const float* in[4] = {m->packed + p.bias, m->blob + e.off, nullptr, nullptr};
+                const float w2[4] = {1.0f, 1.0f, 0.0f, 0.0f};
+                if (int rc = launch_lincomb(m->packed + p.bias, in, w2, 1.0f, 2, p.Cout_each, s)) return rc;
+            }
             if (p.wpw >= 0)
                 if (int rc = launch_pack_wino_weight(m->blob + w.off, m->packed + p.wpw, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
         }
@@ -548,7 +555,8 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
         m->cond_noise_offset = sample_offset;
         m->cond_noise_draw = 0;
     }
-    struct CondGammaGuard { mcvd_model* m; ~CondGammaGuard() { m->cond_gamma_k = 0.f; } } cg_guard{m};
+    struct CondGammaGuard { mcvd_model* m; ~CondGammaGuard() { m->cond_gamma_k = 0.f; m->uniform_labels = 0; } } cg_guard{m};
+    m->uniform_labels = 1;            // every forward of the loop labels all rows alike (:283, :332)
     auto set_cond_gamma = [&](int label) {         // ncsnpp_more.py:761-765: k_cum[labels], theta_t[labels], alphas[labels]
         if (!(gam && m->d.noise_in_cond)) return;
         m->cond_gamma_k = m->k_cum[label];
@@ -626,7 +634,8 @@ int mcvd_fpndm_run(mcvd_model* m, float* x, const float* cond, int subsample_ste
     const int64_t n = per * B;
     if (int rc = m->prepare_B(B)) return rc;
     if (int rc = m->prepare_cond(cond, B)) return rc;
-    struct CacheGuard { mcvd_model* m; ~CacheGuard() { m->cond_cache_valid = false; } } guard{m};
+    struct CacheGuard { mcvd_model* m; ~CacheGuard() { m->cond_cache_valid = false; m->uniform_labels = 0; } } guard{m};
+    m->uniform_labels = 1;
     hipStream_t s = m->ctx->stream;
     if (m->fp_B < B) {
         MCVD_HIP_CHECK(hipStreamSynchronize(s));

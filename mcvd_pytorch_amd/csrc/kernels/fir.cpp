@@ -127,10 +127,101 @@ __global__ __launch_bounds__(256) void fir2_kernel(FirArgs a) {
     }
 }
 
+// FIR x2 UP, one thread per (input row ny, 4 input columns): the 3 x 6 input window (rows ny-1..ny+1, columns nx0-1..nx0+4) as one
+// aligned float4 + the two edge columns per row, unconditional with clamped coordinates, activated ONCE per element and zeroed
+// after the activation where outside -> 2 x 8 outputs (rows 2ny, 2ny+1; columns 2nx0..2nx0+7) as four float4 stores.
+// (The generic path above loads 8 predicated scalars and activates them for every 4 outputs: 152 us -> see DESIGN.md for the
+// 32x32 -> 64x64, 192-channel, B=64 launch.)
+__global__ __launch_bounds__(256) void fir_up2_kernel(FirArgs a) {
+    const int W4 = a.W >> 2;
+    const int OW = 2 * a.W;
+    const long n = (long)a.B * a.C * a.H * W4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int nx0 = (int)(i % W4) * 4;
+        const int ny = (int)((i / W4) % a.H);
+        const long bc = i / ((long)W4 * a.H);
+        const float* plane = a.x + bc * a.H * a.W;
+        float cA = 1.f, cB = 0.f, sA = 1.f, sB = 0.f;
+        if (a.coef) { cA = a.coef[bc * 2]; cB = a.coef[bc * 2 + 1]; }
+        if (a.coef2) { sA = a.coef2[bc * 2]; sB = a.coef2[bc * 2 + 1]; }
+        const float* gpl = nullptr;
+        const float* bpl = nullptr;
+        if (a.gamma) {
+            const long b = bc / a.C, c = bc - b * a.C;
+            gpl = a.gamma + (b * 2 * a.C + c) * a.H * a.W;
+            bpl = a.beta + (b * 2 * a.C + c) * a.H * a.W;
+        }
+        const bool in_l = nx0 > 0, in_r = nx0 + 4 < a.W;
+        float hv[3][6], rv[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = ny - 1 + r;
+            const bool in_y = yy >= 0 && yy < a.H;
+            const int yc = min(max(yy, 0), a.H - 1);
+            const float* rowp = plane + yc * a.W;
+            const float4 q = *reinterpret_cast<const float4*>(rowp + nx0);
+            const float vals[6] = {rowp[max(nx0 - 1, 0)], q.x, q.y, q.z, q.w, rowp[min(nx0 + 4, a.W - 1)]};
+            float gv[6], bv[6];
+            if (a.gamma) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gpl + yc * a.W + nx0);
+                const float4 b4 = *reinterpret_cast<const float4*>(bpl + yc * a.W + nx0);
+                gv[0] = gpl[yc * a.W + max(nx0 - 1, 0)]; gv[1] = g4.x; gv[2] = g4.y; gv[3] = g4.z; gv[4] = g4.w; gv[5] = gpl[yc * a.W + min(nx0 + 4, a.W - 1)];
+                bv[0] = bpl[yc * a.W + max(nx0 - 1, 0)]; bv[1] = b4.x; bv[2] = b4.y; bv[3] = b4.z; bv[4] = b4.w; bv[5] = bpl[yc * a.W + min(nx0 + 4, a.W - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const bool in = in_y && (j == 0 ? in_l : j == 5 ? in_r : true);
+                float v = vals[j];
+                if (a.coef) v = v * cA + cB;
+                if (a.gamma) {
+                    v = v * (1.0f + gv[j]) + bv[j];
+                    v = v * sA + sB;
+                }
+                if (a.act) v = silu1(v);
+                hv[r][j] = in ? v : 0.0f;
+                rv[r][j] = in ? vals[j] : 0.0f;
+            }
+        }
+        // per axis: y[2n] = x[n-1]/4 + 3x[n]/4 ; y[2n+1] = 3x[n]/4 + x[n+1]/4     (SURVEY 9.4), rows first then columns,
+        // with the operation order of the generic path (wya * p + wyb * q; 0.25 * c0 + 0.75 * c1 ...)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            float col[6], colr[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                col[j] = rr == 0 ? 0.25f * hv[0][j] + 0.75f * hv[1][j] : 0.75f * hv[1][j] + 0.25f * hv[2][j];
+                colr[j] = rr == 0 ? 0.25f * rv[0][j] + 0.75f * rv[1][j] : 0.75f * rv[1][j] + 0.25f * rv[2][j];
+            }
+            float o[8], r8[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[2 * k] = 0.25f * col[k] + 0.75f * col[k + 1];
+                o[2 * k + 1] = 0.75f * col[k + 1] + 0.25f * col[k + 2];
+                r8[2 * k] = 0.25f * colr[k] + 0.75f * colr[k + 1];
+                r8[2 * k + 1] = 0.75f * colr[k + 1] + 0.25f * colr[k + 2];
+            }
+            const long orow = (bc * 2 * a.H + 2 * ny + rr) * OW + 2 * nx0;
+            *reinterpret_cast<float4*>(a.y + orow) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(a.y + orow + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            if (a.y_raw) {
+                *reinterpret_cast<float4*>(a.y_raw + orow) = make_float4(r8[0], r8[1], r8[2], r8[3]);
+                *reinterpret_cast<float4*>(a.y_raw + orow + 4) = make_float4(r8[4], r8[5], r8[6], r8[7]);
+            }
+        }
+    }
+}
+
 int launch_fir2(const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W,
                 const float* gamma, const float* beta, const float* coef2, float* y_raw, hipStream_t s) {
     MCVD_REQUIRE((up ? W * 2 : W / 2) % 4 == 0 && H % 2 == 0, "fir2: H=%d W=%d unsupported", H, W);
     FirArgs a{x, coef, act, up, y, B, C, H, W, y_raw, gamma, beta, coef2};
+    if (up && W % 4 == 0) {
+        const long n = (long)B * C * H * (W / 4);
+        const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+        hipLaunchKernelGGL(fir_up2_kernel, dim3(blocks), dim3(256), 0, s, a);
+        MCVD_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const long n4 = (long)B * C * (up ? H * 2 : H / 2) * ((up ? W * 2 : W / 2) / 4);
     const int blocks = (int)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
     hipLaunchKernelGGL(fir2_kernel, dim3(blocks), dim3(256), 0, s, a);

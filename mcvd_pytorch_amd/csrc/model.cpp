@@ -237,6 +237,7 @@ struct Builder {
         h1.H = Ho;
         h1.a = alloc(cout, Ho);
         TRef shortcut_src0 = x.a, shortcut_src1 = x.b;
+        std::string shortcut_bias;  // up blocks: Conv_2's bias joins Conv_1's (see below)
         TRef res = x.a;             // identity shortcut unless Conv_2 exists (in == out, no resample => single source)
         auto emit_shortcut = [&]() {
             if (!conv2) return;
@@ -247,10 +248,35 @@ struct Builder {
             conv_pack(c, {P + ".Conv_2.weight"}, {P + ".Conv_2.bias"}, cout, cin, 1, 0);
             m.ops.push_back(c);
         };
-        if (up || down) {
+        if (up) {
+            // Up block: Conv_2 is pointwise over channels, the FIR acts per channel over space -- the two commute EXACTLY
+            // (zero boundary included): Conv_2(FIR_up(x)) = FIR_up(W2 x) + b2.  So the shortcut GEMM runs on the LOW-resolution x
+            // (a quarter of the pixels the reference order multiplies, layerspp.py:600-601, :619-620), its result is upsampled, and
+            // b2 -- which must not pass through the zero-padded FIR -- is added with Conv_1's bias in that conv's epilogue.
+            TRef r_lo = alloc(cout, H);
+            Op c2{};
+            c2.kind = OP_CONV; c2.module = idx; c2.src0 = x.a; c2.H = c2.W = H; c2.dst = r_lo;
+            conv_pack(c2, {P + ".Conv_2.weight"}, {P + ".Conv_2.bias"}, cout, cin, 1, 0);
+            m.packs.back().zero_bias = true;
+            m.ops.push_back(c2);
+            res = alloc(cout, Ho);
+            Op f2{};
+            f2.kind = OP_FIR; f2.module = idx; f2.src0 = r_lo; f2.H = f2.W = H; f2.up = 1; f2.dst = res;
+            m.ops.push_back(f2);
+            TRef hA = alloc(cin, Ho);
+            Op f{};
+            f.kind = OP_FIR; f.module = idx; f.src0 = x.a; f.H = f.W = H; f.coef = coef0; f.act = 1; f.up = 1; f.dst = hA;
+            if (spade) { f.gb = gb0; f.coef2 = c2_0; }
+            m.ops.push_back(f);
+            Op c{};
+            c.kind = OP_CONV; c.module = idx; c.src0 = hA; c.H = c.W = Ho; c.dst = h1.a;
+            conv_pack(c, {P + ".Conv_0.weight"}, {P + ".Conv_0.bias"}, cout, cin, 3, 0);
+            m.ops.push_back(c);
+            shortcut_bias = P + ".Conv_2.bias";
+        } else if (down) {
             TRef hA = alloc(cin, Ho), xr = alloc(cin, Ho);
             Op f{};
-            f.kind = OP_FIR; f.module = idx; f.src0 = x.a; f.H = f.W = H; f.coef = coef0; f.act = 1; f.up = up ? 1 : 0; f.dst = hA;
+            f.kind = OP_FIR; f.module = idx; f.src0 = x.a; f.H = f.W = H; f.coef = coef0; f.act = 1; f.up = 0; f.dst = hA;
             if (spade) { f.gb = gb0; f.coef2 = c2_0; }
             f.dst2 = xr;                 // one read of x produces both FIR(act(norm(x))) and FIR(x) (layerspp.py:600-601)
             m.ops.push_back(f);
@@ -294,6 +320,7 @@ struct Builder {
         c.coef = coef1; c.act = 1;
         if (spade) { c.gb = gb1; c.coef2 = c2_1; c.tmp = alloc(cout, Ho); }
         conv_pack(c, {P + ".Conv_1.weight"}, {P + ".Conv_1.bias"}, cout, cout, 3, 0);
+        m.packs.back().extra_bias = shortcut_bias;
         m.ops.push_back(c);
         return 0;
     }
@@ -575,12 +602,13 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             const float* w1 = blob + params[find_param("unet.all_modules.1.weight")].off;
             const float* b1 = blob + params[find_param("unet.all_modules.1.bias")].off;
             const float* emb = d.cond_emb ? blob + params[find_param("unet.all_modules.2.weight")].off : nullptr;
-            return launch_temb_mlp(lab, labels_f32, packed + freqs_off, w0, b0, w1, b1, resolve(op.dst, x, cond, out, B), B, d.ngf, T,
-                                   emb, cond_mask, s);
+            // uniform labels (and no per-row mask embedding): one row serves the batch
+            return launch_temb_mlp(lab, labels_f32, packed + freqs_off, w0, b0, w1, b1, resolve(op.dst, x, cond, out, B),
+                                   (uniform_labels && !d.cond_emb) ? 1 : B, d.ngf, T, emb, cond_mask, s);
         }
         case OP_DENSE:
             return launch_dense_all(resolve(op.src0, x, cond, out, B), packed + dense_wt, packed + dense_bias,
-                                    resolve(op.dst, x, cond, out, B), B, T, NE, s);
+                                    resolve(op.dst, x, cond, out, B), (uniform_labels && !d.cond_emb) ? 1 : B, T, NE, s);
         case OP_GN: {
             GnArgs a{};
             a.x0 = resolve(op.src0, x, cond, out, B);
@@ -592,7 +620,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.mode = op.gn_mode;
             if (op.gn_mode == 1) {
                 a.p0 = resolve(ops[1].dst, x, cond, out, B);
-                a.emb_stride = NE;
+                a.emb_stride = (uniform_labels && !d.cond_emb) ? 0 : NE;
                 a.emb_off = op.emb_off;
             } else if (op.gn_mode == 2) {
                 a.p0 = blob + op.p0;
@@ -714,8 +742,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                                      resolve(op.dst, x, cond, out, B), B, per, s);
         }
         case OP_COEF2:
-            return launch_coef2(resolve(ops[1].dst, x, cond, out, B), NE, op.emb_off, resolve(op.dst, x, cond, out, B), B,
-                                op.Cout, s);
+            return launch_coef2(resolve(ops[1].dst, x, cond, out, B), (uniform_labels && !d.cond_emb) ? 0 : NE, op.emb_off,
+                                resolve(op.dst, x, cond, out, B), B, op.Cout, s);
         case OP_APPLY:
             return launch_spade_apply(resolve(op.src0, x, cond, out, B), op.src0.C, resolve(op.src1, x, cond, out, B),
                                       op.src1.kind == REF_NONE ? 0 : op.src1.C, resolve(op.coef, x, cond, out, B),
@@ -909,7 +937,7 @@ int mcvd_model::forward(const float* x, const void* lab, const float* cond, floa
         // happens inside a capture), captured + instantiated the second time, replayed from then on.  The sampler loop
         // presents the same (x, labels, eps, cond, B) for every step of a call.
         GraphKey k;
-        k.x = x; k.lab = lab; k.cond = cond; k.out = out; k.B = B; k.labels_f32 = labels_f32; k.mask = cond_mask; k.epoch = epoch; k.ctx_epoch = ctx->epoch;
+        k.x = x; k.lab = lab; k.cond = cond; k.out = out; k.B = B; k.labels_f32 = labels_f32 | (uniform_labels << 1); k.mask = cond_mask; k.epoch = epoch; k.ctx_epoch = ctx->epoch;
         if (graph_exec && k == graph_key) {
             MCVD_HIP_CHECK(hipGraphLaunch(graph_exec, ctx->stream));
             ++graph_replays;

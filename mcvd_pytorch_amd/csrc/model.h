@@ -109,6 +109,8 @@ struct ConvPack {
     int Cout_each, Cin, ks, CinP, CoutP, nin;
     int64_t wp, bias;
     int64_t wpw = -1;
+    bool zero_bias = false;             // the packed bias stays zero (the shortcut GEMM of an up block: its bias is added elsewhere)
+    std::string extra_bias;             // a second bias parameter added into this conv's packed bias (that shortcut's)
 };
 
 }  // namespace mcvd
@@ -200,6 +202,8 @@ struct mcvd_model {
     int add_param(const std::string& name, std::initializer_list<int64_t> shape);
     int find_param(const char* name) const;
     int ensure_workspace(int B);
+    int uniform_labels = 0;        // every row of the forward in flight carries the SAME label (the sampler loops): the time MLP and
+                                   //    the Dense_0 projections are evaluated for one row and read with stride 0
     int labels_f32 = 0;            // the labels of the forward in flight are float [B] instead of int64 [B] (mcvd_unet_forward_ft)
     int forward(const float* x, const void* labels, const float* cond, float* out, int B);
     int launch_op(const mcvd::Op& op, const float* x, const void* labels, const float* cond, float* out, int B);
