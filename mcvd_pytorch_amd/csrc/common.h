@@ -67,7 +67,8 @@ struct ConvArgs {
     int B, Cin, CinP, Cout, CoutP, H, W;
     int ks;               // 1 or 3
     int cot;              // cout tile in units of 32 channels (1..4); CoutP % (32*cot) == 0
-    int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile, 3 split-K+WDB, 4 Winograd (8: with a 2-way K split), 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels per chunk)
+    int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile, 3 split-K+WDB, 4 Winograd (8: with a 2-way K split), 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels per chunk),
+                          // 9 the 1x1 GEMM with 64 pixels per wave, 10 Winograd on the bf16 pipe with split operands (11: with a 2-way K split)
     int ksplit;           // Winograd kernel only: 2 = two workgroups per tile contract half the input channels each into
                           // `part`, a second pass sums the halves; 0/1 = off
     float* part;          // ksplit == 2: scratch for the two partial results, 2 * B*Cout*H*W floats
@@ -95,6 +96,11 @@ bool conv_wino_supported(int ks, int H, int W);      // geometry only (decides w
 int conv_wino_cout_tile(int Cout);
 bool conv_wino_usable(const ConvArgs& a);            // shape id 4 applies to this launch
 int launch_conv_wino(const ConvArgs& a, hipStream_t s);
+int launch_wino_ksplit_reduce(const ConvArgs& a, hipStream_t s);      // second pass of the 2-way K split (both Winograd kernels)
+// the same convolution with the channel contraction on the bf16 matrix pipe at fp32 accuracy (three-way split of both operands,
+// six piece products; conv_wino3.cpp): tile shape ids 10 / 11 (11: 2-way K split); shares the packed weights of shape id 4
+bool conv_wino3_usable(const ConvArgs& a);
+int launch_conv_wino3(const ConvArgs& a, hipStream_t s);
 // all-DMA 1x1 GEMM (conv1x1_dma.cpp): tile shape ids 5 / 6; cot_req <= 0 picks the default cout tile
 bool conv1x1_dma_supported(const ConvArgs& a, int ck, int pxw = 1);     // ck: channels per chunk, 16 (shape id 5) or 32 (shape id 6); pxw = 2: 256-pixel tiles (shape id 9, ck 16)
 int conv1x1_dma_cout_tile(int CoutP);

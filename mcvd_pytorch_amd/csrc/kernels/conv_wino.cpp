@@ -446,7 +446,9 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
         WR_LOAD_B(7, yb)
         WR_DO_MFMA(3, yb, A1)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stray patch prefetches past the last chunk
+    // stray patch prefetches past the last chunk: pd stays reserved (an operand of this wait) until they have landed -- to the
+    // compiler the registers are dead after the loop, and anything it put there would be overwritten by the late loads
+    WR_WAIT_P(0, pd)
 
     // ---------------- inverse transform + epilogue, one 32-cout sub-tile at a time ----------------
     // The barriers below guard LDS only (s_waitcnt lgkmcnt(0) + s_barrier): the residual loads of the NEXT sub-tile are issued
@@ -649,6 +651,29 @@ static int wino_launch_exp(int e, const ConvArgs& k, dim3 grid, size_t lds, hipS
     }
 }
 
+// Second pass of the 2-way K split (conv_wino.cpp and conv_wino3.cpp): y = s * (p0 + p1 + bias + res), with the GroupNorm partials of
+// the final values where the plane size allows (one partial per (sample, channel) plane).
+int launch_wino_ksplit_reduce(const ConvArgs& a, hipStream_t s) {
+    const long n = (long)a.B * a.Cout * a.H * a.W, n4 = n / 4;
+    const int hw4 = a.H * a.W / 4;
+    if (a.stats && (hw4 == 16 || hw4 == 64)) {     // ... with the GroupNorm partials of the final values (one per plane)
+        const int blocks = (int)((n4 + 255) / 256);
+        if (hw4 == 16)
+            hipLaunchKernelGGL(wino_ksplit_reduce_stats_kernel<16>, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale,
+                               a.y, n4, n, a.Cout, a.stats);
+        else
+            hipLaunchKernelGGL(wino_ksplit_reduce_stats_kernel<64>, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale,
+                               a.y, n4, n, a.Cout, a.stats);
+        set_last_conv_stats_np(1);
+    } else {
+        const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+        hipLaunchKernelGGL(wino_ksplit_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale, a.y, n4, n,
+                           a.Cout, hw4);
+    }
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <int COT, int PRO, bool G8>
 static int wino_launch3(const ConvArgs& a, hipStream_t s) {
     constexpr int BCO = 32 * COT;
@@ -674,24 +699,8 @@ static int wino_launch3(const ConvArgs& a, hipStream_t s) {
     } else
     hipLaunchKernelGGL((conv_wino_kernel<COT, PRO, G8>), grid, dim3(WR_NT), lds, s, k);
     MCVD_HIP_CHECK(hipGetLastError());
-    if (ksp == 2) {                                    // second pass: p0 + p1 + bias + res, scaled
-        const long n = (long)a.B * a.Cout * a.H * a.W, n4 = n / 4;
-        const int hw4 = a.H * a.W / 4;
-        if (a.stats && (hw4 == 16 || hw4 == 64)) {     // ... with the GroupNorm partials of the final values (one per plane)
-            const int blocks = (int)((n4 + 255) / 256);
-            if (hw4 == 16)
-                hipLaunchKernelGGL(wino_ksplit_reduce_stats_kernel<16>, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale,
-                                   a.y, n4, n, a.Cout, a.stats);
-            else
-                hipLaunchKernelGGL(wino_ksplit_reduce_stats_kernel<64>, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale,
-                                   a.y, n4, n, a.Cout, a.stats);
-            set_last_conv_stats_np(1);
-        } else {
-            const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
-            hipLaunchKernelGGL(wino_ksplit_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale, a.y, n4, n,
-                               a.Cout, hw4);
-        }
-        MCVD_HIP_CHECK(hipGetLastError());
+    if (ksp == 2) {
+        if (int rc = launch_wino_ksplit_reduce(a, s)) return rc;
     } else if (a.stats) {
         set_last_conv_stats_np(G8 ? 1 : (a.H / 8) * (a.W / 16));
     }

@@ -841,6 +841,15 @@ int mcvd_model::autotune(int B) {
                 if (conv_wino_usable(b))
                     if (int rc = time_candidate(8, op.cot)) return rc;
             }
+            if (op.ks == 3 && ctx->winograd && ctx->bf16x3 && !spade_fused) {     // 10 / 11 = Winograd on the bf16 pipe, operands split three ways
+                ConvArgs b = a;
+                b.ksplit = 0;
+                if (conv_wino3_usable(b))
+                    if (int rc = time_candidate(10, op.cot)) return rc;
+                b.ksplit = 2;
+                if (conv_wino3_usable(b))
+                    if (int rc = time_candidate(11, op.cot)) return rc;
+            }
             if (op.ks == 1 && ctx->conv_dma1) {        // 5 / 6 = all-DMA 1x1 GEMM (16 / 32 channels per chunk), cout tiles of its own
                 // small cout tiles first: the sweep of every 1x1 layer shape (profiles/r02_conv1x1_candidates.txt) has tiles 1-3 winning
                 // everywhere; 6 / 9 never did

@@ -20,6 +20,7 @@ struct mcvd_ctx {
     int conv_shape = -1;           // -1 auto, 0/1/2 force a conv tile shape (tests)
     int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
     int conv_cot = 0;              // > 0 with conv_shape 5: cout tile (32-channel units) mcvd_op_conv2d requests (tests)
+    int bf16x3 = 1;                // offer the split-operand bf16 Winograd kernel (conv_wino3.cpp, fp32-accurate) to the autotuner
     int conv_dma1 = 1;             // offer the all-DMA 1x1 GEMM kernel (conv1x1_dma.cpp) to the autotuner
     int conv_wdma = 1;             // weight chunks by LDS-DMA (1) or register staging (0)
     int side_stream = 0;           // 1: run the ResBlock shortcut 1x1 convs on a second stream (measured -2 %: off by default)

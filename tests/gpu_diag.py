@@ -333,11 +333,72 @@ def wexp(f):
     ctx.opt("conv_shape", -1)
 
 
+def w3exp(f):
+    """conv_wino3.cpp (split-operand bf16 Winograd): kernel time and K-loop cycles per 16-channel chunk per ablation (env
+    MCVD_WINO3_EXP), next to the fp32-MFMA Winograd kernel on the same layers."""
+    from tests.hiputil import Ctx, P
+    ctx = Ctx()
+    B = 64
+    labels = {0: "baseline", 1: "no transform (WRITE_V)", 2: "no patch activation/park (WRITE_P)", 4: "no VMEM in the loop",
+              64: "no weight split", 15: "weight split + MFMA only", 79: "MFMA only", 16: "everything but the MFMAs",
+              80: "no MFMA, no weight split", 27: "VMEM + weight split only", 91: "VMEM only",
+              128: "phase order by wave parity", 132: "phase by parity, no VMEM"}
+    cases = [(96, 96, 64), (192, 192, 32), (480, 192, 32), (576, 288, 16)]
+    if os.environ.get("MCVD_WEXP_CASES", "all") != "all":
+        cases = [cases[int(v)] for v in os.environ["MCVD_WEXP_CASES"].split(",")]
+    if os.environ.get("MCVD_WEXP_ONLY"):
+        keep = [int(v) for v in os.environ["MCVD_WEXP_ONLY"].split(",")]
+        labels = {k: v for k, v in labels.items() if k in keep}
+    f.write("# bf16x3 winograd K-loop, B=64, conv_wino3_kernel<3,2>; ideal MFMA time per chunk per SIMD = 2 waves x 36 x 32 = 2304 cycles\n")
+
+    def run(shape, e):
+        ctx.opt("conv_shape", shape)
+        os.environ["MCVD_WINO3_EXP"] = str(e)
+        for _ in range(2):
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 4
+        per = []
+        for wv in (0, 7):
+            os.environ["MCVD_DBG_WAVE"] = str(wv)
+            dbg = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
+            _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
+            d = dbg.view(-1, 8).cpu().double()
+            d = d[d[:, 7] > 0]
+            m = d.mean(0)
+            per.append((m[0].item(), m[1].item() / max(m[6].item(), 1), m[5].item(), m[7].item()))
+        return us, per
+
+    for cin, cout, H in cases:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda")
+        os.environ["MCVD_DBG_WAVE"] = "0"
+        us4, _ = run(4, 0)
+        f.write(f"cin{cin} cout{cout} H{H} fp32-MFMA winograd (shape 4): kernel {us4:7.1f} us\n")
+        for e, lab in labels.items():
+            us, per = run(10, e)
+            f.write(f"cin{cin} cout{cout} H{H} exp{e:4d} {lab:36s}: kernel {us:7.1f} us | wave0 pro {per[0][0]:6.0f} loop/chunk {per[0][1]:6.0f} epi {per[0][2]:6.0f} total {per[0][3]:7.0f}"
+                    f" | wave7 pro {per[1][0]:6.0f} loop/chunk {per[1][1]:6.0f} epi {per[1][2]:6.0f} total {per[1][3]:7.0f}\n")
+            f.flush()
+    os.environ["MCVD_WINO3_EXP"] = "0"
+    ctx.opt("conv_shape", -1)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["precision", "ops", "sweep"]
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "sweep1": sweep1}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "sweep1": sweep1}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 

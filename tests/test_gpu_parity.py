@@ -66,6 +66,17 @@ CONV_CASES = [
     (3, 32, 0, 64, 8, 3, True, 1, False, 8),        # too few chunks to split: runs unsplit
     (2, 288, 0, 288, 16, 3, True, 1, True, 8),      # K split on the 16x16 288-channel layers (the ones the bench splits)
     (2, 384, 288, 288, 16, 3, True, 1, True, 8),    # ... up-path concat 672 -> 288 @16
+    (2, 96, 0, 96, 64, 3, True, 1, True, 10),       # Winograd on the bf16 pipe, operands split three ways: ResBlock Conv_1 @64 (cout tile 96)
+    (2, 10, 0, 96, 64, 3, False, 0, False, 10),     # ... stem (one ragged chunk)
+    (3, 192, 96, 192, 32, 3, True, 1, False, 10),   # ... up-path concat input
+    (3, 64, 0, 128, 16, 3, True, 1, True, 10),      # ... 64-channel cout tile
+    (2, 96, 0, 5, 64, 3, True, 1, False, 10),       # ... final conv, Cout=5 (32-channel cout tile, padded)
+    (1, 32, 0, 32, 128, 3, True, 1, True, 10),      # ... 128x128, affine without SiLU below
+    (2, 40, 0, 32, 16, 3, True, 0, False, 10),      # ... affine prologue only (PRO 1), ragged last chunk
+    (5, 48, 16, 96, 8, 3, True, 1, True, 10),       # ... 8x8 images: not served, the fp32 Winograd kernel takes the launch
+    (2, 288, 0, 288, 16, 3, True, 1, True, 11),     # ... with the 2-way K split
+    (2, 384, 288, 288, 16, 3, True, 1, True, 11),   # ... K split over a concat
+    (3, 32, 0, 64, 16, 3, True, 1, False, 11),      # ... too few chunks to split: runs unsplit
     (2, 96, 0, 192, 32, 1, False, 0, False, -1),    # 1x1 shortcut
     (2, 96, 96, 192, 32, 1, False, 0, False, 0),    # 1x1 shortcut over a concat
     (2, 192, 0, 576, 32, 1, True, 0, False, 1),     # fused q|k|v projection with GN affine prologue (no SiLU)
@@ -108,6 +119,11 @@ def _expected_kernel(case):
         return fam if Cin % (16 if fam == 5 else 32) == 0 else "direct"
     if fam == 9:
         return 9
+    if fam in (10, 11):
+        if H == 8:
+            return 4                                 # 8x8 images: the fp32 Winograd kernel takes the launch
+        chunks = -(-Cin // 16)
+        return 11 if (fam == 11 and chunks % 2 == 0 and chunks >= 4) else 10
     return None
 
 
@@ -149,6 +165,29 @@ def test_conv2d(ctx, case, naive):
     ctx.opt("conv_shape", -1)
     ctx.opt("conv_cot", 0)
     _close(got, want, what=f"conv {case}")
+
+
+@pytest.mark.parametrize("Cin,Cout,H", [(96, 96, 64), (480, 192, 32), (672, 288, 16)])
+def test_conv_bf16x3_is_fp32_accurate(ctx, Cin, Cout, H):
+    """The split-operand bf16 Winograd kernel (shape id 10) against an fp64 convolution: its error must be that of an fp32
+    computation -- no larger than 1.5x the fp32-MFMA Winograd kernel's (shape id 4) on the same data, and below 4e-6 of the output
+    scale in the worst element."""
+    g = _g(23)
+    B = 2
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = 0.1 * torch.randn(Cout, generator=g)
+    want = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    errs = {}
+    for shape in (4, 10):
+        ctx.opt("conv_shape", shape)
+        got = ctx.conv2d(x.cuda(), w.cuda(), bias.cuda())
+        from mcvd_pytorch_amd import _lib
+        assert _lib.lib.mcvd_last_conv_kernel() == shape
+        errs[shape] = ((got.cpu().double() - want).abs().max() / want.abs().max()).item()
+    ctx.opt("conv_shape", -1)
+    assert errs[10] <= max(1.5 * errs[4], 1e-6), f"bf16x3 conv error {errs[10]:.3e} vs fp32-MFMA {errs[4]:.3e}"
+    assert errs[10] < 4e-6, errs
 
 
 # ------------------------------------------------------------------------------------------------ group norm
@@ -387,14 +426,17 @@ def _net(name):
 
 @pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt", "tiny_cosine_b2.pt",
                                 "smmnist_big5_ngf96_b2.pt"])
-@pytest.mark.parametrize("naive", [0, 3], ids=["mfma", "naive"])
+@pytest.mark.parametrize("naive", [0, 3, 16, 17], ids=["mfma", "naive", "bf16x3", "bf16x3ks"])
 def test_forward_vs_reference_golden(golden_dir, fx, naive):
-    """One UNet forward vs the REAL reference's output (fixture) and, module by module, vs the oracle."""
+    """One UNet forward vs the REAL reference's output (fixture) and, module by module, vs the oracle.  bf16x3 / bf16x3ks: every 3x3
+    conv the split-operand bf16 Winograd kernel serves is forced onto it (shape ids 10 / 11), same tolerances."""
     from tests.hiputil import module_output
     g = torch.load(os.path.join(golden_dir, fx), weights_only=False)
     config, sd, net = _net(g["config_name"])
     net.set_option("naive_conv", naive & 1)
     net.set_option("naive_attn", (naive >> 1) & 1)
+    if naive >= 16:
+        net.set_option("conv_shape", 10 + (naive & 1))
     x, cond = synth.make_inputs(config, g["batch"], seed=0)
     t = g["fwd_t"]
     eps = net(x.cuda(), t.cuda(), cond=cond.cuda())
@@ -422,6 +464,23 @@ def test_forward_vs_reference_golden(golden_dir, fx, naive):
     refg = g["fwd_eps"]
     assert (eps.cpu() - refg).abs().max().item() <= 1e-4 * refg.abs().max().item()
     assert (eps.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [4, 10, 11])
+def test_forward_is_bit_deterministic(shape):
+    """300 forwards of BASELINE config 1 (B = 2) with every 3x3 conv forced onto one Winograd kernel must be bit-identical.  The
+    kernels count their own VMEM waits; a register the compiler copies (or reuses) while a load into it is still in flight shows
+    up here as a rare, timing-dependent difference (it did, once, where the two K loops of conv_wino3.cpp join: W3_DRAIN)."""
+    config, sd, net = _net("smmnist_big5")
+    net.set_option("conv_shape", shape)
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    x, cond = x.cuda(), cond.cuda()
+    t = torch.full((2,), 500, dtype=torch.long, device="cuda")
+    eps0 = net(x, t, cond=cond).clone()
+    bad = torch.zeros((), device="cuda")
+    for _ in range(300):
+        bad += (net(x, t, cond=cond) != eps0).any()
+    assert bad.item() == 0, f"{int(bad.item())} of 300 forwards differ from the first"
 
 
 @pytest.mark.parametrize("fx,key,kind,sub,extra", [

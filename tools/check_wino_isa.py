@@ -9,6 +9,10 @@ the destination registers of those loads are pending.  That is only sound if, in
   3. the loop's VMEM instructions are exactly the asm loads (COT weight loads twice per chunk + 3 patch loads, 2 for the 8x8 form)
      plus, in the SPADE-prologue instantiations (PRO 3), two LDS-DMA loads per patch load (gamma | beta), which the vmcnt counts include.
 This script compiles the file to gfx950 assembly and verifies 1-3 for every instantiation of conv_wino_kernel.
+
+conv_wino3.cpp (the split-operand bf16 form of the same convolution) counts its VMEM the same way: its K loops (two per kernel,
+one per phase order) must hold exactly 4*COT weight loads + 6 patch loads, no scratch traffic, and keep the load destinations
+untouched up to the next vmcnt wait.
 """
 import os
 import re
@@ -18,6 +22,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc", "kernels", "conv_wino.cpp")
+SRC3 = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc", "kernels", "conv_wino3.cpp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -71,16 +76,86 @@ def check(asm_text):
     return problems
 
 
+def _dest_untouched(name, loop, problems):
+    n = len(loop)
+    for i, l in enumerate(loop):
+        mm = re.match(r"^global_load_dword(?:x4)? (v\d+|v\[\d+:\d+\]),", l)
+        if not mm:
+            continue
+        dest = _regs(mm.group(1))
+        for k in range(1, n + 1):                                   # layout order, wrapping around the back edge
+            nxt = loop[(i + k) % n]
+            if re.match(r"^s_waitcnt.*vmcnt", nxt):
+                break
+            ops = nxt.split(None, 1)
+            if len(ops) > 1 and _regs(ops[1]) & dest:
+                problems.append(f"{name}: `{nxt}` touches the destination of `{l}` before any vmcnt wait")
+                break
+
+
+def check3(asm_text):
+    """conv_wino3_kernel<COT, PRO, 0>: every loop that holds MFMAs is a K loop."""
+    problems, seen = [], 0
+    for m in re.finditer(r"^(_ZN4mcvd17conv_wino3_kernelILi(\d)ELi(\d)ELi0EEEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
+        name, cot, body = m.group(1), int(m.group(2)), m.group(4)
+        seen += 1
+        lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        kloops = 0
+        i = 0
+        while i < len(lines):
+            hm = re.match(r"^\.LBB(\d+)_(\d+):.*Loop Header", lines[i])
+            if not hm:
+                i += 1
+                continue
+            tag = f"Header=BB{hm.group(1)}_{hm.group(2)} "
+            j = i + 1
+            while j < len(lines) and not (re.match(r"^\.LBB", lines[j]) and tag not in lines[j] + " "):
+                j += 1
+            loop = [l for l in lines[i:j] if not re.match(r"^\.LBB", l)]
+            i = j
+            if not any(l.startswith("v_mfma") for l in loop):
+                continue
+            kloops += 1
+            vmem = [l for l in loop if re.match(r"^(global_|buffer_|scratch_|flat_)", l)]
+            if any(l.startswith("scratch_") for l in vmem):
+                problems.append(f"{name}: spill code inside a K loop")
+            wl = [l for l in vmem if re.match(r"^global_load_dwordx4 v", l)]
+            pl = [l for l in vmem if re.match(r"^global_load_dword v", l)]
+            if len(wl) != 4 * cot or len(pl) != 6 or len(wl) + len(pl) != len(vmem):
+                problems.append(f"{name}: expected {4 * cot} weight + 6 patch loads and no other VMEM in a K loop, found {len(wl)} + {len(pl)} of {len(vmem)}")
+            _dest_untouched(name, loop, problems)
+            # leaving the loop: its loads may still be in flight; nothing may read or overwrite their destinations before vmcnt(0)
+            dests = set()
+            for l in wl + pl:
+                dests |= _regs(l.split(",")[0])
+            for t in lines[j:]:
+                if re.match(r"^\.LBB", t):
+                    continue
+                if re.match(r"^s_waitcnt.*vmcnt\(0\)", t):
+                    break
+                ops = t.split(None, 1)
+                if len(ops) > 1 and not t.startswith("s_waitcnt") and _regs(ops[1]) & dests:
+                    problems.append(f"{name}: `{t}` touches a K-loop load destination after the loop, before vmcnt(0)")
+                    break
+        if kloops != 2:
+            problems.append(f"{name}: expected 2 K loops (one per phase order), found {kloops}")
+    if seen != 9:
+        problems.append(f"expected 9 instantiations of conv_wino3_kernel<COT, PRO, 0>, found {seen}")
+    return problems
+
+
 def main():
+    problems = []
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "conv_wino.s")
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
-               SRC, "-o", out]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            print(r.stderr, file=sys.stderr)
-            return 2
-        problems = check(open(out).read())
+        for src, fn in ((SRC, check), (SRC3, check3)):
+            out = os.path.join(td, os.path.basename(src)[:-4] + ".s")
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                   src, "-o", out]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                print(r.stderr, file=sys.stderr)
+                return 2
+            problems += fn(open(out).read())
     for p in problems:
         print("conv_wino ISA check:", p, file=sys.stderr)
     if not problems:
