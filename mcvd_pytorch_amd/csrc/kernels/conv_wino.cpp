@@ -16,7 +16,7 @@
 //     lane l  ->  U_xi[co = ct*32 + (l & 31)][ci = 2*kp + (l >> 5)]
 // i.e. ONE value per lane, and no other wave ever needs it: staging U through LDS (an earlier version: 48 KiB of DMA writes
 // plus 48 KiB of operand reads per 8 channels and workgroup) buys nothing.  The weights are therefore packed per (cout tile,
-// 8-channel unit, position) as [COT][64 lanes][4] floats (pack_wino_weight_kernel) and every wave fetches its 4*COT A operands
+// 8-channel unit, position) as [COT][64 lanes][4] floats -- float4 number = cout sub-tile, component = k-pair (pack_wino_weight_kernel) -- and every wave fetches its 4*COT A operands
 // of an 8-channel unit with COT fully coalesced global_load_dwordx4 (L2-resident data), one unit ahead of its use.
 //   * LDS holds only the transformed patches V (B operand) and the activated input patch: 16 input channels per chunk
 //     (HALF the barriers of the 8-channel predecessor) in 96 KiB.
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     const float* wr_base = a.wpw + (((long)cotile * nunits * 16 + wave_u) * COT) * 256;
     const unsigned wr_voff = (unsigned)lane * 16u;
 
-    /* A operands of weight unit `u` -> register set S (COT float4 = 4*COT operands, index kp*COT + ct); asm: see header */
+    /* A operands of weight unit `u` -> register set S (COT float4: S[ct][kp] = operand of cout sub-tile ct, k-pair kp); asm: see header */
 #define WR_LOAD_A(u, S)                                                                                         \
     {                                                                                                           \
         const float* ub = wr_base + (long)(u) * (16 * COT * 256);                                               \
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
     /* MFMA group: k-pair kp (0..3) of the weight unit held in register set S */
 #define WR_DO_MFMA(kp, BV, S)                                                                                   \
     _Pragma("unroll") for (int ct = 0; ct < COT; ++ct)                                                          \
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(S[((kp) * COT + ct) >> 2][((kp) * COT + ct) & 3], BV, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(S[ct][kp], BV, acc[ct], 0, 0, 0);
 
     f32x16 acc[COT];
 #pragma unroll
@@ -755,7 +755,7 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
 }
 
 // U = G g G^T per (cout, cin), stored operand-major:
-//   up[((((cotile*nunits + ci/8)*16 + xi)*COT + idx/4)*64 + lane)*4 + idx%4],   idx = ((ci%8)/2)*COT + (co%BCO)/32,
+//   up[((((cotile*nunits + ci/8)*16 + xi)*COT + ct)*64 + lane)*4 + kp],   ct = (co%BCO)/32, kp = (ci%8)/2,
 //   lane = (ci%2)*32 + co%32.   The buffer (CinP*16*CoutP floats) must be zero-filled: padded channels stay zero.
 __global__ void pack_wino_weight_kernel(const float* w, float* up, int Cout, int Cin, int CinP, int CoutP, int COT) {
     const long n = (long)Cout * Cin;
@@ -772,7 +772,7 @@ __global__ void pack_wino_weight_kernel(const float* w, float* up, int Cout, int
             t[3][j] = g[2 * 3 + j];
         }
         const int cotile = co / BCO, ct = (co % BCO) / 32, lane = (ci & 1) * 32 + (co & 31);
-        const int idx = ((ci & 7) >> 1) * COT + ct;
+        const int idx = ct * 4 + ((ci & 7) >> 1);             // float4 number = cout sub-tile, component = k-pair
         const long base = ((((long)cotile * nunits + (ci >> 3)) * 16) * COT + (idx >> 2)) * 256 + lane * 4 + (idx & 3);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                           // (.) G^T

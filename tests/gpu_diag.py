@@ -342,7 +342,7 @@ def w3exp(f):
     labels = {0: "baseline", 1: "no transform (WRITE_V)", 2: "no patch activation/park (WRITE_P)", 4: "no VMEM in the loop",
               64: "no weight split", 15: "weight split + MFMA only", 79: "MFMA only", 16: "everything but the MFMAs",
               80: "no MFMA, no weight split", 27: "VMEM + weight split only", 91: "VMEM only",
-              128: "phase order by wave parity", 132: "phase by parity, no VMEM"}
+              128: "phase order by wave parity", 256: "no patch loads", 512: "no weight loads"}
     cases = [(96, 96, 64), (192, 192, 32), (480, 192, 32), (576, 288, 16)]
     if os.environ.get("MCVD_WEXP_CASES", "all") != "all":
         cases = [cases[int(v)] for v in os.environ["MCVD_WEXP_CASES"].split(",")]
@@ -394,11 +394,48 @@ def w3exp(f):
     ctx.opt("conv_shape", -1)
 
 
+def convops(f):
+    """Per-op times of the 3x3 convs of one instrumented forward (BASELINE config 2, B = 64): kernel the autotuner chose and ms,
+    with the split-operand bf16 Winograd kernel offered (MCVD_BF16X3 unset) -- run again with MCVD_BF16X3=0 for the fp32 table."""
+    import ctypes as C
+    from oracle import synth
+    from mcvd_pytorch_amd.scorenet import HipScoreNet
+    B = int(os.environ.get("B", 64))
+    config = synth.make_config(os.environ.get("CFG", "smmnist_big5_ngf96")); config.device = "cuda:0"
+    sd = synth.make_state_dict(config, seed=123)
+    net = HipScoreNet(config); net.load_state_dict({"module." + k: v for k, v in sd.items()}, strict=False); net.eval()
+    x, cond = synth.make_inputs(config, B, seed=0)
+    x, cond = x.cuda(), cond.cuda()
+    t = torch.full((B,), 500, dtype=torch.long, device="cuda")
+    for _ in range(3):
+        net(x, t, cond=cond)
+    net.set_option("profile", 1)
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    ddpm_sampler(x, net, cond=cond, denoise=True, subsample_steps=2, clip_before=True, verbose=False, log=False, config=config, final_only=True)
+    torch.cuda.synchronize()
+    n = _lib.lib.mcvd_model_profile_read(net._model, None, None, None, None, None, 0)
+    kinds, kss = (C.c_int * n)(), (C.c_int * n)()
+    ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    _lib.lib.mcvd_model_profile_read(net._model, kinds, kss, ms, fl, by, n)
+    info = (C.c_int * 8)()
+    tot = {}
+    for i in range(n):
+        if kinds[i] != 3 or ms[i] == 0.0:
+            continue
+        _lib.lib.mcvd_model_op_info(net._model, i, info)
+        shape = (info[6] >> 4) & 15 if (info[6] >> 12) else -1
+        key = (kss[i], shape)
+        tot[key] = tot.get(key, 0.0) + ms[i]
+        if kss[i] == 3:
+            f.write(f"op {i:3d} 3x3 H{info[3]:3d} cin{info[4]:4d} cout{info[5]:4d} shape {shape:2d} cot {(info[6] >> 8) & 15}: {ms[i] * 1e3:7.1f} us  {fl[i] / ms[i] / 1e9:6.1f} TF/s\n")
+    f.write("totals (ks, shape) -> ms: " + ", ".join(f"{k}: {v:.3f}" for k, v in sorted(tot.items())) + "\n")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["precision", "ops", "sweep"]
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "sweep1": sweep1}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "convops": convops, "sweep1": sweep1}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 

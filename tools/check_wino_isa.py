@@ -93,6 +93,34 @@ def _dest_untouched(name, loop, problems):
                 break
 
 
+def _dest_untouched_covering(name, loop, problems):
+    """Stricter form for loops with several wait points: a load's destination stays untouched until a vmcnt(N) wait with N <= the
+    number of loads issued after it (in-order return: only then has it landed), following the back edge."""
+    n = len(loop)
+    for i, l in enumerate(loop):
+        mm = re.match(r"^global_load_dword(?:x4)? (v\d+|v\[\d+:\d+\]),", l)
+        if not mm:
+            continue
+        dest = _regs(mm.group(1))
+        younger = 0
+        for k in range(1, 2 * n + 1):
+            nxt = loop[(i + k) % n]
+            if nxt.startswith("global_load"):
+                younger += 1
+                continue
+            wm = re.match(r"^s_waitcnt.*vmcnt\((\d+)\)", nxt)
+            if wm:
+                if int(wm.group(1)) <= younger:
+                    break
+                continue
+            ops = nxt.split(None, 1)
+            if len(ops) > 1 and _regs(ops[1]) & dest:
+                problems.append(f"{name}: `{nxt}` touches the destination of `{l}` before a wait that covers it")
+                break
+        else:
+            problems.append(f"{name}: no wait covers `{l}`")
+
+
 def check3(asm_text):
     """conv_wino3_kernel<COT, PRO, 0>: every loop that holds MFMAs is a K loop."""
     problems, seen = [], 0
@@ -112,24 +140,47 @@ def check3(asm_text):
             while j < len(lines) and not (re.match(r"^\.LBB", lines[j]) and tag not in lines[j] + " "):
                 j += 1
             loop = [l for l in lines[i:j] if not re.match(r"^\.LBB", l)]
-            i = j
+            i0, i = i, j
             if not any(l.startswith("v_mfma") for l in loop):
                 continue
             kloops += 1
             vmem = [l for l in loop if re.match(r"^(global_|buffer_|scratch_|flat_)", l)]
             if any(l.startswith("scratch_") for l in vmem):
                 problems.append(f"{name}: spill code inside a K loop")
+            if any(re.match(r"^s_waitcnt.*vmcnt\(0\)", l) for l in loop):
+                problems.append(f"{name}: a vmcnt(0) wait inside a K loop (the loop's loads are meant to stay in flight)")
             wl = [l for l in vmem if re.match(r"^global_load_dwordx4 v", l)]
             pl = [l for l in vmem if re.match(r"^global_load_dword v", l)]
             if len(wl) != 4 * cot or len(pl) != 6 or len(wl) + len(pl) != len(vmem):
                 problems.append(f"{name}: expected {4 * cot} weight + 6 patch loads and no other VMEM in a K loop, found {len(wl)} + {len(pl)} of {len(vmem)}")
-            _dest_untouched(name, loop, problems)
+            _dest_untouched_covering(name, loop, problems)
             # leaving the loop: its loads may still be in flight; nothing may read or overwrite their destinations before vmcnt(0)
             dests = set()
             for l in wl + pl:
                 dests |= _regs(l.split(",")[0])
-            for t in lines[j:]:
+            # the exit edge: the last conditional branch of the loop that leaves it (else the code laid out behind the loop)
+            inside = {re.match(r"^(\.LBB\d+_\d+):", l).group(1) for l in lines[i0:j] if re.match(r"^\.LBB\d+_\d+:", l)}
+            start = j
+            for l in reversed(lines[i0:j]):
+                bm = re.match(r"^s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+                if bm and bm.group(1) not in inside:
+                    tgt = [k for k, t in enumerate(lines) if t.startswith(bm.group(1) + ":")]
+                    if tgt:
+                        start = tgt[0]
+                    break
+            pos, steps = start, 0
+            while pos < len(lines) and steps < 4000:          # follow the fall-through path and unconditional branches
+                t = lines[pos]
+                pos += 1
+                steps += 1
                 if re.match(r"^\.LBB", t):
+                    continue
+                bm = re.match(r"^s_(?:branch|cbranch_execnz) (\.LBB\d+_\d+)", t)      # (EXEC is never zero in this kernel)
+                if bm:
+                    tgt = [k for k, u in enumerate(lines) if u.startswith(bm.group(1) + ":")]
+                    if not tgt:
+                        break
+                    pos = tgt[0]
                     continue
                 if re.match(r"^s_waitcnt.*vmcnt\(0\)", t):
                     break
