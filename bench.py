@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: v_mfma_f32_32x32x16_bf16 / _f16 dense peak (no sparsity)
 HBM_PEAK_GBS = 8000.0
 
 # per-config defaults: (per-GPU batch, subsample, metric label) -- BASELINE.json configs[1..4] at their per-GPU batch
@@ -156,6 +157,7 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MCVD_GRAPH", "1")), help="hipGraph replay of the forwards")
     ap.add_argument("--tune-cache", default=None, help="JSON file: load the kernel-selection table if it exists, else save it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--f16x2", type=int, default=None, help="0: keep every 3x3 conv product at fp32 accuracy (do not offer the two-piece fp16 kernel)")
     args = ap.parse_args()
 
     cmd = plan_launch(args.gpus, os.environ)
@@ -201,6 +203,8 @@ def main():
     broadcast_weights(net, src=0)                    # ONE RCCL broadcast of the packed blob (no-op at N=1)
     net.set_option("profile", 1)
     net.set_option("graph", args.graph)
+    if args.f16x2 is not None:
+        net.set_option("f16x2", args.f16x2)
     tuned_from_cache = False
     if args.tune_cache and os.path.exists(args.tune_cache):
         net.load_tuning(args.tune_cache)
@@ -270,19 +274,29 @@ def main():
     # ---- dominant kernel: the 3x3 convs.  Which implementation each layer runs is the autotuner's choice (op_info):
     # shape 4 / 8 = Winograd F(2x2,3x3) (conv_wino_kernel; 8: + its K-split reduce pass), else the direct implicit GEMM.
     info = (C.c_int * 8)()
-    wino = dict(launches=0, ms=0.0, flops=0.0, bytes=0.0)
+    fam = {k: dict(launches=0, ms=0.0, flops=0.0, bytes=0.0) for k in ("wino_f32", "wino_bf16x3", "wino_f16x2", "direct")}
     for i in range(n):
         if kinds[i] != 3 or kss[i] != 3 or ms[i] == 0.0:
             continue
         _lib.check(_lib.lib.mcvd_model_op_info(net._model, i, info), "op_info")
-        if (info[6] >> 12) and ((info[6] >> 4) & 15) in (4, 8):         # 8 = the same kernel with the 2-way K split
-            wino["launches"] += 1; wino["ms"] += ms[i]; wino["flops"] += fl[i]; wino["bytes"] += by[i]
+        shape = ((info[6] >> 4) & 15) if (info[6] >> 12) else -1
+        f = fam["wino_f32" if shape in (4, 8) else "wino_bf16x3" if shape in (10, 11) else "wino_f16x2" if shape in (12, 13) else "direct"]   # 8 / 11 / 13: + the K-split reduce pass
+        f["launches"] += 1; f["ms"] += ms[i]; f["flops"] += fl[i]; f["bytes"] += by[i]
     c3 = agg["conv3x3"]
-    dom, dom_name = c3, "conv_mfma_kernel<3x3> (direct implicit GEMM, v_mfma_f32_32x32x2_f32)"
-    mult_ratio = 1.0
-    if wino["ms"] > 0.5 * c3["ms"]:
-        dom, dom_name = wino, "conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)"
-        mult_ratio = 16.0 / 36.0          # multiplies executed per output tile: 16 (Winograd) vs 36 (direct form)
+    dom_key = max(fam, key=lambda k: fam[k]["ms"])
+    dom = fam[dom_key]
+    # (kernel name, matrix-pipe flops executed per direct-form flop, peak of the pipe it runs on, arithmetic)
+    #   fp32 Winograd F(2x2,3x3): 16 of the direct form's 36 multiplies per output tile, on the fp32 MFMA
+    #   bf16x3 Winograd: the same 16/36, each product as SIX bf16 piece products (exact three-way operand split, fp32 accumulate)
+    FAMILY = {
+        "wino_f32": ("conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", 16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS),
+        "wino_bf16x3": ("conv_wino3_kernel (3x3 conv, Winograd F(2x2,3x3), operands split exactly into 3 bf16 pieces, 6 piece "
+                        "products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)", 6.0 * 16.0 / 36.0, BF16_MFMA_PEAK_TFLOPS),
+        "wino_f16x2": ("conv_wino2h_kernel (3x3 conv, Winograd F(2x2,3x3), operands split into 2 fp16 pieces = 22 significant bits, weights "
+                       "pre-split at pack time, 3 piece products on v_mfma_f32_32x32x16_f16, fp32 accumulate)", 3.0 * 16.0 / 36.0, BF16_MFMA_PEAK_TFLOPS),
+        "direct": ("conv_mfma_kernel<3x3> (direct implicit GEMM, v_mfma_f32_32x32x2_f32)", 1.0, FP32_MFMA_PEAK_TFLOPS),
+    }
+    dom_name, mult_ratio, pipe_peak = FAMILY[dom_key]
     algorithmic = dom["flops"] / dom["ms"] / 1e9
     executed = algorithmic * mult_ratio
     traffic, traffic_src = None, None     # HBM-side bytes per launch from the committed PMC passes over the SAME launch population
@@ -290,24 +304,36 @@ def main():
         tr = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("conv_wino_traffic.json"))
         if tr and args.config == "smmnist_big5_ngf96" and B == 64:
             tj = json.load(open(os.path.join(ROOT, "profiles", tr[-1])))
-            traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/" + tr[-1]
+            if tj.get("family", "wino_f32") == dom_key:
+                traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/" + tr[-1]
     except Exception:
         traffic = None
     roofline = dict(bound="mfma", kernel=dom_name,
-                    achieved=round(executed, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(executed / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
-                    note=("achieved / frac = flops the kernel EXECUTES on the fp32 matrix pipe (Winograd F(2x2,3x3): 16/36 of the "
-                          "direct-form multiplies) / HIP-event time of its launches in one forward of the timed region / MFMA peak, "
-                          "i.e. the matrix-pipe utilisation (agrees with PMC SQ_VALU_MFMA_BUSY_CYCLES, profiles/); "
-                          "algorithmic_* applies the contract's direct-form count 2*B*HW*Cout*Cin*9 and may exceed 1"),
+                    achieved=round(executed, 2), peak=pipe_peak, unit="TFLOP/s",
+                    frac=round(executed / pipe_peak, 4), traffic=traffic, traffic_source=traffic_src,
+                    note=("achieved / frac = flops the kernel EXECUTES on its matrix pipe (Winograd F(2x2,3x3): 16/36 of the "
+                          "direct-form multiplies; the bf16x3 kernel issues six bf16 piece products per fp32 product) / HIP-event time "
+                          "of its launches in one forward of the timed region / that pipe's dense peak, i.e. the matrix-pipe "
+                          "utilisation (agrees with PMC SQ_VALU_MFMA_BUSY_CYCLES, profiles/); algorithmic_* applies the contract's "
+                          "direct-form count 2*B*HW*Cout*Cin*9 against the FP32 matrix peak (the precision the path delivers) and may exceed 1"),
                     algorithmic_achieved=round(algorithmic, 2), algorithmic_frac=round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
                     algorithmic_bytes_per_launch=round(dom["bytes"] / dom["launches"]),
                     launches=dom["launches"], avg_launch_us=round(1e3 * dom["ms"] / dom["launches"], 1),
                     flops_per_launch_avg=dom["flops"] / dom["launches"],
+                    conv3x3_families={k: dict(launches=v["launches"], ms=round(v["ms"], 3),
+                                              algorithmic_tflops=round(v["flops"] / v["ms"] / 1e9, 2) if v["ms"] else None)
+                                      for k, v in fam.items()},
                     all_conv3x3=dict(launches=c3["launches"], ms=round(c3["ms"], 3), tflops=round(c3["flops"] / c3["ms"] / 1e9, 2)),
                     forward_ms_events=round(fwd_ms, 3),
                     forward_ms_events_note="sum of per-op event intervals of ONE instrumented forward: upper bound (event gaps, ~3 %)",
                     breakdown=breakdown)
+    arith = "f32"
+    if fam["wino_f16x2"]["launches"]:
+        arith = ("f32 storage and accumulation; %d of %d 3x3 convs multiply operands rounded to two fp16 pieces (22 significant bits, 3 piece "
+                 "products, fp32 accumulate; parity fixtures hold at the fp32 tolerances, error vs fp64 measured next to the fp32-MFMA kernel in "
+                 "tests/test_gpu_parity.py::test_conv_f16x2_accuracy); everything else f32 MFMA / f32 VALU" % (fam["wino_f16x2"]["launches"], c3["launches"]))
+    elif fam["wino_bf16x3"]["launches"]:
+        arith = "f32 (3x3 convs: exact bf16x3 operand split, 6 piece products, f32 accumulate; everything else f32 MFMA / f32 VALU)"
 
     if rank == 0:
         cap, rep = C.c_int64(), C.c_int64()
@@ -316,7 +342,7 @@ def main():
         res = dict(metric=f"sampled frames/sec (whole node), {label}", value=round(value, 3),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(1e3 * dt / args.steps, 2), higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype="f32", data="synthetic",
+                   dtype=arith, data="synthetic",
                    config=dict(workload=f"{args.config}: " + (f"video_gen, {n_blocks} autoregressive blocks of " if autoreg else "")
                                + f"ddpm_sampler subsample={subsample} (+1 denoise forward), "
                                f"{config.data.image_size}x{config.data.image_size}, {config.data.num_frames_cond} cond + {nfr} pred frames"

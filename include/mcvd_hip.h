@@ -88,8 +88,11 @@ void mcvd_ctx_destroy(mcvd_ctx* ctx);
 int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
 /* options: "naive_conv", "naive_attn" (0/1: route through the simple one-thread-per-output HIP kernels, used by the
  * tests to triangulate), "conv_shape" (-1 auto; 0/1/2/3 force the 256/128/64-pixel / split-K conv tile, 4 the Winograd F(2x2,3x3) kernel where
- * it applies (8: with its 2-way split of the input channels), 5 / 6 the all-DMA 1x1 GEMM kernel (16 / 32 channels per chunk) where it applies), "winograd" / "conv_dma1" (1: offer the Winograd / all-DMA 1x1
- * kernel to the autotuner), "conv_cot" (with conv_shape 5: cout tile, in 32-channel units, that mcvd_op_conv2d requests), "conv_wdma" (1: weight
+ * it applies (8: with its 2-way split of the input channels), 5 / 6 the all-DMA 1x1 GEMM kernel (16 / 32 channels per chunk) where it applies,
+ * 10 / 11 the Winograd kernel on the bf16 matrix pipe with three-piece operands (fp32-accurate), 12 / 13 on the fp16 matrix pipe with two-piece
+ * operands (22-bit operands, fp32 accumulate)), "winograd" / "conv_dma1" (1: offer the Winograd / all-DMA 1x1
+ * kernel to the autotuner), "bf16x3" / "f16x2" (1: offer the bf16-pipe / fp16-pipe forms of the Winograd kernel to the autotuner; "f16x2" = 0 keeps every
+ * product of the 3x3 convs at fp32 accuracy), "conv_cot" (with conv_shape 5: cout tile, in 32-channel units, that mcvd_op_conv2d requests), "conv_wdma" (1: weight
  * chunks by LDS-DMA, 0: register staging), "autotune" (1: time the conv tile candidates per layer shape on first use of a batch
  * size and keep the fastest), "side_stream" (1: ResBlock shortcut convs run on a second HIP stream concurrently with Conv_0; default 0, it measured slower), "profile" (0/1, see
  * mcvd_model_profile_read), "spade_fuse" (1: the SPADE modulation of a norm is applied inside the Winograd conv loader -- gamma | beta by LDS-DMA -- where that

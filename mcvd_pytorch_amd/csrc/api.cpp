@@ -47,6 +47,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     if (const char* t = getenv("MCVD_WINOGRAD")) c->winograd = atoi(t);
     if (const char* t = getenv("MCVD_CONV_DMA1")) c->conv_dma1 = atoi(t);
     if (const char* t = getenv("MCVD_BF16X3")) c->bf16x3 = atoi(t);
+    if (const char* t = getenv("MCVD_F16X2")) c->f16x2 = atoi(t);
     if (const char* t = getenv("MCVD_GRAPH")) c->graph = atoi(t);
     if (const char* t = getenv("MCVD_GN_STATS")) c->gn_stats = atoi(t);
     if (const char* t = getenv("MCVD_SPADE_FUSE")) c->spade_fuse = atoi(t);
@@ -110,6 +111,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "winograd")) ctx->winograd = value;
     else if (!strcmp(key, "conv_dma1")) ctx->conv_dma1 = value;
     else if (!strcmp(key, "bf16x3")) ctx->bf16x3 = value;
+    else if (!strcmp(key, "f16x2")) ctx->f16x2 = value;
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
     else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
     else if (!strcmp(key, "spade_fuse")) ctx->spade_fuse = value;
@@ -283,6 +285,8 @@ int mcvd_model_finalize(mcvd_model* m) {
             }
             if (p.wpw >= 0)
                 if (int rc = launch_pack_wino_weight(m->blob + w.off, m->packed + p.wpw, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
+            if (p.wph >= 0)
+                if (int rc = launch_pack_wino2h_weight(m->blob + w.off, m->packed + p.wph, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
         }
     }
     for (const DenseEntry& e : m->dense) {
@@ -415,7 +419,7 @@ int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* co
     MCVD_REQUIRE(n == (int)m->ops.size(), "set_tuning: %d entries for a plan of %d ops (tuning of another model?)", n, (int)m->ops.size());
     for (int i = 0; i < n; ++i) {
         const bool conv = m->ops[i].kind == OP_CONV;
-        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 11 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
+        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 13 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
                      "set_tuning: entry %d (shape %d, cout tile %d) does not fit op kind %d", i, shapes[i], cots[i], (int)m->ops[i].kind);
     }
     m->tuned_cache[B] = {std::vector<int>(shapes, shapes + n), std::vector<int>(cots, cots + n)};
@@ -760,16 +764,22 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.CinP = round_up(a.Cin, conv_chunk(ks));
     a.CoutP = round_up(Cout, 32 * a.cot);
     const size_t wfloats = (size_t)a.CinP * ks * ks * a.CoutP;
-    const bool wino = (ctx->conv_shape == 4 || ctx->conv_shape == 8 || ctx->conv_shape == 10 || ctx->conv_shape == 11) &&
+    const bool wino = (ctx->conv_shape == 4 || ctx->conv_shape == 8 || (ctx->conv_shape >= 10 && ctx->conv_shape <= 13)) &&
                       conv_wino_supported(ks, H, W);
+    const bool wino_h = wino && (ctx->conv_shape == 12 || ctx->conv_shape == 13) && !(H == 8 && W == 8);     // fp16 pieces as well
     const size_t ufloats = wino ? (size_t)a.CinP * 16 * a.CoutP : 0;
-    const size_t pfloats = (wino && (ctx->conv_shape == 8 || ctx->conv_shape == 11)) ? (size_t)2 * B * Cout * H * W : 0;     // K-split partial results
-    if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats + pfloats) * sizeof(float))) return rc;
-    MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP + ufloats) * sizeof(float), ctx->stream));
+    const size_t hfloats = wino_h ? (size_t)((conv_wino2h_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4) : 0;
+    const size_t pfloats = (wino && (ctx->conv_shape == 8 || ctx->conv_shape == 11 || ctx->conv_shape == 13)) ? (size_t)2 * B * Cout * H * W : 0;     // K-split partial results
+    if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats + hfloats + pfloats) * sizeof(float))) return rc;
+    MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP + ufloats + hfloats) * sizeof(float), ctx->stream));
     if (wino) {
         if (int rc = launch_pack_wino_weight(w, ctx->scratch + wfloats + a.CoutP, Cout, a.Cin, a.CinP, a.CoutP, ctx->stream)) return rc;
         a.wpw = ctx->scratch + wfloats + a.CoutP;
-        if (pfloats) a.part = ctx->scratch + wfloats + a.CoutP + ufloats;
+        if (wino_h) {
+            if (int rc = launch_pack_wino2h_weight(w, ctx->scratch + wfloats + a.CoutP + ufloats, Cout, a.Cin, a.CinP, a.CoutP, ctx->stream)) return rc;
+            a.wph = ctx->scratch + wfloats + a.CoutP + ufloats;
+        }
+        if (pfloats) a.part = ctx->scratch + wfloats + a.CoutP + ufloats + hfloats;
     }
     if (int rc = launch_pack_conv_weight(w, ctx->scratch, Cout, a.Cin, ks, a.CinP, a.CoutP, 0, 0, ctx->stream)) return rc;
     MCVD_HIP_CHECK(hipMemcpyAsync(ctx->scratch + wfloats, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));

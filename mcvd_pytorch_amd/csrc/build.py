@@ -52,7 +52,7 @@ def build(force=False, jobs=None, verbose=True):
             objs.append(obj)
             if log is not None:
                 rebuilt += 1
-                wino_rebuilt |= os.path.basename(obj) in ("conv_wino.o", "conv_wino3.o")
+                wino_rebuilt |= os.path.basename(obj) in ("conv_wino.o", "conv_wino3.o", "conv_wino2h.o")
                 if log and verbose:
                     print(log, file=sys.stderr)
     if wino_rebuilt:

@@ -60,6 +60,7 @@ struct ConvArgs {
     int act;              // SiLU after the affine
     const float* wp;      // packed weights
     const float* wpw;     // Winograd-transformed weights, operand-major (conv_wino.cpp: pack_wino_weight_kernel; 3x3 only), or null
+    const float* wph;     // the same weights pre-split into two fp16 pieces + header (conv_wino2h.cpp: launch_pack_wino2h_weight), or null
     const float* bias;    // [Cout]
     const float* res;     // residual [B][Cout][H][W] or null
     float out_scale;
@@ -68,7 +69,8 @@ struct ConvArgs {
     int ks;               // 1 or 3
     int cot;              // cout tile in units of 32 channels (1..4); CoutP % (32*cot) == 0
     int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile, 3 split-K+WDB, 4 Winograd (8: with a 2-way K split), 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels per chunk),
-                          // 9 the 1x1 GEMM with 64 pixels per wave, 10 Winograd on the bf16 pipe with split operands (11: with a 2-way K split)
+                          // 9 the 1x1 GEMM with 64 pixels per wave, 10 Winograd on the bf16 pipe with split operands (11: with a 2-way K split),
+                          // 12 Winograd on the fp16 pipe with two-piece operands (13: with a 2-way K split)
     int ksplit;           // Winograd kernel only: 2 = two workgroups per tile contract half the input channels each into
                           // `part`, a second pass sums the halves; 0/1 = off
     float* part;          // ksplit == 2: scratch for the two partial results, 2 * B*Cout*H*W floats
@@ -101,6 +103,12 @@ int launch_wino_ksplit_reduce(const ConvArgs& a, hipStream_t s);      // second 
 // six piece products; conv_wino3.cpp): tile shape ids 10 / 11 (11: 2-way K split); shares the packed weights of shape id 4
 bool conv_wino3_usable(const ConvArgs& a);
 int launch_conv_wino3(const ConvArgs& a, hipStream_t s);
+// the same convolution on the fp16 matrix pipe, operands split into two fp16 pieces (22-bit operands, three piece products; weights
+// pre-split at pack time; conv_wino2h.cpp): tile shape ids 12 / 13 (13: 2-way K split); needs ConvArgs::wph
+bool conv_wino2h_usable(const ConvArgs& a);
+int launch_conv_wino2h(const ConvArgs& a, hipStream_t s);
+long conv_wino2h_weight_floats(int CinP, int CoutP);          // size of the wph buffer (header + pieces), in floats
+int launch_pack_wino2h_weight(const float* w, float* wh, int Cout, int Cin, int CinP, int CoutP, hipStream_t s);   // wh zero-filled
 // all-DMA 1x1 GEMM (conv1x1_dma.cpp): tile shape ids 5 / 6; cot_req <= 0 picks the default cout tile
 bool conv1x1_dma_supported(const ConvArgs& a, int ck, int pxw = 1);     // ck: channels per chunk, 16 (shape id 5) or 32 (shape id 6); pxw = 2: 256-pixel tiles (shape id 9, ck 16)
 int conv1x1_dma_cout_tile(int CoutP);

@@ -171,7 +171,10 @@ struct Builder {
         p.bias = alloc_packed(p.CoutP);
         if (wnames.size() == 1 && !nin && conv_wino_supported(ks, op.H, op.W))
             p.wpw = alloc_packed((int64_t)p.CinP * 16 * p.CoutP);
+        if (p.wpw >= 0 && !(op.H == 8 && op.W == 8))          // the fp16-piece form serves the 8x16-pixel regions only
+            p.wph = alloc_packed(conv_wino2h_weight_floats(p.CinP, p.CoutP));
         op.wpw = p.wpw;
+        op.wph = p.wph;
         m.packs.push_back(p);
         op.ks = ks;
         op.Cout = Cout;
@@ -648,6 +651,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.act = op.act;
             a.wp = packed + op.wp;
             a.wpw = op.wpw >= 0 ? packed + op.wpw : nullptr;
+            a.wph = op.wph >= 0 ? packed + op.wph : nullptr;
             a.bias = packed + op.bias;
             a.res = op.res.kind == REF_NONE ? nullptr : resolve(op.res, x, cond, out, B);
             a.out_scale = op.out_scale;
@@ -791,6 +795,7 @@ int mcvd_model::autotune(int B) {
             a.act = op.act;
             a.wp = packed + op.wp;
             a.wpw = op.wpw >= 0 ? packed + op.wpw : nullptr;
+            a.wph = op.wph >= 0 ? packed + op.wph : nullptr;
             a.bias = packed + op.bias;
             a.res = op.res.kind == REF_NONE ? nullptr : resolve(op.res, scratch_io, scratch_io, scratch_io, B);
             a.out_scale = op.out_scale;
@@ -849,6 +854,15 @@ int mcvd_model::autotune(int B) {
                 b.ksplit = 2;
                 if (conv_wino3_usable(b))
                     if (int rc = time_candidate(11, op.cot)) return rc;
+            }
+            if (op.ks == 3 && ctx->winograd && ctx->f16x2 && !spade_fused) {      // 12 / 13 = Winograd on the fp16 pipe, two-piece operands
+                ConvArgs b = a;
+                b.ksplit = 0;
+                if (conv_wino2h_usable(b))
+                    if (int rc = time_candidate(12, op.cot)) return rc;
+                b.ksplit = 2;
+                if (conv_wino2h_usable(b))
+                    if (int rc = time_candidate(13, op.cot)) return rc;
             }
             if (op.ks == 1 && ctx->conv_dma1) {        // 5 / 6 = all-DMA 1x1 GEMM (16 / 32 channels per chunk), cout tiles of its own
                 // small cout tiles first: the sweep of every 1x1 layer shape (profiles/r02_conv1x1_candidates.txt) has tiles 1-3 winning

@@ -21,6 +21,7 @@ struct mcvd_ctx {
     int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
     int conv_cot = 0;              // > 0 with conv_shape 5: cout tile (32-channel units) mcvd_op_conv2d requests (tests)
     int bf16x3 = 1;                // offer the split-operand bf16 Winograd kernel (conv_wino3.cpp, fp32-accurate) to the autotuner
+    int f16x2 = 1;                 // offer the two-piece fp16 Winograd kernel (conv_wino2h.cpp: 22-bit operands, fp32 accumulate) to the autotuner
     int conv_dma1 = 1;             // offer the all-DMA 1x1 GEMM kernel (conv1x1_dma.cpp) to the autotuner
     int conv_wdma = 1;             // weight chunks by LDS-DMA (1) or register staging (0)
     int side_stream = 0;           // 1: run the ResBlock shortcut 1x1 convs on a second stream (measured -2 %: off by default)
@@ -78,6 +79,7 @@ struct Op {
     // conv
     int64_t wp = -1, bias = -1;    // packed blob offsets
     int64_t wpw = -1;              // Winograd-transformed weights (3x3 convs at supported resolutions), else -1
+    int64_t wph = -1;              // the same, pre-split into two fp16 pieces (conv_wino2h.cpp), else -1
     int CinP = 0, CoutP = 0, cot = 0;
     float out_scale = 1.f;
     // fir
@@ -110,6 +112,7 @@ struct ConvPack {
     int Cout_each, Cin, ks, CinP, CoutP, nin;
     int64_t wp, bias;
     int64_t wpw = -1;
+    int64_t wph = -1;
     bool zero_bias = false;             // the packed bias stays zero (the shortcut GEMM of an up block: its bias is added elsewhere)
     std::string extra_bias;             // a second bias parameter added into this conv's packed bias (that shortcut's)
 };

@@ -339,21 +339,30 @@ def w3exp(f):
     from tests.hiputil import Ctx, P
     ctx = Ctx()
     B = 64
-    labels = {0: "baseline", 1: "no transform (WRITE_V)", 2: "no patch activation/park (WRITE_P)", 4: "no VMEM in the loop",
-              64: "no weight split", 15: "weight split + MFMA only", 79: "MFMA only", 16: "everything but the MFMAs",
-              80: "no MFMA, no weight split", 27: "VMEM + weight split only", 91: "VMEM only",
-              128: "phase order by wave parity", 256: "no patch loads", 512: "no weight loads"}
+    kshape = int(os.environ.get("MCVD_WEXP_SHAPE", "10"))         # 10: conv_wino3.cpp (bf16x3), 12: conv_wino2h.cpp (f16x2)
+    envname = "MCVD_WINO3_EXP" if kshape == 10 else "MCVD_WINO2H_EXP"
+    if kshape == 10:
+        labels = {0: "baseline", 1: "no transform (WRITE_V)", 2: "no patch activation/park (WRITE_P)", 4: "no VMEM in the loop",
+                  64: "no weight split", 15: "weight split + MFMA only", 79: "MFMA only", 16: "everything but the MFMAs",
+                  80: "no MFMA, no weight split", 27: "VMEM + weight split only", 91: "VMEM only",
+                  128: "phase order by wave parity", 256: "no patch loads", 512: "no weight loads"}
+    else:
+        labels = {0: "baseline", 1: "no transform (WRITE_V)", 2: "no patch activation/park (WRITE_P)", 3: "neither", 4: "no VMEM in the loop",
+                  16: "everything but the MFMAs", 15: "MFMA only", 27: "VMEM only", 11: "VMEM + MFMA only"}
     cases = [(96, 96, 64), (192, 192, 32), (480, 192, 32), (576, 288, 16)]
     if os.environ.get("MCVD_WEXP_CASES", "all") != "all":
         cases = [cases[int(v)] for v in os.environ["MCVD_WEXP_CASES"].split(",")]
     if os.environ.get("MCVD_WEXP_ONLY"):
         keep = [int(v) for v in os.environ["MCVD_WEXP_ONLY"].split(",")]
         labels = {k: v for k, v in labels.items() if k in keep}
-    f.write("# bf16x3 winograd K-loop, B=64, conv_wino3_kernel<3,2>; ideal MFMA time per chunk per SIMD = 2 waves x 36 x 32 = 2304 cycles\n")
+    if kshape == 10:
+        f.write("# bf16x3 winograd K-loop, B=64, conv_wino3_kernel<3,2>; ideal MFMA time per chunk per SIMD = 2 waves x 36 x 32 = 2304 cycles\n")
+    else:
+        f.write("# f16x2 winograd K-loop, B=64, conv_wino2h_kernel<3,2>; ideal MFMA time per chunk per SIMD = 2 waves x 18 x 32 = 1152 cycles\n")
 
     def run(shape, e):
         ctx.opt("conv_shape", shape)
-        os.environ["MCVD_WINO3_EXP"] = str(e)
+        os.environ[envname] = str(e)
         for _ in range(2):
             ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -386,11 +395,11 @@ def w3exp(f):
         us4, _ = run(4, 0)
         f.write(f"cin{cin} cout{cout} H{H} fp32-MFMA winograd (shape 4): kernel {us4:7.1f} us\n")
         for e, lab in labels.items():
-            us, per = run(10, e)
+            us, per = run(kshape, e)
             f.write(f"cin{cin} cout{cout} H{H} exp{e:4d} {lab:36s}: kernel {us:7.1f} us | wave0 pro {per[0][0]:6.0f} loop/chunk {per[0][1]:6.0f} epi {per[0][2]:6.0f} total {per[0][3]:7.0f}"
                     f" | wave7 pro {per[1][0]:6.0f} loop/chunk {per[1][1]:6.0f} epi {per[1][2]:6.0f} total {per[1][3]:7.0f}\n")
             f.flush()
-    os.environ["MCVD_WINO3_EXP"] = "0"
+    os.environ[envname] = "0"
     ctx.opt("conv_shape", -1)
 
 

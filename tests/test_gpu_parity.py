@@ -77,6 +77,17 @@ CONV_CASES = [
     (2, 288, 0, 288, 16, 3, True, 1, True, 11),     # ... with the 2-way K split
     (2, 384, 288, 288, 16, 3, True, 1, True, 11),   # ... K split over a concat
     (3, 32, 0, 64, 16, 3, True, 1, False, 11),      # ... too few chunks to split: runs unsplit
+    (2, 96, 0, 96, 64, 3, True, 1, True, 12),       # Winograd on the fp16 pipe, two-piece operands, pre-split weights: ResBlock Conv_1 @64 (cout tile 96)
+    (2, 10, 0, 96, 64, 3, False, 0, False, 12),     # ... stem (one ragged chunk)
+    (3, 192, 96, 192, 32, 3, True, 1, False, 12),   # ... up-path concat input
+    (3, 64, 0, 128, 16, 3, True, 1, True, 12),      # ... 64-channel cout tile
+    (2, 96, 0, 5, 64, 3, True, 1, False, 12),       # ... final conv, Cout=5 (32-channel cout tile, padded)
+    (1, 32, 0, 32, 128, 3, True, 1, True, 12),      # ... 128x128
+    (2, 40, 0, 32, 16, 3, True, 0, False, 12),      # ... affine prologue only (PRO 1), ragged last chunk
+    (5, 48, 16, 96, 8, 3, True, 1, True, 12),       # ... 8x8 images: not served, the fp32 Winograd kernel takes the launch
+    (2, 288, 0, 288, 16, 3, True, 1, True, 13),     # ... with the 2-way K split
+    (2, 384, 288, 288, 16, 3, True, 1, True, 13),   # ... K split over a concat
+    (3, 32, 0, 64, 16, 3, True, 1, False, 13),      # ... too few chunks to split: runs unsplit
     (2, 96, 0, 192, 32, 1, False, 0, False, -1),    # 1x1 shortcut
     (2, 96, 96, 192, 32, 1, False, 0, False, 0),    # 1x1 shortcut over a concat
     (2, 192, 0, 576, 32, 1, True, 0, False, 1),     # fused q|k|v projection with GN affine prologue (no SiLU)
@@ -124,6 +135,11 @@ def _expected_kernel(case):
             return 4                                 # 8x8 images: the fp32 Winograd kernel takes the launch
         chunks = -(-Cin // 16)
         return 11 if (fam == 11 and chunks % 2 == 0 and chunks >= 4) else 10
+    if fam in (12, 13):
+        if H == 8:
+            return 4
+        chunks = -(-Cin // 16)
+        return 13 if (fam == 13 and chunks % 2 == 0 and chunks >= 4) else 12
     return None
 
 
@@ -188,6 +204,32 @@ def test_conv_bf16x3_is_fp32_accurate(ctx, Cin, Cout, H):
     ctx.opt("conv_shape", -1)
     assert errs[10] <= max(1.5 * errs[4], 1e-6), f"bf16x3 conv error {errs[10]:.3e} vs fp32-MFMA {errs[4]:.3e}"
     assert errs[10] < 4e-6, errs
+
+
+@pytest.mark.parametrize("Cin,Cout,H", [(96, 96, 64), (480, 192, 32), (672, 288, 16)])
+@pytest.mark.parametrize("wscale,xscale", [(1.0, 1.0), (1e-3, 30.0), (40.0, 0.02)], ids=["unit", "small_w_big_x", "big_w_small_x"])
+def test_conv_f16x2_accuracy(ctx, Cin, Cout, H, wscale, xscale):
+    """The two-piece fp16 Winograd kernel (shape id 12; operands of 22 significant bits, fp32 accumulate, per-layer power-of-two
+    weight scale) against an fp64 convolution, next to the fp32-MFMA Winograd kernel (shape id 4) on the same data: its worst-element
+    error must stay within 2x the fp32 kernel's and below 6e-6 of the output scale, whatever the magnitudes of weights and inputs
+    (the per-layer scale and the fp16 range must not show)."""
+    g = _g(29)
+    B = 2
+    x = torch.randn(B, Cin, H, H, generator=g) * xscale
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5 * wscale
+    bias = 0.1 * torch.randn(Cout, generator=g) * wscale * xscale
+    want = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    errs = {}
+    for shape in (4, 12):
+        ctx.opt("conv_shape", shape)
+        got = ctx.conv2d(x.cuda(), w.cuda(), bias.cuda())
+        from mcvd_pytorch_amd import _lib
+        assert _lib.lib.mcvd_last_conv_kernel() == shape
+        errs[shape] = ((got.cpu().double() - want).abs().max() / want.abs().max()).item()
+    ctx.opt("conv_shape", -1)
+    print(f"f16x2 accuracy Cin{Cin} Cout{Cout} H{H} w*{wscale} x*{xscale}: fp32-MFMA {errs[4]:.3e}  f16x2 {errs[12]:.3e}")
+    assert errs[12] <= max(2.0 * errs[4], 1e-6), f"f16x2 conv error {errs[12]:.3e} vs fp32-MFMA {errs[4]:.3e}"
+    assert errs[12] < 6e-6, errs
 
 
 # ------------------------------------------------------------------------------------------------ group norm
@@ -426,17 +468,18 @@ def _net(name):
 
 @pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt", "tiny_cosine_b2.pt",
                                 "smmnist_big5_ngf96_b2.pt"])
-@pytest.mark.parametrize("naive", [0, 3, 16, 17], ids=["mfma", "naive", "bf16x3", "bf16x3ks"])
+@pytest.mark.parametrize("naive", [0, 3, 16, 17, 18, 19], ids=["mfma", "naive", "bf16x3", "bf16x3ks", "f16x2", "f16x2ks"])
 def test_forward_vs_reference_golden(golden_dir, fx, naive):
     """One UNet forward vs the REAL reference's output (fixture) and, module by module, vs the oracle.  bf16x3 / bf16x3ks: every 3x3
-    conv the split-operand bf16 Winograd kernel serves is forced onto it (shape ids 10 / 11), same tolerances."""
+    conv the split-operand bf16 Winograd kernel serves is forced onto it (shape ids 10 / 11), same tolerances; f16x2 / f16x2ks: onto
+    the two-piece fp16 kernel (shape ids 12 / 13), same tolerances."""
     from tests.hiputil import module_output
     g = torch.load(os.path.join(golden_dir, fx), weights_only=False)
     config, sd, net = _net(g["config_name"])
-    net.set_option("naive_conv", naive & 1)
-    net.set_option("naive_attn", (naive >> 1) & 1)
+    net.set_option("naive_conv", naive & 1 if naive < 16 else 0)
+    net.set_option("naive_attn", (naive >> 1) & 1 if naive < 16 else 0)
     if naive >= 16:
-        net.set_option("conv_shape", 10 + (naive & 1))
+        net.set_option("conv_shape", 10 + (naive & 3))
     x, cond = synth.make_inputs(config, g["batch"], seed=0)
     t = g["fwd_t"]
     eps = net(x.cuda(), t.cuda(), cond=cond.cuda())
@@ -466,7 +509,7 @@ def test_forward_vs_reference_golden(golden_dir, fx, naive):
     assert (eps.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("shape", [4, 10, 11])
+@pytest.mark.parametrize("shape", [4, 10, 11, 12, 13])
 def test_forward_is_bit_deterministic(shape):
     """300 forwards of BASELINE config 1 (B = 2) with every 3x3 conv forced onto one Winograd kernel must be bit-identical.  The
     kernels count their own VMEM waits; a register the compiler copies (or reuses) while a load into it is still in flight shows

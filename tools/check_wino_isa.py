@@ -13,6 +13,10 @@ This script compiles the file to gfx950 assembly and verifies 1-3 for every inst
 conv_wino3.cpp (the split-operand bf16 form of the same convolution) counts its VMEM the same way: its K loops (two per kernel,
 one per phase order) must hold exactly 4*COT weight loads + 6 patch loads, no scratch traffic, and keep the load destinations
 untouched up to the next vmcnt wait.
+
+conv_wino2h.cpp (two fp16 pieces per operand, pre-split weights) has the same two K loops and the same load counts; its MFMAs are
+inline asm that read their A operand straight out of the load destinations, so in addition nothing but MFMAs may touch an
+accumulator register inside a K loop (the compiler does not know they are MFMA results and would not insert the wait states).
 """
 import os
 import re
@@ -23,6 +27,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc", "kernels", "conv_wino.cpp")
 SRC3 = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc", "kernels", "conv_wino3.cpp")
+SRC2H = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc", "kernels", "conv_wino2h.cpp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -121,10 +126,10 @@ def _dest_untouched_covering(name, loop, problems):
             problems.append(f"{name}: no wait covers `{l}`")
 
 
-def check3(asm_text):
-    """conv_wino3_kernel<COT, PRO, 0>: every loop that holds MFMAs is a K loop."""
+def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=False):
+    """conv_wino3_kernel<COT, PRO, 0> / conv_wino2h_kernel<COT, PRO, 0>: every loop that holds MFMAs is a K loop."""
     problems, seen = [], 0
-    for m in re.finditer(r"^(_ZN4mcvd17conv_wino3_kernelILi(\d)ELi(\d)ELi0EEEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN4mcvd" + kernel + r"ILi(\d)ELi(\d)ELi0EEEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
         name, cot, body = m.group(1), int(m.group(2)), m.group(4)
         seen += 1
         lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
@@ -154,6 +159,16 @@ def check3(asm_text):
             if len(wl) != 4 * cot or len(pl) != 6 or len(wl) + len(pl) != len(vmem):
                 problems.append(f"{name}: expected {4 * cot} weight + 6 patch loads and no other VMEM in a K loop, found {len(wl)} + {len(pl)} of {len(vmem)}")
             _dest_untouched_covering(name, loop, problems)
+            if asm_mfma:      # accumulators: written and read by MFMAs only
+                acc = set()
+                for l in loop:
+                    if l.startswith("v_mfma"):
+                        acc |= _regs(l.split(",")[0])
+                for l in loop:
+                    ops = l.split(None, 1)
+                    if not l.startswith("v_mfma") and len(ops) > 1 and _regs(ops[1]) & acc:
+                        problems.append(f"{name}: `{l}` touches an accumulator inside a K loop")
+                        break
             # leaving the loop: its loads may still be in flight; nothing may read or overwrite their destinations before vmcnt(0)
             dests = set()
             for l in wl + pl:
@@ -191,14 +206,18 @@ def check3(asm_text):
         if kloops != 2:
             problems.append(f"{name}: expected 2 K loops (one per phase order), found {kloops}")
     if seen != 9:
-        problems.append(f"expected 9 instantiations of conv_wino3_kernel<COT, PRO, 0>, found {seen}")
+        problems.append(f"expected 9 instantiations of {kernel}<COT, PRO, 0>, found {seen}")
     return problems
+
+
+def check2h(asm_text):
+    return check3(asm_text, kernel="18conv_wino2h_kernel", asm_mfma=True)
 
 
 def main():
     problems = []
     with tempfile.TemporaryDirectory() as td:
-        for src, fn in ((SRC, check), (SRC3, check3)):
+        for src, fn in ((SRC, check), (SRC3, check3), (SRC2H, check2h)):
             out = os.path.join(td, os.path.basename(src)[:-4] + ".s")
             cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
                    src, "-o", out]
