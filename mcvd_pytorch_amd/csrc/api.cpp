@@ -285,9 +285,11 @@ int mcvd_model_finalize(mcvd_model* m) {
             }
             if (p.wpw >= 0)
                 if (int rc = launch_pack_wino_weight(m->blob + w.off, m->packed + p.wpw, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
-            if (p.wph >= 0)
+            if (p.wph >= 0 && p.ks == 3)
                 if (int rc = launch_pack_wino2h_weight(m->blob + w.off, m->packed + p.wph, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
         }
+        if (p.wph >= 0 && p.ks == 1)           // from the packed fp32 matrix: every fused weight (q | k | v) and the padding are in place
+            if (int rc = launch_pack_conv1x1_h2(m->packed + p.wp, m->packed + p.wph, p.CinP, p.CoutP, s)) return rc;
     }
     for (const DenseEntry& e : m->dense) {
         const ParamInfo& w = m->params[m->find_param(e.weight.c_str())];
@@ -419,7 +421,7 @@ int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* co
     MCVD_REQUIRE(n == (int)m->ops.size(), "set_tuning: %d entries for a plan of %d ops (tuning of another model?)", n, (int)m->ops.size());
     for (int i = 0; i < n; ++i) {
         const bool conv = m->ops[i].kind == OP_CONV;
-        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 13 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
+        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 14 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
                      "set_tuning: entry %d (shape %d, cout tile %d) does not fit op kind %d", i, shapes[i], cots[i], (int)m->ops[i].kind);
     }
     m->tuned_cache[B] = {std::vector<int>(shapes, shapes + n), std::vector<int>(cots, cots + n)};
@@ -768,7 +770,8 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
                       conv_wino_supported(ks, H, W);
     const bool wino_h = wino && (ctx->conv_shape == 12 || ctx->conv_shape == 13) && !(H == 8 && W == 8);     // fp16 pieces as well
     const size_t ufloats = wino ? (size_t)a.CinP * 16 * a.CoutP : 0;
-    const size_t hfloats = wino_h ? (size_t)((conv_wino2h_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4) : 0;
+    const size_t hfloats = wino_h ? (size_t)((conv_wino2h_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4)
+                                  : (ks == 1 && ctx->conv_shape == 14) ? (size_t)((conv1x1_h2_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4) : 0;
     const size_t pfloats = (wino && (ctx->conv_shape == 8 || ctx->conv_shape == 11 || ctx->conv_shape == 13)) ? (size_t)2 * B * Cout * H * W : 0;     // K-split partial results
     if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats + hfloats + pfloats) * sizeof(float))) return rc;
     MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP + ufloats + hfloats) * sizeof(float), ctx->stream));
@@ -782,11 +785,15 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
         if (pfloats) a.part = ctx->scratch + wfloats + a.CoutP + ufloats + hfloats;
     }
     if (int rc = launch_pack_conv_weight(w, ctx->scratch, Cout, a.Cin, ks, a.CinP, a.CoutP, 0, 0, ctx->stream)) return rc;
+    if (ks == 1 && ctx->conv_shape == 14) {
+        if (int rc = launch_pack_conv1x1_h2(ctx->scratch, ctx->scratch + wfloats + a.CoutP, a.CinP, a.CoutP, ctx->stream)) return rc;
+        a.wph = ctx->scratch + wfloats + a.CoutP;
+    }
     MCVD_HIP_CHECK(hipMemcpyAsync(ctx->scratch + wfloats, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     a.wp = ctx->scratch;
     a.bias = ctx->scratch + wfloats;
     a.shape_hint = ctx->conv_shape;
-    if ((ctx->conv_shape == 5 || ctx->conv_shape == 6 || ctx->conv_shape == 9) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
+    if ((ctx->conv_shape == 5 || ctx->conv_shape == 6 || ctx->conv_shape == 9 || ctx->conv_shape == 14) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
     a.wdma = ctx->conv_wdma;
     a.dbg = ctx->dbg;
     a.stats = ctx->naive_conv ? nullptr : ctx->stats_buf;

@@ -60,7 +60,8 @@ struct ConvArgs {
     int act;              // SiLU after the affine
     const float* wp;      // packed weights
     const float* wpw;     // Winograd-transformed weights, operand-major (conv_wino.cpp: pack_wino_weight_kernel; 3x3 only), or null
-    const float* wph;     // the same weights pre-split into two fp16 pieces + header (conv_wino2h.cpp: launch_pack_wino2h_weight), or null
+    const float* wph;     // the weights pre-split into two fp16 pieces + header: 3x3 Winograd-transformed (conv_wino2h.cpp:
+                          // launch_pack_wino2h_weight) or 1x1 (conv1x1_h2.cpp: launch_pack_conv1x1_h2), or null
     const float* bias;    // [Cout]
     const float* res;     // residual [B][Cout][H][W] or null
     float out_scale;
@@ -70,7 +71,8 @@ struct ConvArgs {
     int cot;              // cout tile in units of 32 channels (1..4); CoutP % (32*cot) == 0
     int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile, 3 split-K+WDB, 4 Winograd (8: with a 2-way K split), 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels per chunk),
                           // 9 the 1x1 GEMM with 64 pixels per wave, 10 Winograd on the bf16 pipe with split operands (11: with a 2-way K split),
-                          // 12 Winograd on the fp16 pipe with two-piece operands (13: with a 2-way K split)
+                          // 12 Winograd on the fp16 pipe with two-piece operands (13: with a 2-way K split), 14 the 1x1 GEMM on the fp16 pipe
+                          // with two-piece operands
     int ksplit;           // Winograd kernel only: 2 = two workgroups per tile contract half the input channels each into
                           // `part`, a second pass sums the halves; 0/1 = off
     float* part;          // ksplit == 2: scratch for the two partial results, 2 * B*Cout*H*W floats
@@ -109,6 +111,12 @@ bool conv_wino2h_usable(const ConvArgs& a);
 int launch_conv_wino2h(const ConvArgs& a, hipStream_t s);
 long conv_wino2h_weight_floats(int CinP, int CoutP);          // size of the wph buffer (header + pieces), in floats
 int launch_pack_wino2h_weight(const float* w, float* wh, int Cout, int Cin, int CinP, int CoutP, hipStream_t s);   // wh zero-filled
+// 1x1 GEMM on the fp16 matrix pipe with two-piece operands (conv1x1_h2.cpp): tile shape id 14, cout tile a.cot = 1..4; needs
+// ConvArgs::wph (launch_pack_conv1x1_h2 from the packed fp32 matrix wp)
+bool conv1x1_h2_supported(const ConvArgs& a, int cot);
+int launch_conv1x1_h2(const ConvArgs& a, int cot, hipStream_t s);
+long conv1x1_h2_weight_floats(int CinP, int CoutP);
+int launch_pack_conv1x1_h2(const float* wp, float* wh, int CinP, int CoutP, hipStream_t s);      // wh[0] zero on entry
 // all-DMA 1x1 GEMM (conv1x1_dma.cpp): tile shape ids 5 / 6; cot_req <= 0 picks the default cout tile
 bool conv1x1_dma_supported(const ConvArgs& a, int ck, int pxw = 1);     // ck: channels per chunk, 16 (shape id 5) or 32 (shape id 6); pxw = 2: 256-pixel tiles (shape id 9, ck 16)
 int conv1x1_dma_cout_tile(int CoutP);

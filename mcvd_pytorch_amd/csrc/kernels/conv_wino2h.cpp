@@ -168,15 +168,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     }
 #define H2_WAIT(N) asm volatile("s_waitcnt vmcnt(%1)\n\ts_mov_b32 %0, 0" : "=s"(vtok) : "n"(N) : "memory");
     /* unconditional, clamped raw loads of the patch of chunk `ch` (conv_wino.cpp: WR_LOAD_P) */
-#define H2_LOAD_P(ch, DEP)                                                                                      \
+#define H2_READ_OFF(OFS) { _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) OFS[sl] = sOff[sl * NT + tid]; }
+#define H2_LOAD_P(ch, DEP, OFS)                                                                                 \
     {                                                                                                           \
         const int cb = min((ch) * CK, Cin - 1);                                                                 \
         const unsigned lim = (unsigned)((Cin - cb) * HW - 1) * 4u;                                              \
         const bool second = cb >= a.C0;                                                                         \
         const float* srcb = second ? a.x1 + ((long)b * a.C1 + (cb - a.C0)) * HW : a.x0 + ((long)b * a.C0 + cb) * HW; \
-        unsigned off[MAXP];          /* all offsets first: ONE LDS round trip (the asm loads below are not reordered) */ \
+        unsigned off[MAXP];                                                                                     \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl)                                                     \
-            off[sl] = min(sOff[sl * NT + tid], lim);      /* channels past the last one are zeroed at the write: any address inside the source will do */ \
+            off[sl] = min(OFS[sl], lim);      /* channels past the last one are zeroed at the write: any address inside the source will do */ \
         asm volatile("global_load_dword v202, %0, %6\n\tglobal_load_dword v203, %1, %6\n\tglobal_load_dword v204, %2, %6\n\t" \
                      "global_load_dword v205, %3, %6\n\tglobal_load_dword v206, %4, %6\n\tglobal_load_dword v207, %5, %6"       \
                      :: "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "s"(srcb),           \
@@ -194,11 +195,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     }
     /* activate once per pixel (coefficients from the LDS table) and park the patch in LDS; zero padding applies AFTER     \
        the activation */                                                                                           \
-#define H2_WRITE_P(ch, D, FROM_REGS, PV)                                                                         \
+#define H2_READ_C(ch, cfv)                                                                                      \
     {                                                                                                           \
-        float* sPw = sP + (((ch) & 1) ? PBUF : 0);                                                              \
-        const int nvalid = Cin - (ch) * CK;                                                                     \
-        f32x2 cfv[MAXP];                     /* all coefficient reads first: ONE LDS round trip */               \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
             cfv[sl] = f32x2{1.0f, 0.0f};                                                                        \
             if (PRO >= 1) {                                                                                     \
@@ -206,6 +204,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
                 cfv[sl] = *reinterpret_cast<const f32x2*>(sCo + cch * 2);                                       \
             }                                                                                                   \
         }                                                                                                       \
+    }
+#define H2_WRITE_P(ch, D, FROM_REGS, PV, cfv)                                                                    \
+    {                                                                                                           \
+        float* sPw = sP + (((ch) & 1) ? PBUF : 0);                                                              \
+        const int nvalid = Cin - (ch) * CK;                                                                     \
         if (FROM_REGS) {      /* v = A * raw + B straight out of the patch registers (PRO 0: A = 1, B = 0, exact) */ \
             asm("v_fma_f32 %0, v202, %6, %7\n\tv_fma_f32 %1, v203, %8, %9\n\tv_fma_f32 %2, v204, %10, %11\n\t"            \
                          "v_fma_f32 %3, v205, %12, %13\n\tv_fma_f32 %4, v206, %14, %15\n\tv_fma_f32 %5, v207, %16, %17"    \
@@ -224,13 +227,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     /* rows 2rg and 2rg+1 of B^T d for the two channels of the pair (packed fp32: .x = channel s_ca, .y = s_ca + 2), (.) B,      \
        two-way fp16 split, 16 stores:                                                                                        \
        row 0: d0 - d2   row 1: d1 + d2   row 2: d2 - d1   row 3: d1 - d3;   (.) B: m0 - m2, m1 + m2, m2 - m1, m1 - m3 */      \
-#define H2_WRITE_V(ch, RG)                                                                                      \
+#define H2_READ_R(ch, RW)                                                                                       \
     {                                                                                                           \
         const f32x2* sPr = reinterpret_cast<const f32x2*>(sP + (((ch) & 1) ? PBUF : 0) + p_rd);                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) { RW[0][j] = sPr[j]; RW[1][j] = sPr[PP + j]; RW[2][j] = sPr[2 * PP + j]; } \
+    }
+#define H2_WRITE_V(ch, RG, RW)                                                                                  \
+    {                                                                                                           \
         unsigned* vdst = sV + (((ch) & 1) ? VW : 0) + v_wr;                                                     \
         f32x2 mx[4], my[4];                                                                                     \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-            const f32x2 r0 = sPr[j], r1 = sPr[PP + j], r2 = sPr[2 * PP + j];                                    \
+            const f32x2 r0 = RW[0][j], r1 = RW[1][j], r2 = RW[2][j];                                            \
             if ((RG) == 0) { mx[j] = r0 - r2; my[j] = r1 + r2; }                                                \
             else { mx[j] = r1 - r0; my[j] = r0 - r2; }                                                          \
         }                                                                                                       \
@@ -280,12 +287,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     /* patch of chunk ch+2 -> LDS, raw patch of chunk ch+3 requested, V(ch+1) -> LDS */
 #define H2_VALU_PHASE(ch, RG)                                                                                   \
     {                                                                                                           \
+        /* every LDS read of the phase is issued up front: ONE round trip (coefficients, load offsets, the 12 patch pairs) */ \
+        f32x2 cfv[MAXP], rw[3][4];                                                                              \
+        unsigned ofs[MAXP];                                                                                     \
+        if (!(EXP & 2)) H2_READ_C((ch) + 2, cfv)                                                                \
+        if (!(EXP & 4)) H2_READ_OFF(ofs)                                                                        \
+        if (!(EXP & 1)) H2_READ_R((ch) + 1, rw)                                                                 \
         if (!(EXP & 4)) H2_WAIT(NA)                                                                             \
         float pv[MAXP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                        \
-        if (!(EXP & 2)) H2_WRITE_P((ch) + 2, q0, true, pv)                                                      \
-        if (!(EXP & 4)) H2_LOAD_P((ch) + 3, pv)                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if (!(EXP & 1)) H2_WRITE_V((ch) + 1, RG)                                                                 \
+        if (!(EXP & 2)) H2_WRITE_P((ch) + 2, q0, true, pv, cfv)                                                 \
+        if (!(EXP & 4)) H2_LOAD_P((ch) + 3, pv, ofs)                                                            \
+        if (!(EXP & 1)) H2_WRITE_V((ch) + 1, RG, rw)                                                            \
     }
 
     f32x16 acc[2][COT];
@@ -298,8 +310,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
 
     // diagnostics (mcvd_ctx_set_debug_buffer): shader-clock time the wave a.wdma spends per phase
     const bool rec = a.dbg != nullptr && wave == a.wdma;
-    unsigned long long tk0 = 0, tprev = 0, dt[2] = {0, 0}, pt[3] = {0, 0, 0};
-    if (rec) tk0 = tprev = __builtin_amdgcn_s_memtime();
+    unsigned long long tk0 = 0, tprev = 0, dt[2] = {0, 0}, rt0 = 0;
+    if (rec) {
+        rt0 = __builtin_amdgcn_s_memrealtime();          // constant 100 MHz: start / end of the workgroup on the wall clock
+        tk0 = tprev = __builtin_amdgcn_s_memtime();
+    }
 #define H2_STAMP(i)                                                                                             \
     if (rec) {                                                                                                  \
         const unsigned long long now = __builtin_amdgcn_s_memtime();                                            \
@@ -321,7 +336,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         H2_LOAD_A(c_begin, 1)
         H2_LOAD_Q(c_begin, q0)
         H2_LOAD_Q(c_begin + 1, q1)
-        H2_LOAD_P(c_begin + 2, q0)
+        {
+            unsigned ofs[MAXP];
+            H2_READ_OFF(ofs)
+            H2_LOAD_P(c_begin + 2, q0, ofs)
+        }
         if (PRO) {
             for (int c = tid; c < Cin; c += NT) {
                 if (a.coef) cfl = *reinterpret_cast<const f32x2*>(a.coef + ((long)b * Cin + c) * 2);
@@ -332,12 +351,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         if (PRO) __syncthreads();          // coefficient table visible
         {
             float pv[MAXP];
-            H2_WRITE_P(c_begin, q0, false, pv)
-            H2_WRITE_P(c_begin + 1, q1, false, pv)
+            f32x2 cf0[MAXP], cf1[MAXP];
+            H2_READ_C(c_begin, cf0)
+            H2_READ_C(c_begin + 1, cf1)
+            H2_WRITE_P(c_begin, q0, false, pv, cf0)
+            H2_WRITE_P(c_begin + 1, q1, false, pv, cf1)
         }
     }
     __syncthreads();                       // the first two patches visible
-    H2_WRITE_V(c_begin, rg)
+    {
+        f32x2 rw[3][4];
+        H2_READ_R(c_begin, rw)
+        H2_WRITE_V(c_begin, rg, rw)
+    }
     __syncthreads();                       // V of the first chunk visible
     H2_STAMP(0)
 
@@ -457,7 +483,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         const unsigned long long now = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
             unsigned long long* d = a.dbg + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
-            d[0] = dt[0]; d[1] = dt[1]; d[2] = pt[0]; d[3] = pt[1]; d[4] = pt[2];
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            d[0] = dt[0]; d[1] = dt[1]; d[2] = rt0; d[3] = __builtin_amdgcn_s_memrealtime();
+            d[4] = ((unsigned long long)xcc << 32) | hwid;          // which CU ran it (gpu_diag.py w2htl: per-CU timeline)
             d[5] = now - tprev;            // epilogue
             d[6] = (unsigned long long)(c_end - c_begin);
             d[7] = now - tk0;
@@ -473,6 +503,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
 #undef H2_WAIT
 #undef H2_WRITE_P
 #undef H2_WRITE_V
+#undef H2_READ_R
+#undef H2_READ_C
+#undef H2_READ_OFF
 #undef H2_LOAD_B
 #undef H2_MFMA_PHASE
 #undef H2_VALU_PHASE

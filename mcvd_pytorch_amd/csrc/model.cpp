@@ -173,6 +173,7 @@ struct Builder {
             p.wpw = alloc_packed((int64_t)p.CinP * 16 * p.CoutP);
         if (p.wpw >= 0 && !(op.H == 8 && op.W == 8))          // the fp16-piece form serves the 8x16-pixel regions only
             p.wph = alloc_packed(conv_wino2h_weight_floats(p.CinP, p.CoutP));
+        if (ks == 1) p.wph = alloc_packed(conv1x1_h2_weight_floats(p.CinP, p.CoutP));      // two fp16 pieces of the packed matrix (conv1x1_h2.cpp)
         op.wpw = p.wpw;
         op.wph = p.wph;
         m.packs.push_back(p);
@@ -876,6 +877,11 @@ int mcvd_model::autotune(int B) {
                         ++tried;
                         if (int rc = time_candidate(ck == 16 ? 5 : 6, c)) return rc;
                     }
+                }
+                if (ctx->f16x2) {                           // 14 = the GEMM on the fp16 pipe with two-piece operands, cout tiles 1..4
+                    for (int c = 4; c >= 1; --c)
+                        if (conv1x1_h2_supported(a, c))
+                            if (int rc = time_candidate(14, c)) return rc;
                 }
                 if (conv1x1_dma_supported(a, 16, 2)) {      // 9 = the same GEMM with 64 pixels per wave (256-pixel tiles), cout tiles 1 / 2
                     if (int rc = time_candidate(9, 1)) return rc;

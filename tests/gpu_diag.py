@@ -403,6 +403,65 @@ def w3exp(f):
     ctx.opt("conv_shape", -1)
 
 
+def w2htl(f):
+    """Per-CU timeline of conv_wino2h_kernel launches: every workgroup records its start / end on the 100 MHz wall clock, its
+    shader-cycle count and the CU it ran on.  Answers: what is the shader clock under this kernel, and how long does a CU sit
+    between two workgroups (dispatch gap)."""
+    from tests.hiputil import Ctx, P
+    ctx = Ctx()
+    B = 64
+    cases = [(96, 96, 64, 3, 12, 0), (480, 192, 32, 3, 12, 0), (192, 576, 32, 1, 14, 2), (192, 576, 32, 1, 14, 3), (288, 96, 64, 1, 14, 3), (384, 1152, 8, 1, 14, 3)]
+    if os.environ.get("MCVD_TL_CASES"):
+        cases = [cases[int(v)] for v in os.environ["MCVD_TL_CASES"].split(",")]
+    for cin, cout, H, ks, shp, cot in cases:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, ks, ks, device="cuda") / (cin * ks * ks) ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda")
+        ctx.opt("conv_shape", shp)
+        ctx.opt("conv_cot", cot)
+        f.write(f"--- {ks}x{ks} shape {shp} cot {cot}: ")
+        os.environ["MCVD_DBG_WAVE"] = "0"
+        for _ in range(3):
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 4
+        dbg = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
+        _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
+        ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
+        d = dbg.view(-1, 8).cpu()
+        d = d[d[:, 7] > 0]
+        rt0, rt1, cyc, who = d[:, 2].double(), d[:, 3].double(), d[:, 7].double(), d[:, 4]
+        span = (rt1.max() - rt0.min()).item() * 10e-3          # us (100 MHz ticks)
+        clk = (cyc / ((rt1 - rt0) * 10e-9)).median().item() / 1e9
+        f.write(f"cin{cin} cout{cout} H{H}: kernel {us:.1f} us (events), first start -> last end {span:.1f} us, {len(d)} workgroups, "
+                f"shader clock (cycles / wall time inside a workgroup, median) {clk:.3f} GHz, workgroup {cyc.mean().item():.0f} cycles = {((rt1 - rt0).mean().item() * 10e-3):.2f} us"
+                f" (prologue {d[:, 0].double().mean().item():.0f}, loop {d[:, 1].double().mean().item():.0f} = {(d[:, 1].double() / d[:, 6].double().clamp(min=1)).mean().item():.0f} per chunk, epilogue {d[:, 5].double().mean().item():.0f})\n")
+        # per-CU timelines
+        cus = {}
+        for i in range(len(d)):
+            cus.setdefault(((int(who[i].item()) >> 32) & 0xf, (int(who[i].item()) >> 8) & 0xff), []).append((rt0[i].item(), rt1[i].item()))   # key: (XCC, SE | SH | CU) of HW_ID
+        gaps, busy, nper = [], [], []
+        for k, v in cus.items():
+            v.sort()
+            nper.append(len(v))
+            busy.append(sum(b - a for a, b in v))
+            gaps += [v[j + 1][0] - v[j][1] for j in range(len(v) - 1)]
+        g = torch.tensor(gaps) * 10e-3 if gaps else torch.zeros(1)
+        f.write(f"   {len(cus)} CUs, workgroups per CU {min(nper)}..{max(nper)}, busy per CU {min(busy) * 10e-3:.1f}..{max(busy) * 10e-3:.1f} us, "
+                f"gap between consecutive workgroups on a CU: median {g.median().item():.2f} us, mean {g.mean().item():.2f} us, max {g.max().item():.2f} us; "
+                f"first workgroup starts {((torch.tensor([v[0][0] for v in cus.values()]) - rt0.min().item()) * 10e-3).max().item():.2f} us after the earliest\n")
+    ctx.opt("conv_shape", -1)
+    ctx.opt("conv_cot", 0)
+
+
 def convops(f):
     """Per-op times of the 3x3 convs of one instrumented forward (BASELINE config 2, B = 64): kernel the autotuner chose and ms,
     with the split-operand bf16 Winograd kernel offered (MCVD_BF16X3 unset) -- run again with MCVD_BF16X3=0 for the fp32 table."""
@@ -435,8 +494,7 @@ def convops(f):
         shape = (info[6] >> 4) & 15 if (info[6] >> 12) else -1
         key = (kss[i], shape)
         tot[key] = tot.get(key, 0.0) + ms[i]
-        if kss[i] == 3:
-            f.write(f"op {i:3d} 3x3 H{info[3]:3d} cin{info[4]:4d} cout{info[5]:4d} shape {shape:2d} cot {(info[6] >> 8) & 15}: {ms[i] * 1e3:7.1f} us  {fl[i] / ms[i] / 1e9:6.1f} TF/s\n")
+        f.write(f"op {i:3d} {kss[i]}x{kss[i]} H{info[3]:3d} cin{info[4]:4d} cout{info[5]:4d} shape {shape:2d} cot {(info[6] >> 8) & 15}: {ms[i] * 1e3:7.1f} us  {fl[i] / ms[i] / 1e9:6.1f} TF/s  {by[i] / ms[i] / 1e6:7.1f} GB/s\n")
     f.write("totals (ks, shape) -> ms: " + ", ".join(f"{k}: {v:.3f}" for k, v in sorted(tot.items())) + "\n")
 
 
@@ -445,6 +503,6 @@ if __name__ == "__main__":
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "convops": convops, "sweep1": sweep1}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "convops": convops, "sweep1": sweep1, "w2htl": w2htl}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 

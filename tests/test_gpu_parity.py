@@ -109,6 +109,14 @@ CONV_CASES = [
     (3, 192, 0, 576, 32, 1, True, 0, False, 9 + 16 * 1),   # ... q|k|v with the GN affine, cout tile 32, B*HW not a multiple of 256? (3*1024 is)
     (5, 288, 0, 288, 8, 1, True, 1, True, 9 + 16 * 1),     # ... four 8x8 images per pixel tile, ragged last tile (5 images), affine + SiLU, residual
     (1, 96, 0, 96, 16, 1, False, 0, True, 9 + 16 * 1),     # ... exactly one 256-pixel tile
+    (2, 96, 0, 192, 32, 1, False, 0, False, 14 + 16 * 3),  # 1x1 GEMM on the fp16 pipe, two-piece operands: shortcut, cout tile 96
+    (2, 96, 96, 192, 32, 1, False, 0, False, 14 + 16 * 2), # ... shortcut over a concat, cout tile 64
+    (2, 192, 0, 576, 32, 1, True, 0, False, 14 + 16 * 3),  # ... q|k|v projection with the GN affine (PRO 1)
+    (3, 288, 0, 288, 8, 1, False, 0, True, 14 + 16 * 3),   # ... NIN_3 with residual, two 8x8 images per pixel tile, ragged last tile
+    (3, 288, 0, 288, 8, 1, True, 1, True, 14 + 16 * 1),    # ... affine + SiLU prologue, cout tile 32
+    (3, 128, 0, 128, 16, 1, True, 0, True, 14 + 16 * 4),   # ... cout tile 128
+    (1, 96, 0, 96, 64, 1, False, 0, False, 14 + 16 * 1),
+    (3, 72, 0, 64, 16, 1, False, 0, True, 14 + 16 * 2),    # Cin not a multiple of 32: not served, the staged kernel takes the launch
 ]
 
 
@@ -130,6 +138,8 @@ def _expected_kernel(case):
         return fam if Cin % (16 if fam == 5 else 32) == 0 else "direct"
     if fam == 9:
         return 9
+    if fam == 14:
+        return 14 if Cin % 32 == 0 else "direct"
     if fam in (10, 11):
         if H == 8:
             return 4                                 # 8x8 images: the fp32 Winograd kernel takes the launch
@@ -230,6 +240,30 @@ def test_conv_f16x2_accuracy(ctx, Cin, Cout, H, wscale, xscale):
     print(f"f16x2 accuracy Cin{Cin} Cout{Cout} H{H} w*{wscale} x*{xscale}: fp32-MFMA {errs[4]:.3e}  f16x2 {errs[12]:.3e}")
     assert errs[12] <= max(2.0 * errs[4], 1e-6), f"f16x2 conv error {errs[12]:.3e} vs fp32-MFMA {errs[4]:.3e}"
     assert errs[12] < 6e-6, errs
+
+
+@pytest.mark.parametrize("Cin,Cout,H,cot", [(192, 576, 32, 3), (384, 384, 8, 4), (96, 192, 64, 2)])
+def test_conv1x1_f16x2_accuracy(ctx, Cin, Cout, H, cot):
+    """The two-piece fp16 1x1 GEMM (shape id 14) against an fp64 product, next to the fp32-MFMA GEMM (shape id 5) on the same data."""
+    g = _g(31)
+    B = 2
+    x = torch.randn(B, Cin, H, H, generator=g) * 3.0
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5 * 0.05
+    bias = 0.01 * torch.randn(Cout, generator=g)
+    want = F.conv2d(x.double(), w.double(), bias.double())
+    errs = {}
+    from mcvd_pytorch_amd import _lib
+    for shape in (5, 14):
+        ctx.opt("conv_shape", shape)
+        ctx.opt("conv_cot", cot if shape == 14 else 0)
+        got = ctx.conv2d(x.cuda(), w.cuda(), bias.cuda())
+        assert _lib.lib.mcvd_last_conv_kernel() == shape
+        errs[shape] = ((got.cpu().double() - want).abs().max() / want.abs().max()).item()
+    ctx.opt("conv_shape", -1)
+    ctx.opt("conv_cot", 0)
+    print(f"f16x2 1x1 accuracy Cin{Cin} Cout{Cout} H{H}: fp32-MFMA {errs[5]:.3e}  f16x2 {errs[14]:.3e}")
+    assert errs[14] <= max(2.0 * errs[5], 1e-6), f"f16x2 1x1 error {errs[14]:.3e} vs fp32-MFMA {errs[5]:.3e}"
+    assert errs[14] < 4e-6, errs
 
 
 # ------------------------------------------------------------------------------------------------ group norm
