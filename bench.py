@@ -301,11 +301,11 @@ def main():
     executed = algorithmic * mult_ratio
     traffic, traffic_src = None, None     # HBM-side bytes per launch from the committed PMC passes over the SAME launch population
     try:
-        tr = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("conv_wino_traffic.json"))
-        if tr and args.config == "smmnist_big5_ngf96" and B == 64:
-            tj = json.load(open(os.path.join(ROOT, "profiles", tr[-1])))
-            if tj.get("family", "wino_f32") == dom_key:
-                traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/" + tr[-1]
+        if args.config == "smmnist_big5_ngf96" and B == 64:      # the committed PMC passes are of this workload
+            for fn in sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")):
+                tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if tj.get("family", "wino_f32") == dom_key and "traffic_bytes_per_launch" in tj:
+                    traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/" + fn      # the latest file of the family wins
     except Exception:
         traffic = None
     roofline = dict(bound="mfma", kernel=dom_name,
@@ -319,6 +319,7 @@ def main():
                     algorithmic_achieved=round(algorithmic, 2), algorithmic_frac=round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
                     algorithmic_bytes_per_launch=round(dom["bytes"] / dom["launches"]),
                     launches=dom["launches"], avg_launch_us=round(1e3 * dom["ms"] / dom["launches"], 1),
+                    hbm_gbs=(round(traffic / (1e3 * dom["ms"] / dom["launches"]) / 1e3, 1) if traffic else None), hbm_peak_gbs=HBM_PEAK_GBS,
                     flops_per_launch_avg=dom["flops"] / dom["launches"],
                     conv3x3_families={k: dict(launches=v["launches"], ms=round(v["ms"], 3),
                                               algorithmic_tflops=round(v["flops"] / v["ms"] / 1e9, 2) if v["ms"] else None)

@@ -49,7 +49,7 @@ prof)
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --graph 0 --tune-cache $TUNE > $R/gpurun_out/pmc_fetch.json 2> $R/gpurun_out/pmc_fetch.err
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --graph 0 --tune-cache $TUNE > $R/gpurun_out/pmc_write.json 2> $R/gpurun_out/pmc_write.err
   cd $R; python tools/summarize_prof.py > gpurun_out/prof_summary.txt 2>&1; head -40 gpurun_out/prof_summary.txt
-  python tools/summarize_prof.py traffic gpurun_out/conv_wino_traffic.json > gpurun_out/traffic.log 2>&1; tail -3 gpurun_out/traffic.log
+  python tools/summarize_prof.py traffic gpurun_out/conv3x3_traffic.json > gpurun_out/traffic.log 2>&1; tail -3 gpurun_out/traffic.log
   find gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -size +20M -delete;;
 pmc_mfma)
   cd /tmp

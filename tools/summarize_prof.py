@@ -105,8 +105,22 @@ def traffic(out_json):
     op of the forwards of the run (a K-split op = conv_wino_kernel + its reduce pass), no autotune launches (the runs load the
     kernel table from the tune cache).  Forwards are counted by temb_mlp_kernel dispatches.  Also a per-instantiation table."""
     import json
-    res = {"kernel_family": "conv_wino_kernel<*> + wino_ksplit_reduce_kernel", "per_instantiation": {}}
-    fam = lambda k: k.startswith("conv_wino_kernel") or k.startswith("wino_ksplit_reduce")
+    # which 3x3 family dominates is the bench line's call (bench.py: roofline.kernel); the population follows it
+    dom = ""
+    try:
+        dom = json.load(open(os.path.join(OUT, "pmc_fetch.json")))["roofline"]["kernel"]
+    except Exception:
+        pass
+    if dom.startswith("conv_wino2h_kernel"):
+        res = {"family": "wino_f16x2", "kernel_family": "conv_wino2h_kernel<*> (the reduce passes of its 3 K-split ops per forward share a kernel "
+               "with the fp32 Winograd K-split ops and are left out: 3 x 8 us of 41 ops)", "per_instantiation": {}}
+        fam = lambda k: k.startswith("conv_wino2h_kernel")
+    elif dom.startswith("conv_wino3_kernel"):
+        res = {"family": "wino_bf16x3", "kernel_family": "conv_wino3_kernel<*>", "per_instantiation": {}}
+        fam = lambda k: k.startswith("conv_wino3_kernel")
+    else:
+        res = {"family": "wino_f32", "kernel_family": "conv_wino_kernel<*> + wino_ksplit_reduce_kernel", "per_instantiation": {}}
+        fam = lambda k: k.startswith("conv_wino_kernel") or k.startswith("wino_ksplit_reduce")
     tot = {}
     for key, dirname, counter in (("fetch", "pmc_fetch", "FETCH_SIZE"), ("write", "pmc_write", "WRITE_SIZE")):
         per = defaultdict(lambda: [0, 0.0])
@@ -123,6 +137,7 @@ def traffic(out_json):
                     per[k][1] += float(r["Counter_Value"])
         res[f"forwards_{key}"] = fwd
         tot[key] = sum(v for _, v in per.values()) * 1024.0                      # rocprofv3 reports KiB
+        res[f"family_launches_{key}"] = sum(c for c, _ in per.values())
         for k, (c, v) in per.items():
             e = res["per_instantiation"].setdefault(k, {})
             e[f"launches_{key}"] = c
@@ -134,6 +149,8 @@ def traffic(out_json):
         pass
     res["wino_ops_per_forward"] = ops_per_forward
     n_ops = (ops_per_forward or 0) * res.get("forwards_fetch", 0)
+    if res["family"] != "wino_f32":
+        n_ops = res.get("family_launches_fetch", 0)             # one launch per op in these families
     res["fetch_correction"] = "x2 (gfx950 FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)"
     if n_ops:
         res["traffic_bytes_per_launch"] = (2.0 * tot["fetch"] + tot["write"]) / n_ops
