@@ -87,7 +87,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out);
 void mcvd_ctx_destroy(mcvd_ctx* ctx);
 int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
 /* options: "naive_conv", "naive_attn" (0/1: route through the simple one-thread-per-output HIP kernels, used by the
- * tests to triangulate), "conv_shape" (-1 auto; 0/1/2/3 force the 256/128/64-pixel / split-K conv tile, 4 the Winograd F(2x2,3x3) kernel where
+ * tests to triangulate; "naive_attn" 2 / 3 force the fp32-MFMA / the two-piece fp16 flash attention kernel, 0 picks by "f16x2"), "conv_shape" (-1 auto; 0/1/2/3 force the 256/128/64-pixel / split-K conv tile, 4 the Winograd F(2x2,3x3) kernel where
  * it applies (8: with its 2-way split of the input channels), 5 / 6 the all-DMA 1x1 GEMM kernel (16 / 32 channels per chunk) where it applies,
  * 10 / 11 the Winograd kernel on the bf16 matrix pipe with three-piece operands (fp32-accurate), 12 / 13 on the fp16 matrix pipe with two-piece
  * operands (22-bit operands, fp32 accumulate)), "winograd" / "conv_dma1" (1: offer the Winograd / all-DMA 1x1

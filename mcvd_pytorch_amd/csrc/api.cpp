@@ -841,7 +841,7 @@ int mcvd_op_gn_coef(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int
 
 int mcvd_op_attention(mcvd_ctx* ctx, const float* qkv, float* out, int B, int C, int heads, int HW) {
     MCVD_REQUIRE(ctx && qkv && out, "op_attention: NULL argument");
-    return (ctx->naive_attn ? launch_attention_naive : launch_attention_mfma)(qkv, out, B, C, heads, HW, ctx->stream);
+    return launch_attention(ctx->naive_attn, ctx->f16x2, qkv, out, B, C, heads, HW, ctx->stream);
 }
 
 int mcvd_op_fir2(mcvd_ctx* ctx, const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W) {

@@ -151,6 +151,12 @@ int launch_gn_finalize(const GnArgs& a, const float* st0, int np0, const float* 
 bool attention_mfma_supported(int C, int heads, int HW);      // head dim 32..256 in steps of 32, HW % 32 == 0; else the general kernel
 int launch_attention_mfma(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
 int launch_attention_naive(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
+// the flash kernel on the fp16 matrix pipe with two-piece operands (attention_h2.cpp): head dim 32..128 in steps of 32, HW % 32 == 0
+bool attention_h2_supported(int C, int heads, int HW);
+int launch_attention_h2(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
+// which attention kernel a launch takes: mode = the "naive_attn" option (0 auto: the fp16-pipe kernel when f16x2 is on and it applies,
+// else the fp32 flash kernel; 1 the one-thread-per-query kernel; 2 the fp32 flash kernel; 3 the fp16-pipe kernel where it applies)
+int launch_attention(int mode, int f16x2, const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
 
 // ------------------------------------------------------------------ FIR resampling
 int launch_fir2(const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W,

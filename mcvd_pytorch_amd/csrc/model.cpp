@@ -756,8 +756,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                                       op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B),
                                       resolve(op.dst, x, cond, out, B), B, op.H * op.W, s);
         case OP_ATTN:
-            return (ctx->naive_attn ? launch_attention_naive : launch_attention_mfma)(
-                resolve(op.src0, x, cond, out, B), resolve(op.dst, x, cond, out, B), B, op.Cout, op.heads, op.H * op.W, s);
+            return launch_attention(ctx->naive_attn, ctx->f16x2, resolve(op.src0, x, cond, out, B), resolve(op.dst, x, cond, out, B), B, op.Cout,
+                                    op.heads, op.H * op.W, s);
         default:
             set_error("forward: unknown op kind %d", (int)op.kind);
             return -1;

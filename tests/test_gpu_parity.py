@@ -435,7 +435,7 @@ def test_gn_statistics_paths_agree_on_a_forward():
                                          (2, 256, 1, 16),      # head dim 256: 65 KiB of dynamic LDS
                                          (1, 320, 1, 8),       # head dim 320 (n_head_channels = -1 on a wide level): general kernel
                                          (1, 48, 1, 8)])       # head dim not a multiple of 32: general kernel
-@pytest.mark.parametrize("naive", [0, 1], ids=["mfma", "naive"])
+@pytest.mark.parametrize("naive", [2, 1, 3], ids=["mfma", "naive", "f16x2"])
 def test_attention(ctx, B, C, heads, H, naive):
     g = _g(9)
     S = H * H
