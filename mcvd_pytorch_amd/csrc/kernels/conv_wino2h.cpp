@@ -116,6 +116,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     const int co0 = cotile * BCO;
     const int rg = __builtin_amdgcn_readfirstlane(wave >> 2);   // rows 2rg, 2rg+1 of B^T d; phase order of the wave
 
+    // prologue coefficients of this sample: requested first, so that their latency passes under the index arithmetic below
+    f32x2 cpre[2] = {{1.0f, 0.0f}, {1.0f, 0.0f}};               // Cin <= 1024: at most two table entries per thread
+    if (PRO && a.coef) {                                        // unconditional (clamped) loads: the wait belongs at the use
+#pragma unroll
+        for (int k = 0; k < 2; ++k) cpre[k] = *reinterpret_cast<const f32x2*>(a.coef + ((long)b * Cin + min(tid + k * NT, Cin - 1)) * 2);
+    }
+
     // ---- transform role: (channel pair, tile) = tid & 255.  Pair s_cp = channels (s_ca, s_ca + 2), s_ca = 4*(s_cp >> 1) + (s_cp & 1):
     //      the low and high fp16 of word (k half s_cp & 1, k pair s_cp >> 1) of the B operand.
     const int s_tile = tid & 31, s_cp = (tid & 255) >> 5;
@@ -166,10 +173,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         const unsigned* ua = wr_base + (long)(ch) * (16 * COT * 512) + (i) * (NQ * 256);                        \
         _Pragma("unroll") for (int qq = 0; qq < NQ; ++qq) { H2_QUADS(H2_LD1, (i) * NQ + qq, ua + qq * 256, 0) } \
     }
+    /* prologue: quads Q0 .. Q1-1 of chunk `ch`, issued behind the instructions that produced DEP (which read the registers) */
+#define H2_LD1D(K, R, q, P, DEP) if ((q) == K) asm volatile("global_load_dwordx4 " R ", %0, %1" :: "v"(wr_voff), "s"(P), "v"(DEP[0]), "v"(DEP[1]), "v"(DEP[2]), "v"(DEP[3]), "v"(DEP[4]), "v"(DEP[5]) : "memory");
+#define H2_LOAD_A_RANGE(ch, Q0, Q1, DEP)                                                                        \
+    {                                                                                                           \
+        const unsigned* ua = wr_base + (long)(ch) * (16 * COT * 512);                                           \
+        _Pragma("unroll") for (int qq = (Q0); qq < (Q1); ++qq) { H2_QUADS(H2_LD1D, qq, ua + qq * 256, DEP) }    \
+    }
 #define H2_WAIT(N) asm volatile("s_waitcnt vmcnt(%1)\n\ts_mov_b32 %0, 0" : "=s"(vtok) : "n"(N) : "memory");
     /* unconditional, clamped raw loads of the patch of chunk `ch` (conv_wino.cpp: WR_LOAD_P) */
 #define H2_READ_OFF(OFS) { _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) OFS[sl] = sOff[sl * NT + tid]; }
-#define H2_LOAD_P(ch, DEP, OFS)                                                                                 \
+#define H2_LOAD_P(ch, DEP, OFS) H2_LOAD_PR(ch, DEP, OFS, "v202", "v203", "v204", "v205", "v206", "v207")
+#define H2_LOAD_PR(ch, DEP, OFS, R0, R1, R2, R3, R4, R5)                                                        \
     {                                                                                                           \
         const int cb = min((ch) * CK, Cin - 1);                                                                 \
         const unsigned lim = (unsigned)((Cin - cb) * HW - 1) * 4u;                                              \
@@ -178,20 +193,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         unsigned off[MAXP];                                                                                     \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl)                                                     \
             off[sl] = min(OFS[sl], lim);      /* channels past the last one are zeroed at the write: any address inside the source will do */ \
-        asm volatile("global_load_dword v202, %0, %6\n\tglobal_load_dword v203, %1, %6\n\tglobal_load_dword v204, %2, %6\n\t" \
-                     "global_load_dword v205, %3, %6\n\tglobal_load_dword v206, %4, %6\n\tglobal_load_dword v207, %5, %6"       \
+        asm volatile("global_load_dword " R0 ", %0, %6\n\tglobal_load_dword " R1 ", %1, %6\n\tglobal_load_dword " R2 ", %2, %6\n\t" \
+                     "global_load_dword " R3 ", %3, %6\n\tglobal_load_dword " R4 ", %4, %6\n\tglobal_load_dword " R5 ", %5, %6"       \
                      :: "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "s"(srcb),           \
                         "v"(DEP[0]), "v"(DEP[1]), "v"(DEP[2]), "v"(DEP[3]), "v"(DEP[4]), "v"(DEP[5]) : "memory");           \
-    }
-    /* the same loads of the first two chunks as ordinary (compiler-tracked) loads: prologue only */
-#define H2_LOAD_Q(ch, D)                                                                                        \
-    {                                                                                                           \
-        const int cb = min((ch) * CK, Cin - 1);                                                                 \
-        const unsigned lim = (unsigned)((Cin - cb) * HW - 1) * 4u;                                              \
-        const bool second = cb >= a.C0;                                                                         \
-        const float* srcb = second ? a.x1 + ((long)b * a.C1 + (cb - a.C0)) * HW : a.x0 + ((long)b * a.C0 + cb) * HW; \
-        _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl)                                                     \
-            D[sl] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(srcb) + min(sOff[sl * NT + tid], lim)); \
     }
     /* activate once per pixel (coefficients from the LDS table) and park the patch in LDS; zero padding applies AFTER     \
        the activation */                                                                                           \
@@ -205,19 +210,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
             }                                                                                                   \
         }                                                                                                       \
     }
-#define H2_WRITE_P(ch, D, FROM_REGS, PV, cfv)                                                                    \
+#define H2_WRITE_P(ch, PV, cfv) H2_WRITE_PR(ch, PV, cfv, "v202", "v203", "v204", "v205", "v206", "v207")
+#define H2_WRITE_PR(ch, PV, cfv, R0, R1, R2, R3, R4, R5)                                                        \
     {                                                                                                           \
         float* sPw = sP + (((ch) & 1) ? PBUF : 0);                                                              \
         const int nvalid = Cin - (ch) * CK;                                                                     \
-        if (FROM_REGS) {      /* v = A * raw + B straight out of the patch registers (PRO 0: A = 1, B = 0, exact) */ \
-            asm("v_fma_f32 %0, v202, %6, %7\n\tv_fma_f32 %1, v203, %8, %9\n\tv_fma_f32 %2, v204, %10, %11\n\t"            \
-                         "v_fma_f32 %3, v205, %12, %13\n\tv_fma_f32 %4, v206, %14, %15\n\tv_fma_f32 %5, v207, %16, %17"    \
-                : "=&v"(PV[0]), "=&v"(PV[1]), "=&v"(PV[2]), "=&v"(PV[3]), "=&v"(PV[4]), "=&v"(PV[5])                      \
-                : "v"(cfv[0].x), "v"(cfv[0].y), "v"(cfv[1].x), "v"(cfv[1].y), "v"(cfv[2].x), "v"(cfv[2].y),               \
-                  "v"(cfv[3].x), "v"(cfv[3].y), "v"(cfv[4].x), "v"(cfv[4].y), "v"(cfv[5].x), "v"(cfv[5].y), "s"(vtok));   \
-        } else {                                                                                                \
-            _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) PV[sl] = PRO >= 1 ? __builtin_fmaf(D[sl], cfv[sl].x, cfv[sl].y) : D[sl]; \
-        }                                                                                                       \
+        /* v = A * raw + B straight out of the patch registers (PRO 0: A = 1, B = 0, exact) */                  \
+        asm("v_fma_f32 %0, " R0 ", %6, %7\n\tv_fma_f32 %1, " R1 ", %8, %9\n\tv_fma_f32 %2, " R2 ", %10, %11\n\t"             \
+                     "v_fma_f32 %3, " R3 ", %12, %13\n\tv_fma_f32 %4, " R4 ", %14, %15\n\tv_fma_f32 %5, " R5 ", %16, %17"     \
+            : "=&v"(PV[0]), "=&v"(PV[1]), "=&v"(PV[2]), "=&v"(PV[3]), "=&v"(PV[4]), "=&v"(PV[5])                          \
+            : "v"(cfv[0].x), "v"(cfv[0].y), "v"(cfv[1].x), "v"(cfv[1].y), "v"(cfv[2].x), "v"(cfv[2].y),                   \
+              "v"(cfv[3].x), "v"(cfv[3].y), "v"(cfv[4].x), "v"(cfv[4].y), "v"(cfv[5].x), "v"(cfv[5].y), "s"(vtok));       \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
             float v = PV[sl];                                                                                   \
             if (PRO >= 2) v = silu_h2(v);                                                                       \
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         if (!(EXP & 1)) H2_READ_R((ch) + 1, rw)                                                                 \
         if (!(EXP & 4)) H2_WAIT(NA)                                                                             \
         float pv[MAXP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                        \
-        if (!(EXP & 2)) H2_WRITE_P((ch) + 2, q0, true, pv, cfv)                                                 \
+        if (!(EXP & 2)) H2_WRITE_P((ch) + 2, pv, cfv)                                                           \
         if (!(EXP & 4)) H2_LOAD_P((ch) + 3, pv, ofs)                                                            \
         if (!(EXP & 1)) H2_WRITE_V((ch) + 1, RG, rw)                                                            \
     }
@@ -309,7 +312,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
             for (int r = 0; r < 16; ++r) acc[i][ct][r] = 0.0f;
 
     // diagnostics (mcvd_ctx_set_debug_buffer): shader-clock time the wave a.wdma spends per phase
-    const bool rec = a.dbg != nullptr && wave == a.wdma;
+    const bool rec = a.dbg != nullptr && wave == (a.wdma & 63);
+    const bool sub = (a.wdma & 64) != 0;           // record prologue / epilogue sub-phase stamps instead of the wall clock
+    unsigned long long sp[3] = {0, 0, 0};
     unsigned long long tk0 = 0, tprev = 0, dt[2] = {0, 0}, rt0 = 0;
     if (rec) {
         rt0 = __builtin_amdgcn_s_memrealtime();          // constant 100 MHz: start / end of the workgroup on the wall clock
@@ -327,38 +332,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     const int ksp = a.ksplit == 2 ? 2 : 1, kh = ksp == 2 ? (int)blockIdx.y : 0;
     const int c_begin = kh * (nch_all / ksp), c_end = c_begin + nch_all / ksp;
 
-    // ---- prologue: every global load of the first chunks + the coefficient table is issued before anything waits
-    float q0[MAXP], q1[MAXP];                           // patches of the first two chunks: prologue only
+    // ---- prologue.  Issue order = need order: the raw patches of the first two chunks (into the registers of weight quads 0-2, which
+    // are not needed before the first MFMA phase), the patch of the third chunk, then the weight quads 3.. of the first chunk.  The
+    // first two patches are activated and parked as soon as THEY have landed (the weights, 3/4 of the bytes, are still in flight);
+    // quads 0-2 follow once their registers have been read.  (With one wait for everything the prologue took 10-12 k cycles, of
+    // which 5-8 k went into pulling ~130 KB through the CU's memory pipe before any work started: profiles/r02_wino2h_prologue.txt.)
     int vtok = 0;                                       // ordering token: written by every VMEM wait, an operand of the register reads
     {
-        f32x2 cfl = {1.0f, 0.0f};
-        H2_LOAD_A(c_begin, 0)
-        H2_LOAD_A(c_begin, 1)
-        H2_LOAD_Q(c_begin, q0)
-        H2_LOAD_Q(c_begin + 1, q1)
+        float nodep[MAXP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (PRO) {                         // (the compiler waits for the coefficient loads here: nothing else is in flight yet)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (tid + k * NT < Cin) *reinterpret_cast<f32x2*>(sCo + (tid + k * NT) * 2) = cpre[k];
+        }
         {
             unsigned ofs[MAXP];
             H2_READ_OFF(ofs)
-            H2_LOAD_P(c_begin + 2, q0, ofs)
+            H2_LOAD_PR(c_begin, nodep, ofs, "v208", "v209", "v210", "v211", "v212", "v213")
+            H2_LOAD_PR(c_begin + 1, nodep, ofs, "v214", "v215", "v216", "v217", "v218", "v219")
+            H2_LOAD_P(c_begin + 2, nodep, ofs)
         }
-        if (PRO) {
-            for (int c = tid; c < Cin; c += NT) {
-                if (a.coef) cfl = *reinterpret_cast<const f32x2*>(a.coef + ((long)b * Cin + c) * 2);
-                *reinterpret_cast<f32x2*>(sCo + c * 2) = cfl;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ONE memory latency for everything above
+        H2_LOAD_A_RANGE(c_begin, 3, NA, nodep)
         if (PRO) __syncthreads();          // coefficient table visible
+        if (rec) sp[0] = __builtin_amdgcn_s_memtime() - tk0;      // loads issued
+        H2_WAIT(MAXP + NA - 3)             // the two patches have landed; younger: patch(c_begin + 2), quads 3..
+        if (rec) sp[1] = __builtin_amdgcn_s_memtime() - tk0;      // first patches landed
         {
-            float pv[MAXP];
+            float pv0[MAXP], pv1[MAXP];
             f32x2 cf0[MAXP], cf1[MAXP];
             H2_READ_C(c_begin, cf0)
             H2_READ_C(c_begin + 1, cf1)
-            H2_WRITE_P(c_begin, q0, false, pv, cf0)
-            H2_WRITE_P(c_begin + 1, q1, false, pv, cf1)
+            H2_WRITE_PR(c_begin, pv0, cf0, "v208", "v209", "v210", "v211", "v212", "v213")
+            H2_WRITE_PR(c_begin + 1, pv1, cf1, "v214", "v215", "v216", "v217", "v218", "v219")
+            float dep[MAXP];
+            _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) dep[sl] = pv0[sl] + pv1[sl];
+            H2_LOAD_A_RANGE(c_begin, 0, NA < 3 ? NA : 3, dep)
         }
     }
     __syncthreads();                       // the first two patches visible
+    if (rec) sp[2] = __builtin_amdgcn_s_memtime() - tk0;          // first two patches activated and parked
     {
         f32x2 rw[3][4];
         H2_READ_R(c_begin, rw)
@@ -373,6 +385,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     //   patch(c+2) before its write: one chunk's weight loads were issued after it                              vmcnt(NA)
     //   weights(c) of a position before its MFMAs: see H2_MFMA_PHASE                                            vmcnt(VM_A)
     // (the loads still in flight when a loop is left target registers the compiler does not know: one wait behind the loops)
+    H2_WAIT(0)                             // weight quads 0-2 were issued last: the loop's in-order counts start from an empty queue
     const int ph = (EXP & 128) ? __builtin_amdgcn_readfirstlane(wave & 1) : rg;     // phase order of the wave
     if (ph == 0) {
         for (int c = c_begin; c + 1 < c_end; ++c) {
@@ -488,6 +501,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             d[0] = dt[0]; d[1] = dt[1]; d[2] = rt0; d[3] = __builtin_amdgcn_s_memrealtime();
             d[4] = ((unsigned long long)xcc << 32) | hwid;          // which CU ran it (gpu_diag.py w2htl: per-CU timeline)
+            if (sub) { d[2] = sp[0]; d[3] = sp[1]; d[4] = sp[2]; }   // MCVD_DBG_WAVE >= 64: prologue sub-phases (cycles from the start)
             d[5] = now - tprev;            // epilogue
             d[6] = (unsigned long long)(c_end - c_begin);
             d[7] = now - tk0;
@@ -499,7 +513,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
 #undef H2_LD1
 #undef H2_MF1
 #undef H2_LOAD_P
-#undef H2_LOAD_Q
+#undef H2_LOAD_PR
+#undef H2_WRITE_PR
+#undef H2_LD1D
+#undef H2_LOAD_A_RANGE
 #undef H2_WAIT
 #undef H2_WRITE_P
 #undef H2_WRITE_V

@@ -462,6 +462,35 @@ def w2htl(f):
     ctx.opt("conv_cot", 0)
 
 
+def w2hsub(f):
+    """Prologue sub-phases of conv_wino2h_kernel (cycles from the workgroup's first stamp, averaged over the workgroups): loads
+    issued, loads landed, first two patches activated + parked (barrier passed), whole prologue (first V tile visible)."""
+    from tests.hiputil import Ctx, P
+    ctx = Ctx()
+    B = 64
+    for cin, cout, H in [(96, 96, 64), (192, 192, 32), (480, 192, 32)]:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda")
+        ctx.opt("conv_shape", 12)
+        for _ in range(3):
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+        for wv in (0, 5):
+            os.environ["MCVD_DBG_WAVE"] = str(64 + wv)
+            dbg = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
+            _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
+            d = dbg.view(-1, 8).cpu().double()
+            d = d[d[:, 7] > 0].mean(0)
+            f.write(f"cin{cin} cout{cout} H{H} wave {wv}: loads issued {d[2].item():6.0f}  landed {d[3].item():6.0f}  patches parked {d[4].item():6.0f}  prologue {d[0].item():6.0f}"
+                    f" | loop {d[1].item():7.0f} ({d[1].item() / max(d[6].item() - 1, 1):5.0f} per chunk)  epilogue {d[5].item():6.0f}  total {d[7].item():7.0f}\n")
+    os.environ["MCVD_DBG_WAVE"] = "0"
+    ctx.opt("conv_shape", -1)
+
+
 def convops(f):
     """Per-op times of the 3x3 convs of one instrumented forward (BASELINE config 2, B = 64): kernel the autotuner chose and ms,
     with the split-operand bf16 Winograd kernel offered (MCVD_BF16X3 unset) -- run again with MCVD_BF16X3=0 for the fp32 table."""
@@ -503,6 +532,6 @@ if __name__ == "__main__":
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "convops": convops, "sweep1": sweep1, "w2htl": w2htl}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "convops": convops, "sweep1": sweep1, "w2htl": w2htl, "w2hsub": w2hsub}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 
