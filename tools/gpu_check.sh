@@ -37,7 +37,7 @@ bench2)
   echo "bench2 rc=$?" >> gpurun_out/bench_2proc.err; cat gpurun_out/bench_2proc.json | cut -c1-600; tail -3 gpurun_out/bench_2proc.err;;
 others)
   for c in smmnist_big5 kth64_big_ngf128 bair_big_spade cityscapes_big cityscapes_big_variant; do
-    for g in 0 1; do
+    for g in ${GRAPHS:-1}; do
       timeout 900 python bench.py --config $c --steps 1 --warmup 1 --graph $g --no-cpu-baseline > gpurun_out/bench_other_${c}_g$g.json 2> gpurun_out/bench_other_${c}_g$g.err
       python -c "import json;d=json.load(open('gpurun_out/bench_other_${c}_g$g.json'));print('$c graph$g', d['value'], d['ms_per_step'], d['roofline']['frac'])"
     done
