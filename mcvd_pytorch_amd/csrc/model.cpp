@@ -673,6 +673,10 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             if (ctx->conv_shape < 0 && tuned_B == B && oi < tuned_shape.size() && tuned_shape[oi] >= 0) {
                 a.shape_hint = tuned_shape[oi];
                 a.cot = tuned_cot[oi];
+                if (!ctx->f16x2 && a.shape_hint >= 12 && a.shape_hint <= 14) {        // an imported table from an f16x2 run: the option wins
+                    a.shape_hint = a.shape_hint == 12 ? 4 : a.shape_hint == 13 ? 8 : 5;
+                    a.cot = op.cot;
+                }
             }
             // epilogue statistics from the 3x3 (Winograd) producers; the 1x1 GEMM's epilogue can emit them too, but its 16*COT
             // 32-lane reductions per wave cost the NIN_3 launches more than the norms they spare save (measured): "gn_stats" = 2 only
@@ -903,6 +907,14 @@ int mcvd_model::autotune(int B) {
 
 int mcvd_model::prepare_B(int B) {
     if (int rc = ensure_workspace(B)) return rc;
+    // the options that decide which kernels the autotuner may offer: a table tuned (or imported) under other settings is dropped --
+    // "f16x2" = 0 must really mean that no two-piece fp16 kernel runs
+    const int sig = (ctx->winograd ? 1 : 0) | (ctx->conv_dma1 ? 2 : 0) | (ctx->bf16x3 ? 4 : 0) | (ctx->f16x2 ? 8 : 0) |
+                    (ctx->spade_fuse ? 16 : 0) | (ctx->conv_wdma ? 32 : 0);
+    if (sig != tuned_sig) {
+        if (tuned_sig >= 0) { tuned_cache.clear(); tuned_B = 0; }
+        tuned_sig = sig;
+    }
     if (ctx->autotune && !ctx->naive_conv && tuned_B != B) {
         auto it = tuned_cache.find(B);
         if (it != tuned_cache.end() && it->second.first.size() == ops.size()) {     // tuned (or imported) before: no timing launches

@@ -166,6 +166,7 @@ struct mcvd_model {
     std::vector<int> stats_np;        // per op: partials per (sample, channel) its last launch wrote (0: none)
     std::vector<int> tuned_shape, tuned_cot;
     int tuned_B = 0;
+    int tuned_sig = -1;            // the kernel-offer options (winograd, conv_dma1, bf16x3, f16x2, spade_fuse, conv_wdma) the tables were tuned under
     // every batch size tuned (or imported through mcvd_model_set_tuning) so far: alternating batch sizes do not re-tune
     std::map<int, std::pair<std::vector<int>, std::vector<int>>> tuned_cache;
     int autotune(int B);

@@ -543,6 +543,39 @@ def test_forward_vs_reference_golden(golden_dir, fx, naive):
     assert (eps.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
+def test_f16x2_option_is_authoritative():
+    """`f16x2` = 0 must mean that no two-piece fp16 kernel runs, also when the model was tuned with them on before: the kernel table
+    is dropped and re-tuned among the fp32-accurate kernels (and the attention takes the fp32 flash kernel); the outputs of the two
+    settings agree to fp32 noise and differ bitwise."""
+    import ctypes as C
+    from mcvd_pytorch_amd import _lib
+    config, sd, net = _net("smmnist_big5")
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    x, cond = x.cuda(), cond.cuda()
+    t = torch.full((2,), 500, dtype=torch.long, device="cuda")
+
+    def families():
+        n = _lib.lib.mcvd_model_profile_read(net._model, None, None, None, None, None, 0)
+        info, fams = (C.c_int * 8)(), set()
+        for i in range(n):
+            _lib.check(_lib.lib.mcvd_model_op_info(net._model, i, info), "op_info")
+            if info[0] == 3 and (info[6] >> 12):
+                fams.add((info[6] >> 4) & 15)
+        return fams
+
+    net.set_option("f16x2", 1)
+    a = net(x, t, cond=cond).clone()
+    on = families()
+    assert on & {12, 13, 14}, f"the f16x2 kernels were offered and never chosen: {sorted(on)}"
+    net.set_option("f16x2", 0)
+    b = net(x, t, cond=cond).clone()
+    off = families()
+    assert not (off & {12, 13, 14}), f"f16x2 = 0 but the table holds {sorted(off)}"
+    net.set_option("f16x2", 1)
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    assert not torch.equal(a, b)
+
+
 @pytest.mark.parametrize("shape", [4, 10, 11, 12, 13])
 def test_forward_is_bit_deterministic(shape):
     """300 forwards of BASELINE config 1 (B = 2) with every 3x3 conv forced onto one Winograd kernel must be bit-identical.  The

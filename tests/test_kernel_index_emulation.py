@@ -109,3 +109,113 @@ def test_gemm1x1_index_maps(B, C0, C1, Cout, H, W, COT, pro, CK):
         xin = xin * torch.sigmoid(xin)
     want = (F.conv2d(xin.double(), w.double(), bias.double()) + res.double()) * 0.5
     np.testing.assert_allclose(got, want.numpy(), rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ two-piece fp16 kernels
+# The f16x2 kernels read pre-split weights in an operand-major layout written by the pack kernels, and B operands the staging
+# threads park in LDS.  Both sides must agree on (a) where a (cout, cin, position, piece) halfword lives and (b) the K-slot
+# convention of the 32x32x16 MFMA (lane half h, element e <-> channel 2e + h of the 16-channel chunk).  The index arithmetic of
+# conv_wino2h.cpp / conv1x1_h2.cpp is restated here lane by lane; the product of the operands as the MFMA would contract them must
+# equal the plain contraction.  Pieces are marked by a factor (piece 1 = f * piece 0) so that a mixed-up piece shows.
+def _mfma_32x32x16(A, Bm):
+    """A[m][h][e], Bm[n][h][e] -> D[m][n]: both operands hold K slot (h, e) of their row / column."""
+    return np.einsum("mhe,nhe->mn", A, Bm)
+
+
+@pytest.mark.parametrize("COT,Cout,Cin,CinP", [(3, 192, 40, 48), (2, 128, 32, 32), (1, 32, 16, 16)])
+def test_wino2h_operand_layout(COT, Cout, Cin, CinP):
+    rng = np.random.default_rng(0)
+    BCO, CoutP, nch = 32 * COT, Cout, CinP // 16
+    U = rng.standard_normal((Cout, CinP, 16))
+    U[:, Cin:] = 0
+    mem = np.zeros(CinP * 16 * CoutP * 2)                       # halfwords behind the header (pack_wino2h_weight_kernel)
+    for co in range(Cout):
+        for ci in range(Cin):
+            cotile, ct, cc = co // BCO, (co % BCO) // 32, ci & 15
+            h, el = cc & 1, cc >> 1
+            lane = h * 32 + (co & 31)
+            base = (((cotile * nch + (ci >> 4)) * 16) * COT + ct) * 1024 + (lane * 4 + (el >> 1)) * 2 + (el & 1)
+            for xi in range(16):
+                mem[base + xi * COT * 1024] = U[co, ci, xi]
+                mem[base + xi * COT * 1024 + 512] = 7.0 * U[co, ci, xi]
+    chunk = nch - 1
+    V = rng.standard_normal((16, 16, 32))                       # [channel in chunk][position][tile]
+    sV = np.zeros((2 * 16 * 2 * 4 * 32, 2))                     # H2_WRITE_V: words [piece][position][half][pair][tile] = (lo, hi)
+    for tid in range(512):
+        rg, s_tile, s_cp = (tid >> 6) >> 2, tid & 31, (tid & 255) >> 5
+        s_ca = 4 * (s_cp >> 1) + (s_cp & 1)
+        v_wr = ((8 * rg * 2 + (s_cp & 1)) * 4 + (s_cp >> 1)) * 32 + s_tile
+        for row in range(2):
+            for q in range(4):
+                xi = (2 * rg + row) * 4 + q
+                sV[v_wr + (row * 4 + q) * 256] = (V[s_ca, xi, s_tile], V[s_ca + 2, xi, s_tile])
+                sV[v_wr + (row * 4 + q) * 256 + 4096] = (3 * V[s_ca, xi, s_tile], 3 * V[s_ca + 2, xi, s_tile])
+    for cotile in range(Cout // BCO):
+        for wave in range(8):
+            for i in range(2):
+                xi = 2 * wave + i
+                for ct in range(COT):
+                    for pa, pb, f in ((0, 1, 3.0), (1, 0, 7.0), (0, 0, 1.0)):          # u1 v2, u2 v1, u1 v1
+                        A, Bm = np.zeros((32, 2, 8)), np.zeros((32, 2, 8))
+                        for lane in range(64):
+                            half, l31 = lane >> 5, lane & 31
+                            q = (i * COT + ct) * 2 + pa                                 # H2_LOAD_A / H2_MF1: quad of (position, sub-tile, piece)
+                            dw0 = (cotile * nch * 16 + 2 * wave) * COT * 512 + chunk * (16 * COT * 512) + q * 256 + lane * 4
+                            A[l31, half] = [mem[(dw0 + j) * 2 + k] for j in range(4) for k in range(2)]
+                            qb = (((2 * wave + i) * 2 + half) * 4) * 32 + l31           # H2_LOAD_B
+                            Bm[l31, half] = [sV[pb * 4096 + qb + jp * 32][k] for jp in range(4) for k in range(2)]
+                        co0 = cotile * BCO + ct * 32
+                        want = f * np.einsum("mc,cn->mn", U[co0:co0 + 32, chunk * 16:chunk * 16 + 16, xi], V[:, xi, :])
+                        assert np.allclose(_mfma_32x32x16(A, Bm), want), (cotile, wave, i, ct, pa, pb)
+
+
+@pytest.mark.parametrize("COT,CinP,CoutP", [(3, 32, 192), (2, 16, 128), (1, 32, 96), (4, 16, 128)])
+def test_conv1x1_h2_operand_layout(COT, CinP, CoutP):
+    rng = np.random.default_rng(1)
+    NS, WPC = CoutP // 32, COT * 128
+    W = rng.standard_normal((CinP, CoutP))
+    mem = np.zeros(CinP * CoutP * 2)                            # pack_conv1x1_h2_kernel
+    for ci in range(CinP):
+        for co in range(CoutP):
+            cc = ci & 15
+            h, el = cc & 1, cc >> 1
+            lane = h * 32 + (co & 31)
+            o = (((ci >> 4) * NS + (co >> 5)) * 2) * 512 + (lane * 4 + (el >> 1)) * 2 + (el & 1)
+            mem[o], mem[o + 512] = W[ci, co], 5.0 * W[ci, co]
+    X = rng.standard_normal((CinP, 128))
+    for ctile in range(CoutP // (32 * COT)):
+        for ch in range(CinP // 16):
+            lds = np.full(COT * 2 * 256 * 2, np.nan)            # the chunk's LDS image, filled by the DMA rounds (Q1_DMA)
+            for s in range((WPC + 255) // 256):
+                for wave in range(4):
+                    q0 = (s * 256 + wave * 64) % WPC
+                    for lane in range(64):
+                        g = (ch * NS + ctile * COT) * 512 + (q0 + lane) * 4             # global dword of the lane's 16 bytes
+                        lds[(q0 + lane) * 8:(q0 + lane) * 8 + 8] = mem[g * 2:g * 2 + 8]
+            assert not np.isnan(lds).any()
+            Bm = np.zeros((128, 2, 8))
+            for n in range(128):
+                for h in range(2):
+                    Bm[n, h] = [X[ch * 16 + 2 * e + h, n] for e in range(8)]
+            for ct in range(COT):
+                for piece, f in ((0, 1.0), (1, 5.0)):
+                    A = np.zeros((32, 2, 8))
+                    for lane in range(64):
+                        idx = ((ct * 2 + piece) * 64 + lane) * 8
+                        A[lane & 31, lane >> 5] = lds[idx:idx + 8]
+                    co0 = (ctile * COT + ct) * 32
+                    want = f * np.einsum("cm,cn->mn", W[ch * 16:ch * 16 + 16, co0:co0 + 32], X[ch * 16:ch * 16 + 16])
+                    assert np.allclose(_mfma_32x32x16(A, Bm), want), (ctile, ch, ct, piece)
+
+
+def test_attention_h2_key_slot_convention():
+    """PV product of attention_h2.cpp: the staging thread that holds keys 4q .. 4q+3 of a channel writes dwords (j0, j0 + 1) of lane
+    half h in step s2; the probabilities of lane half h sit in accumulator registers r = 8 s2 + e with key (r&3) + 8 (r>>2) + 4h.
+    Both must name the same key for every (h, s2, dword j, low / high half)."""
+    for q in range(8):
+        h, s2, j0 = q & 1, q >> 2, 2 * ((q >> 1) & 1)
+        for pair in range(2):
+            for bhalf in range(2):
+                key_staged = 4 * q + 2 * pair + bhalf
+                r = 8 * s2 + 2 * (j0 + pair) + bhalf
+                assert (r & 3) + 8 * (r >> 2) + 4 * h == key_staged
