@@ -768,7 +768,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     const size_t wfloats = (size_t)a.CinP * ks * ks * a.CoutP;
     const bool wino = (ctx->conv_shape == 4 || ctx->conv_shape == 8 || (ctx->conv_shape >= 10 && ctx->conv_shape <= 13)) &&
                       conv_wino_supported(ks, H, W);
-    const bool wino_h = wino && (ctx->conv_shape == 12 || ctx->conv_shape == 13) && !(H == 8 && W == 8);     // fp16 pieces as well
+    const bool wino_h = wino && (ctx->conv_shape == 12 || ctx->conv_shape == 13);     // fp16 pieces as well
     const size_t ufloats = wino ? (size_t)a.CinP * 16 * a.CoutP : 0;
     const size_t hfloats = wino_h ? (size_t)((conv_wino2h_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4)
                                   : (ks == 1 && ctx->conv_shape == 14) ? (size_t)((conv1x1_h2_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4) : 0;

@@ -78,14 +78,17 @@ __device__ __forceinline__ void h2_split2(f32x2 v, unsigned& w1, unsigned& w2) {
 // a.ksplit == 2 (grid.y = 2): half of the input channels per workgroup, raw partial result to a.part[half] (conv_wino.cpp).
 // EXP != 0: timing-only ablations of the K loop (wrong results; env MCVD_WINO2H_EXP, tests/gpu_diag.py w3exp): bit 0 no tile
 //     transform, bit 1 no patch activation/park, bit 2 no VMEM in the loop, bit 3 no B-operand reads, bit 4 no MFMA.
-template <int COT, int PRO, int EXP = 0>
+// G8: 8x8 images -- the 32 tiles of a workgroup are TWO whole images (16 tiles each, image i at patch columns 10 i .. 10 i + 9); every
+//     halo element is zero padding, so only the 2 x 64 interior pixels per channel are loaded (slots 0-3 of the six; the other two
+//     fetch a dummy) and the halo of both patch buffers is zeroed once.  The coefficient table holds both samples.
+template <int COT, int PRO, bool G8, int EXP = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void conv_wino2h_kernel(ConvArgs a) {
     // amdgpu_num_vgpr(202): registers the compiler may allocate; v202-v255 hold the in-flight loads and the A operands (H2_LOAD_A)
     constexpr int NT = H2_NT, CK = H2_CK, T = H2_T, BCO = 32 * COT, PP = H2_PP, VW = H2_VW;
     constexpr int PSZ = CK * 10 * PP;           // activated input patch of one chunk: [CK][10 rows][PP]
     constexpr int PBUF = PSZ + 4;               // + dump space for unused patch slots
-    constexpr int PCOUNT = CK * 10 * 18;        // patch elements loaded per chunk
-    constexpr int MAXP = (PCOUNT + NT - 1) / NT;                // 6 loads per thread and chunk
+    constexpr int PCOUNT = G8 ? CK * 2 * 64 : CK * 10 * 18;     // patch elements loaded per chunk
+    constexpr int MAXP = 6;                                     // load slots per thread and chunk (G8 uses four of them)
     constexpr int NQ = 2 * COT;                                 // weight quads per position: COT cout sub-tiles x 2 pieces
     constexpr int NA = 2 * NQ;                                  // weight loads per wave and chunk
     constexpr int VM_A = NQ + MAXP;                             // see H2_MFMA_PHASE
@@ -93,8 +96,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned* sV = reinterpret_cast<unsigned*>(smem);           // [2][VW]
     float* sP = smem + 2 * VW;                  // [2][PBUF]
-    float* sCo = sP + 2 * PBUF;                 // [Cin][2] prologue coefficients (A_c, B_c) of this sample (PRO only)
-    unsigned* sOff = reinterpret_cast<unsigned*>(sCo + 2 * a.Cin);      // [MAXP][NT] byte offsets of the patch-load slots (read by their owner only)
+    float* sCo = sP + 2 * PBUF;                 // [Cin][2] prologue coefficients (A_c, B_c) of this sample (PRO only; G8: [2][Cin][2])
+    unsigned* sOff = reinterpret_cast<unsigned*>(sCo + (G8 ? 4 : 2) * a.Cin);      // [MAXP][NT] byte offsets of the patch-load slots (read by their owner only)
 
     {   // the kernel descriptor must allocate all 256 registers: the asm statements below name v202-v255 in their text only
         float top;
@@ -102,44 +105,60 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int H = a.H, W = a.W, HW = H * W, Cin = a.Cin;
-    const int rx_n = W >> 4, ry_n = H >> 3;
-    const int nreg = a.B * rx_n * ry_n;
+    const int rx_n = G8 ? 1 : W >> 4, ry_n = G8 ? 1 : H >> 3;
+    const int nreg = G8 ? (a.B + 1) >> 1 : a.B * rx_n * ry_n;
     // block id -> (region, cout tile): the cout tiles of one region run at the same time on the same XCD (conv_wino.cpp)
     const int nct = a.CoutP / BCO;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int reg_id = (slot / nct) * 8 + xcd;
     const int cotile = slot - (slot / nct) * nct;
     if (reg_id >= nreg) return;
-    const int b = reg_id / (rx_n * ry_n);
-    const int rr = reg_id - b * (rx_n * ry_n);
+    const int b = G8 ? 2 * reg_id : reg_id / (rx_n * ry_n);      // (first) sample of the region
+    const int rr = G8 ? 0 : reg_id - b * (rx_n * ry_n);
     const int oy0 = (rr / rx_n) * 8, ox0 = (rr % rx_n) * 16;
     const int co0 = cotile * BCO;
     const int rg = __builtin_amdgcn_readfirstlane(wave >> 2);   // rows 2rg, 2rg+1 of B^T d; phase order of the wave
 
     // prologue coefficients of this sample: requested first, so that their latency passes under the index arithmetic below
-    f32x2 cpre[2] = {{1.0f, 0.0f}, {1.0f, 0.0f}};               // Cin <= 1024: at most two table entries per thread
+    f32x2 cpre[2] = {{1.0f, 0.0f}, {1.0f, 0.0f}};               // Cin <= 1024: at most two table entries per thread (and sample)
+    f32x2 cpre2[2] = {{1.0f, 0.0f}, {1.0f, 0.0f}};              // G8: the region's second sample (clamped to the last one)
     if (PRO && a.coef) {                                        // unconditional (clamped) loads: the wait belongs at the use
 #pragma unroll
-        for (int k = 0; k < 2; ++k) cpre[k] = *reinterpret_cast<const f32x2*>(a.coef + ((long)b * Cin + min(tid + k * NT, Cin - 1)) * 2);
+        for (int k = 0; k < 2; ++k) {
+            cpre[k] = *reinterpret_cast<const f32x2*>(a.coef + ((long)b * Cin + min(tid + k * NT, Cin - 1)) * 2);
+            if (G8) cpre2[k] = *reinterpret_cast<const f32x2*>(a.coef + ((long)min(b + 1, a.B - 1) * Cin + min(tid + k * NT, Cin - 1)) * 2);
+        }
     }
 
     // ---- transform role: (channel pair, tile) = tid & 255.  Pair s_cp = channels (s_ca, s_ca + 2), s_ca = 4*(s_cp >> 1) + (s_cp & 1):
     //      the low and high fp16 of word (k half s_cp & 1, k pair s_cp >> 1) of the B operand.
     const int s_tile = tid & 31, s_cp = (tid & 255) >> 5;
-    const int s_ty = s_tile >> 3, s_tx = s_tile & 7;
+    const int s_ty = G8 ? (s_tile >> 2) & 3 : s_tile >> 3, s_tx = G8 ? (s_tile & 3) + 5 * (s_tile >> 4) : s_tile & 7;
     // LDS patch: [pair 8][10 rows][PP columns][2 channels] floats.  Rows rg, rg+1, rg+2 of the tile's 4x4 window:
     const int p_rd = ((s_cp * 10 + 2 * s_ty + rg) * PP + 2 * s_tx) * 2;
     // word of (piece 0, position 8*rg, half, pair, tile); one position further = 256 words, one piece = 4096
     const int v_wr = ((8 * rg * 2 + (s_cp & 1)) * 4 + (s_cp >> 1)) * T + s_tile;
 
     // ---- patch-load slots (chunk invariant): p_pk = LDS float index of the element (12 bits) | channel code << 12, code = channel
-    // in chunk, + CK when the element is padding / unused; sOff[sl][tid] = byte offset of the (clamped) pixel from the chunk's first
-    // channel plane (parked in LDS: six registers the MFMA phase needs more)
+    // in chunk, + CK when the element is padding / unused (| G8: image of the region << 20); sOff[sl][tid] = byte offset of the
+    // (clamped) pixel from the chunk's first channel plane (parked in LDS: six registers the MFMA phase needs more)
     unsigned p_pk[MAXP];
 #pragma unroll
     for (int sl = 0; sl < MAXP; ++sl) {
         const int e = sl * NT + tid;
-        if (e < PCOUNT) {
+        if (G8) {
+            if (e < PCOUNT) {                   // e -> (channel, image, row, col) of an interior pixel
+                const int ci = e >> 7, img = (e >> 6) & 1, r = (e >> 3) & 7, c = e & 7;
+                const bool valid = b + img < a.B;
+                const int cp = (ci >> 2) * 2 + (ci & 1), ce = (ci >> 1) & 1;
+                p_pk[sl] = (unsigned)(((cp * 10 + r + 1) * PP + img * 10 + c + 1) * 2 + ce) | ((unsigned)(ci + (valid ? 0 : CK)) << 12) |
+                           ((unsigned)(valid ? img : 0) << 20);
+                sOff[sl * NT + tid] = (unsigned)(ci * HW + r * 8 + c) * 4u;
+            } else {
+                p_pk[sl] = (unsigned)PSZ | ((unsigned)CK << 12);
+                sOff[sl * NT + tid] = 0;
+            }
+        } else if (e < PCOUNT) {
             const int ci = e / 180, rem = e - ci * 180;
             const int r = rem / 18, c = rem - r * 18;
             const int y = oy0 - 1 + r, x = ox0 - 1 + c;
@@ -190,9 +209,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         const unsigned lim = (unsigned)((Cin - cb) * HW - 1) * 4u;                                              \
         const bool second = cb >= a.C0;                                                                         \
         const float* srcb = second ? a.x1 + ((long)b * a.C1 + (cb - a.C0)) * HW : a.x0 + ((long)b * a.C0 + cb) * HW; \
+        const unsigned istride = (unsigned)((second ? a.C1 : a.C0) * HW) * 4u;      /* G8: distance to the region's second sample */ \
         unsigned off[MAXP];                                                                                     \
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl)                                                     \
-            off[sl] = min(OFS[sl], lim);      /* channels past the last one are zeroed at the write: any address inside the source will do */ \
+            off[sl] = min(OFS[sl], lim) + (G8 ? ((p_pk[sl] >> 20) & 1u) * istride : 0u);      /* channels past the last one are zeroed at the write: any address inside the source will do */ \
         asm volatile("global_load_dword " R0 ", %0, %6\n\tglobal_load_dword " R1 ", %1, %6\n\tglobal_load_dword " R2 ", %2, %6\n\t" \
                      "global_load_dword " R3 ", %3, %6\n\tglobal_load_dword " R4 ", %4, %6\n\tglobal_load_dword " R5 ", %5, %6"       \
                      :: "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "s"(srcb),           \
@@ -205,7 +225,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
             cfv[sl] = f32x2{1.0f, 0.0f};                                                                        \
             if (PRO >= 1) {                                                                                     \
-                const int cch = min((ch) * CK + (int)((p_pk[sl] >> 12) & (CK - 1)), Cin - 1);                   \
+                const int cch = min((ch) * CK + (int)((p_pk[sl] >> 12) & (CK - 1)), Cin - 1) + (G8 ? (int)((p_pk[sl] >> 20) & 1u) * Cin : 0); \
                 cfv[sl] = *reinterpret_cast<const f32x2*>(sCo + cch * 2);                                       \
             }                                                                                                   \
         }                                                                                                       \
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
             float v = PV[sl];                                                                                   \
             if (PRO >= 2) v = silu_h2(v);                                                                       \
-            sPw[p_pk[sl] & 0xfff] = ((int)(p_pk[sl] >> 12) < min(nvalid, CK)) ? v * H2_ACT_SCALE : 0.0f;       \
+            sPw[p_pk[sl] & 0xfff] = ((int)((p_pk[sl] >> 12) & 0xff) < min(nvalid, CK)) ? v * H2_ACT_SCALE : 0.0f; \
         }                                                                                                       \
     }
     /* rows 2rg and 2rg+1 of B^T d for the two channels of the pair (packed fp32: .x = channel s_ca, .y = s_ca + 2), (.) B,      \
@@ -343,8 +363,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         if (PRO) {                         // (the compiler waits for the coefficient loads here: nothing else is in flight yet)
 #pragma unroll
             for (int k = 0; k < 2; ++k)
-                if (tid + k * NT < Cin) *reinterpret_cast<f32x2*>(sCo + (tid + k * NT) * 2) = cpre[k];
+                if (tid + k * NT < Cin) {
+                    *reinterpret_cast<f32x2*>(sCo + (tid + k * NT) * 2) = cpre[k];
+                    if (G8) *reinterpret_cast<f32x2*>(sCo + (Cin + tid + k * NT) * 2) = cpre2[k];
+                }
         }
+        if (G8)                            // the halo of both patch buffers is zero padding for the whole kernel
+            for (int i = tid; i < 2 * PBUF; i += NT) sP[i] = 0.0f;
         {
             unsigned ofs[MAXP];
             H2_READ_OFF(ofs)
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
             H2_LOAD_P(c_begin + 2, nodep, ofs)
         }
         H2_LOAD_A_RANGE(c_begin, 3, NA, nodep)
-        if (PRO) __syncthreads();          // coefficient table visible
+        if (PRO || G8) __syncthreads();    // coefficient table (and the zeroed halo) visible
         if (rec) sp[0] = __builtin_amdgcn_s_memtime() - tk0;      // loads issued
         H2_WAIT(MAXP + NA - 3)             // the two patches have landed; younger: patch(c_begin + 2), quads 3..
         if (rec) sp[1] = __builtin_amdgcn_s_memtime() - tk0;      // first patches landed
@@ -413,7 +438,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     // ---------------- inverse transform + epilogue, one 32-cout sub-tile at a time ----------------
     float* sM = smem;                      // [16 positions][32 couts][32 tiles] = 64 KiB
     const int e_tile = tid & 31, e_col0 = tid >> 5;            // two (cout, tile) tasks per thread: couts e_col0 and e_col0 + 16
-    const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
+    const int e_ty = G8 ? (e_tile >> 2) & 3 : e_tile >> 3, e_tx = G8 ? e_tile & 3 : e_tile & 7;
+    const int e_b = min(b + (G8 ? e_tile >> 4 : 0), a.B - 1);          // G8: the tile's sample (clamped for the loads)
+    const bool e_valid = !G8 || b + (e_tile >> 4) < a.B;
     const long pix = (long)(oy0 + 2 * e_ty) * W + ox0 + 2 * e_tx;
     const bool fin = ksp == 1;                 // K split: bias, residual and scale are applied by the reduce kernel
     float* const ydst = fin ? a.y : a.part + (long)kh * a.B * a.Cout * HW;
@@ -436,7 +463,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
             const int co = co0 + ct * 32 + e_col;
             f32x2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
             if (a.res && fin) {
-                const long o = ((long)b * a.Cout + min(co, a.Cout - 1)) * HW + pix;
+                const long o = ((long)e_b * a.Cout + min(co, a.Cout - 1)) * HW + pix;
                 r0 = *reinterpret_cast<const f32x2*>(a.res + o);
                 r1 = *reinterpret_cast<const f32x2*>(a.res + o + W);
             }
@@ -455,8 +482,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
             const float osc = fin ? a.out_scale : 1.0f;
             const float v00 = (y00 * inv + bvv + r0.x) * osc, v01 = (y01 * inv + bvv + r0.y) * osc;
             const float v10 = (y10 * inv + bvv + r1.x) * osc, v11 = (y11 * inv + bvv + r1.y) * osc;
-            if (co < a.Cout) {
-                const long o = ((long)b * a.Cout + co) * HW + pix;
+            if (co < a.Cout && e_valid) {
+                const long o = ((long)e_b * a.Cout + co) * HW + pix;
                 *reinterpret_cast<float2*>(ydst + o) = make_float2(v00, v01);
                 *reinterpret_cast<float2*>(ydst + o + W) = make_float2(v10, v11);
             }
@@ -481,11 +508,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
                 H2_MERGE(0x4E, 0xf)                   // quad_perm [2,3,0,1]
                 H2_MERGE(0x124, 0xf)                  // row_ror:4
                 H2_MERGE(0x128, 0xf)                  // row_ror:8
-                H2_MERGE(0x142, 0xa)                  // row_bcast:15: lanes 16-31 / 48-63 take the total of the row below
+                if (!G8) H2_MERGE(0x142, 0xa)         // row_bcast:15: lanes 16-31 / 48-63 take the total of the row below
 #undef H2_MERGE
-                if (e_tile == 31 && co < a.Cout) {
-                    float* q = a.stats + (((long)b * a.Cout + co) * (rx_n * ry_n) + rr) * 2;
-                    q[0] = mu * 128.0f;               // the partial's sum over its 128 pixels
+                // (G8: a DPP row of 16 lanes = the 16 tiles of one image: every lane of the row holds the image's total)
+                const bool writer = G8 ? (e_tile & 15) == 0 : e_tile == 31;
+                if (writer && co < a.Cout && e_valid) {
+                    float* q = a.stats + (((long)e_b * a.Cout + co) * (rx_n * ry_n) + rr) * 2;
+                    q[0] = mu * (G8 ? 64.0f : 128.0f);      // the partial's sum over its pixels
                     q[1] = m2;
                 }
             }
@@ -528,30 +557,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
 #undef H2_VALU_PHASE
 }
 
-static size_t wino2h_lds_bytes(int Cin) {
-    return (size_t)(2 * H2_VW + 2 * (H2_CK * 10 * H2_PP + 4) + 2 * Cin + 6 * H2_NT) * sizeof(float);
+static size_t wino2h_lds_bytes(int Cin, bool g8) {
+    return (size_t)(2 * H2_VW + 2 * (H2_CK * 10 * H2_PP + 4) + (g8 ? 4 : 2) * Cin + 6 * H2_NT) * sizeof(float);
 }
 
 // the K-split second pass lives in conv_wino.cpp
 int launch_wino_ksplit_reduce(const ConvArgs& a, hipStream_t s);
 
-template <int COT, int PRO, int EXP>
+template <int COT, int PRO, bool G8, int EXP>
 static int wino2h_launch_k(const ConvArgs& k, dim3 grid, size_t lds, hipStream_t s) {
     static PerDeviceOnce raised;
     if (raised.first_use()) {
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino2h_kernel<COT, PRO, EXP>),
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino2h_kernel<COT, PRO, G8, EXP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised.done();
     }
-    hipLaunchKernelGGL((conv_wino2h_kernel<COT, PRO, EXP>), grid, dim3(H2_NT), lds, s, k);
+    hipLaunchKernelGGL((conv_wino2h_kernel<COT, PRO, G8, EXP>), grid, dim3(H2_NT), lds, s, k);
     return 0;
 }
 
-template <int COT, int PRO>
+template <int COT, int PRO, bool G8>
 static int wino2h_launch2(const ConvArgs& a, hipStream_t s) {
     constexpr int BCO = 32 * COT;
-    const size_t lds = wino2h_lds_bytes(a.Cin);
-    const int nreg = a.B * (a.H / 8) * (a.W / 16);
+    const size_t lds = wino2h_lds_bytes(a.Cin, G8);
+    const int nreg = G8 ? (a.B + 1) / 2 : a.B * (a.H / 8) * (a.W / 16);
     const int ksp = a.ksplit == 2 ? 2 : 1;
     dim3 grid(((nreg + 7) / 8) * 8 * (a.CoutP / BCO), ksp);
     ConvArgs k = a;
@@ -562,41 +591,47 @@ static int wino2h_launch2(const ConvArgs& a, hipStream_t s) {
     const char* exp_s = getenv("MCVD_WINO2H_EXP");         // read per launch: the diagnostics script flips it between runs
     const int e = exp_s ? atoi(exp_s) : 0;
     int rc = 0;
-    if (COT == 3 && PRO == 2 && e != 0) {                  // timing-only ablations (tests/gpu_diag.py w3exp)
+    if (COT == 3 && PRO == 2 && !G8 && e != 0) {           // timing-only ablations (tests/gpu_diag.py w3exp)
         switch (e) {
-            case 1: rc = wino2h_launch_k<3, 2, 1>(k, grid, lds, s); break;        // no transform
-            case 2: rc = wino2h_launch_k<3, 2, 2>(k, grid, lds, s); break;        // no patch activation / park
-            case 3: rc = wino2h_launch_k<3, 2, 3>(k, grid, lds, s); break;        // neither
-            case 4: rc = wino2h_launch_k<3, 2, 4>(k, grid, lds, s); break;        // no VMEM in the loop
-            case 16: rc = wino2h_launch_k<3, 2, 16>(k, grid, lds, s); break;      // everything but the MFMAs
-            case 15: rc = wino2h_launch_k<3, 2, 15>(k, grid, lds, s); break;      // MFMA only
-            case 27: rc = wino2h_launch_k<3, 2, 27>(k, grid, lds, s); break;      // VMEM only
-            case 11: rc = wino2h_launch_k<3, 2, 11>(k, grid, lds, s); break;      // VMEM + MFMA only
+            case 1: rc = wino2h_launch_k<3, 2, false, 1>(k, grid, lds, s); break;        // no transform
+            case 2: rc = wino2h_launch_k<3, 2, false, 2>(k, grid, lds, s); break;        // no patch activation / park
+            case 3: rc = wino2h_launch_k<3, 2, false, 3>(k, grid, lds, s); break;        // neither
+            case 4: rc = wino2h_launch_k<3, 2, false, 4>(k, grid, lds, s); break;        // no VMEM in the loop
+            case 16: rc = wino2h_launch_k<3, 2, false, 16>(k, grid, lds, s); break;      // everything but the MFMAs
+            case 15: rc = wino2h_launch_k<3, 2, false, 15>(k, grid, lds, s); break;      // MFMA only
+            case 27: rc = wino2h_launch_k<3, 2, false, 27>(k, grid, lds, s); break;      // VMEM only
+            case 11: rc = wino2h_launch_k<3, 2, false, 11>(k, grid, lds, s); break;      // VMEM + MFMA only
             default: mcvd::set_error("MCVD_WINO2H_EXP=%d is not a built ablation", e); return -1;
         }
     } else {
-        rc = wino2h_launch_k<COT, PRO, 0>(k, grid, lds, s);
+        rc = wino2h_launch_k<COT, PRO, G8, 0>(k, grid, lds, s);
     }
     if (rc) return rc;
     MCVD_HIP_CHECK(hipGetLastError());
     if (ksp == 2) return launch_wino_ksplit_reduce(a, s);
-    if (a.stats) set_last_conv_stats_np((a.H / 8) * (a.W / 16));
+    if (a.stats) set_last_conv_stats_np(G8 ? 1 : (a.H / 8) * (a.W / 16));
     return 0;
+}
+
+template <int COT, bool G8>
+static int wino2h_launch1(const ConvArgs& a, hipStream_t s) {
+    if (!a.coef && !a.act) return wino2h_launch2<COT, 0, G8>(a, s);
+    if (!a.act) return wino2h_launch2<COT, 1, G8>(a, s);
+    return wino2h_launch2<COT, 2, G8>(a, s);
 }
 
 template <int COT>
 static int wino2h_launch(const ConvArgs& a, hipStream_t s) {
-    if (!a.coef && !a.act) return wino2h_launch2<COT, 0>(a, s);
-    if (!a.act) return wino2h_launch2<COT, 1>(a, s);
-    return wino2h_launch2<COT, 2>(a, s);
+    return (a.H == 8 && a.W == 8) ? wino2h_launch1<COT, true>(a, s) : wino2h_launch1<COT, false>(a, s);
 }
 
-// Shape ids 12 / 13 apply to this launch: regions of 8 x 16 output pixels (the 8x8 layers stay with conv_wino.cpp), no SPADE
-// prologue, pre-split packed weights present (13: and an even chunk count).
+// Shape ids 12 / 13 apply to this launch: regions of 8 x 16 output pixels or 8 x 8 images (two per workgroup), no SPADE prologue,
+// pre-split packed weights present (13: and an even chunk count).
 bool conv_wino2h_usable(const ConvArgs& a) {
-    return a.ks == 3 && a.H % 8 == 0 && a.W % 16 == 0 && a.H >= 8 && a.W >= 16 && a.wph && !a.gb && a.Cin <= 1024 &&
+    const bool g8 = a.H == 8 && a.W == 8;
+    return a.ks == 3 && ((a.H % 8 == 0 && a.W % 16 == 0 && a.H >= 8 && a.W >= 16) || g8) && a.wph && !a.gb && a.Cin <= 1024 &&
            a.CinP % H2_CK == 0 && (a.C1 == 0 || a.C0 % H2_CK == 0) && a.H * a.W <= 16384 &&
-           (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) && wino2h_lds_bytes(a.Cin) <= 160 * 1024 &&
+           (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) && wino2h_lds_bytes(a.Cin, g8) <= 160 * 1024 &&
            (a.ksplit != 2 || ((a.CinP / H2_CK) % 2 == 0 && a.CinP / H2_CK >= 4 && a.part != nullptr));
 }
 

@@ -171,8 +171,7 @@ struct Builder {
         p.bias = alloc_packed(p.CoutP);
         if (wnames.size() == 1 && !nin && conv_wino_supported(ks, op.H, op.W))
             p.wpw = alloc_packed((int64_t)p.CinP * 16 * p.CoutP);
-        if (p.wpw >= 0 && !(op.H == 8 && op.W == 8))          // the fp16-piece form serves the 8x16-pixel regions only
-            p.wph = alloc_packed(conv_wino2h_weight_floats(p.CinP, p.CoutP));
+        if (p.wpw >= 0) p.wph = alloc_packed(conv_wino2h_weight_floats(p.CinP, p.CoutP));      // two fp16 pieces (conv_wino2h.cpp)
         if (ks == 1) p.wph = alloc_packed(conv1x1_h2_weight_floats(p.CinP, p.CoutP));      // two fp16 pieces of the packed matrix (conv1x1_h2.cpp)
         op.wpw = p.wpw;
         op.wph = p.wph;

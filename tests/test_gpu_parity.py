@@ -84,7 +84,10 @@ CONV_CASES = [
     (2, 96, 0, 5, 64, 3, True, 1, False, 12),       # ... final conv, Cout=5 (32-channel cout tile, padded)
     (1, 32, 0, 32, 128, 3, True, 1, True, 12),      # ... 128x128
     (2, 40, 0, 32, 16, 3, True, 0, False, 12),      # ... affine prologue only (PRO 1), ragged last chunk
-    (5, 48, 16, 96, 8, 3, True, 1, True, 12),       # ... 8x8 images: not served, the fp32 Winograd kernel takes the launch
+    (5, 48, 16, 96, 8, 3, True, 1, True, 12),       # ... 8x8 images: two samples per region, B odd, concat
+    (4, 288, 0, 288, 8, 3, True, 1, True, 13),      # ... 8x8 with the 2-way K split
+    (3, 96, 0, 96, 8, 3, False, 0, False, 13),      # ... 8x8, raw input, K split
+    (2, 384, 0, 384, 8, 3, True, 0, True, 12),      # ... 8x8, affine prologue only, the bench's 384-channel layers
     (2, 288, 0, 288, 16, 3, True, 1, True, 13),     # ... with the 2-way K split
     (2, 384, 288, 288, 16, 3, True, 1, True, 13),   # ... K split over a concat
     (3, 32, 0, 64, 16, 3, True, 1, False, 13),      # ... too few chunks to split: runs unsplit
@@ -145,9 +148,7 @@ def _expected_kernel(case):
             return 4                                 # 8x8 images: the fp32 Winograd kernel takes the launch
         chunks = -(-Cin // 16)
         return 11 if (fam == 11 and chunks % 2 == 0 and chunks >= 4) else 10
-    if fam in (12, 13):
-        if H == 8:
-            return 4
+    if fam in (12, 13):                          # (8x8 images: the two-images-per-workgroup form of the same kernel)
         chunks = -(-Cin // 16)
         return 13 if (fam == 13 and chunks % 2 == 0 and chunks >= 4) else 12
     return None
