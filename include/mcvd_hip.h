@@ -124,6 +124,13 @@ int mcvd_model_set_param(mcvd_model* m, const char* name, const float* data, con
 int mcvd_model_blob_floats(mcvd_model* m, int64_t* n_floats);
 int mcvd_model_export_blob(mcvd_model* m, float* dst_device);
 int mcvd_model_import_blob(mcvd_model* m, const float* src_device); /* marks every parameter as set */
+/* The one-shot weight broadcast of the data-parallel launch, directly on an RCCL communicator (replaces the per-forward
+ * replicate of nn.DataParallel, runners/ncsn_runner.py:924): ncclBroadcast of the raw blob, in place, from rank `root` on the context's
+ * stream.  `rccl_comm` is the caller's ncclComm_t (one process per GPU); librccl is resolved at the first call (dlopen), the library
+ * has no link-time dependency on it.  Every rank must call it; afterwards every parameter counts as set and mcvd_model_finalize has
+ * to run (non-root ranks need no mcvd_model_set_param at all).  Hosts that already have torch.distributed use
+ * mcvd_model_export_blob / import_blob around dist.broadcast instead (mcvd_pytorch_amd/dist.py): same bytes, same single collective. */
+int mcvd_model_broadcast_params(mcvd_model* m, void* rccl_comm, int root);
 /* Pack/transposes weights into kernel layouts, builds the static op plan. */
 int mcvd_model_finalize(mcvd_model* m);
 /* Schedule buffers exactly as UNetMore_DDPM registers them (ncsnpp_more.py:735-743); host pointers, n = num_classes. */

@@ -45,6 +45,7 @@ _PROTOS = {
     "mcvd_model_blob_floats": (_i, [_vp, C.POINTER(_i64)]),
     "mcvd_model_export_blob": (_i, [_vp, _vp]),
     "mcvd_model_import_blob": (_i, [_vp, _vp]),
+    "mcvd_model_broadcast_params": (_i, [_vp, _vp, _i]),
     "mcvd_model_finalize": (_i, [_vp]),
     "mcvd_model_get_schedule": (_i, [_vp, _vp, _vp, _vp, _i]),
     "mcvd_model_set_schedule": (_i, [_vp, _vp, _vp, _vp, _i]),

@@ -1,4 +1,5 @@
 // extern "C" surface of libmcvd_hip.so (see include/mcvd_hip.h).  Nothing here throws.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -258,6 +259,31 @@ int mcvd_model_import_blob(mcvd_model* m, const float* src_device) {
     for (auto& p : m->params) p.set = true;
     m->finalized = false;
     return 0;
+}
+
+// RCCL is resolved at run time: libmcvd_hip.so links the HIP runtime only (single-GPU users never load librccl)
+int mcvd_model_broadcast_params(mcvd_model* m, void* rccl_comm, int root) {
+    API_TRY
+    MCVD_REQUIRE(m && m->ctx && rccl_comm && root >= 0, "broadcast_params: NULL model / communicator or negative root");
+    typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef const char* (*errstr_fn)(int);
+    static bcast_fn bcast = nullptr;
+    static errstr_fn errstr = nullptr;
+    if (!bcast) {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        MCVD_REQUIRE(h, "broadcast_params: librccl.so not found (%s)", dlerror());
+        bcast = reinterpret_cast<bcast_fn>(dlsym(h, "ncclBroadcast"));
+        errstr = reinterpret_cast<errstr_fn>(dlsym(h, "ncclGetErrorString"));
+        MCVD_REQUIRE(bcast, "broadcast_params: ncclBroadcast not exported by librccl");
+    }
+    const int ncclFloat32 = 7;
+    const int rc = bcast(m->blob, m->blob, (size_t)m->blob_floats, ncclFloat32, root, rccl_comm, m->ctx->stream);
+    MCVD_REQUIRE(rc == 0, "broadcast_params: ncclBroadcast failed: %s", errstr ? errstr(rc) : "?");
+    for (auto& p : m->params) p.set = true;
+    m->finalized = false;
+    return 0;
+    API_CATCH
 }
 
 int mcvd_model_finalize(mcvd_model* m) {

@@ -64,7 +64,7 @@ def build(force=False, jobs=None, verbose=True):
         if verbose:
             print(r.stdout.strip())
     if rebuilt or not os.path.exists(LIB) or force:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stderr))

@@ -488,34 +488,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
                 *reinterpret_cast<float2*>(ydst + o + W) = make_float2(v10, v11);
             }
             if (a.stats && fin) {
-                // GroupNorm partials of the FINAL values (ConvArgs::stats): the 32 tiles of this cout are the 32 lanes of a
-                // half-wave; exact per-lane (mean, M2) of its 2x2 pixels, then equal-count pairwise merges over DPP moves
-                // (conv_wino.cpp has the derivation).
-                float mu = 0.25f * ((v00 + v01) + (v10 + v11));
-                const float d0 = v00 - mu, d1 = v01 - mu, d2 = v10 - mu, d3 = v11 - mu;
-                float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                float hn = 2.0f;
+                // GroupNorm partials of the FINAL values (ConvArgs::stats): the tiles of this cout are the 32 lanes of a half-wave (G8:
+                // 16 lanes = one DPP row per image).  Pilot-shifted moments: with p = the group's first value (a sample of the
+                // distribution, so |mean - p| is a few sigma at most and M2 = q - s^2 / n loses a digit, not the result),
+                // s = sum (v - p) and q = sum (v - p)^2 merge by plain addition -- two v_add_f32 with a DPP source per level, where the
+                // exact (mean, M2) pairs of conv_wino.cpp cost eight instructions per level and a quarter of this epilogue.
+                float pil;
+                {
+                    const int pv = __builtin_bit_cast(int, v00);
+                    const int s0 = __builtin_amdgcn_readlane(pv, 0), s2 = __builtin_amdgcn_readlane(pv, 32);
+                    if (G8) {
+                        const int s1 = __builtin_amdgcn_readlane(pv, 16), s3 = __builtin_amdgcn_readlane(pv, 48);
+                        pil = __builtin_bit_cast(float, (lane & 32) ? ((lane & 16) ? s3 : s2) : ((lane & 16) ? s1 : s0));
+                    } else {
+                        pil = __builtin_bit_cast(float, (lane & 32) ? s2 : s0);
+                    }
+                }
+                const float d0 = v00 - pil, d1 = v01 - pil, d2 = v10 - pil, d3 = v11 - pil;
+                float sm = (d0 + d1) + (d2 + d3);
+                float qm = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
 #define H2_MERGE(CTRL, ROWMASK)                                                                                     \
                 {                                                                                                   \
-                    const float mo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, mu), __builtin_bit_cast(int, mu), CTRL, ROWMASK, 0xf, false)); \
-                    const float qo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m2), __builtin_bit_cast(int, m2), CTRL, ROWMASK, 0xf, false)); \
-                    const float dd = mu - mo;                                                                       \
-                    m2 = (m2 + qo) + dd * dd * hn;                                                                  \
-                    mu = 0.5f * (mu + mo);                                                                          \
-                    hn += hn;                                                                                       \
+                    sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), CTRL, ROWMASK, 0xf, false)); \
+                    qm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qm), CTRL, ROWMASK, 0xf, false)); \
                 }
                 H2_MERGE(0xB1, 0xf)                   // quad_perm [1,0,3,2]
                 H2_MERGE(0x4E, 0xf)                   // quad_perm [2,3,0,1]
                 H2_MERGE(0x124, 0xf)                  // row_ror:4
-                H2_MERGE(0x128, 0xf)                  // row_ror:8
-                if (!G8) H2_MERGE(0x142, 0xa)         // row_bcast:15: lanes 16-31 / 48-63 take the total of the row below
+                H2_MERGE(0x128, 0xf)                  // row_ror:8: every lane of a row of 16 holds the row's totals
+                if (!G8) H2_MERGE(0x142, 0xa)         // row_bcast:15: lanes 16-31 / 48-63 add the totals of the row below
 #undef H2_MERGE
-                // (G8: a DPP row of 16 lanes = the 16 tiles of one image: every lane of the row holds the image's total)
                 const bool writer = G8 ? (e_tile & 15) == 0 : e_tile == 31;
                 if (writer && co < a.Cout && e_valid) {
+                    constexpr float NPIX = G8 ? 64.0f : 128.0f;
                     float* q = a.stats + (((long)e_b * a.Cout + co) * (rx_n * ry_n) + rr) * 2;
-                    q[0] = mu * (G8 ? 64.0f : 128.0f);      // the partial's sum over its pixels
-                    q[1] = m2;
+                    q[0] = sm + NPIX * pil;           // the partial's sum over its pixels
+                    q[1] = fmaxf(qm - sm * sm * (1.0f / NPIX), 0.0f);      // M2 about the partial's own mean
                 }
             }
         }

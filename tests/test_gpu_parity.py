@@ -302,6 +302,10 @@ def test_gn_coef(ctx, B, C0, C1, H, mode):
     (5, 48, 96, 8, 3, True, 4, 1),            # Winograd on 8x8 images (two per workgroup, B odd)
     (4, 288, 288, 8, 3, True, 8, 1),          # K split: the reduce pass emits
     (2, 288, 288, 16, 3, False, 8, 1),
+    (2, 96, 96, 64, 3, True, 12, 32),         # two-piece fp16 Winograd kernel: pilot-shifted partials, 8x16 regions
+    (3, 64, 128, 16, 3, True, 12, 2),
+    (5, 48, 96, 8, 3, True, 12, 1),           # ... 8x8 images (two per workgroup, B odd): one partial per image
+    (4, 288, 288, 8, 3, True, 13, 1),         # ... K split: the reduce pass emits
     (2, 192, 192, 32, 1, True, 5, 32),        # all-DMA 1x1 (NIN_3 + residual): one partial per 32-pixel run
     (3, 288, 288, 8, 1, True, 5 + 16 * 3, 2),
     (2, 96, 96, 64, 3, True, 1, 0),           # direct tile: no statistics, consumers must read the tensor
@@ -343,6 +347,26 @@ def test_conv_epilogue_group_norm_statistics(ctx, case):
         want = ctx.gn_coef(y, G2, 1e-5, 1, x1=y2, p0=emb, emb_stride=emb.shape[1], emb_off=3).cpu()
         got = ctx.gn_finalize(st, np_, G2, 1e-5, 1, H * H, st1=st2, np1=np2, p0=emb, emb_stride=emb.shape[1], emb_off=3).cpu()
         torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("H,offset", [(64, 40.0), (8, 40.0), (32, -300.0)])
+def test_wino2h_epilogue_statistics_with_a_large_mean(ctx, H, offset):
+    """The two-piece fp16 Winograd kernel's partials are pilot-shifted moments (sum (v - p), sum (v - p)^2 with p = one value of the
+    group): a channel mean tens to hundreds of standard deviations away from zero must not cost the variance anything."""
+    g = _g(33)
+    B, C = 3, 96
+    x = torch.randn(B, C, H, H, generator=g).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).cuda()
+    bias = (offset + torch.randn(C, generator=g)).cuda()
+    ctx.opt("conv_shape", 12)
+    y, st, np_ = ctx.conv2d_stats(x, w, bias)
+    ctx.opt("conv_shape", -1)
+    assert np_ == (1 if H == 8 else (H // 8) * (H // 16))
+    G = unet_ref.gn_groups(C)
+    want = ctx.gn_coef(y, G, 1e-5, 0).cpu()
+    got = ctx.gn_finalize(st, np_, G, 1e-5, 0, H * H).cpu()
+    # coefficient A = 1 / sqrt(var + eps); B = -mean * A is ~|offset| times larger: relative tolerance on both
+    torch.testing.assert_close(got, want, rtol=5e-5, atol=2e-6 * abs(offset))
 
 
 @pytest.mark.parametrize("case", [
@@ -1226,3 +1250,26 @@ def test_uint8_frame_packing():
                         for t in range(4)], dim=1)
     assert got.shape == want.shape == (3, 4, 32, 32, C) and got.dtype == torch.uint8
     assert torch.equal(got, want)
+
+
+def test_direct_rccl_weight_broadcast_single_rank():
+    """mcvd_model_broadcast_params (the weight broadcast directly on an RCCL communicator, no torch): plumbing check on a
+    one-rank communicator -- librccl is resolved at run time, ncclBroadcast runs on the context's stream, the parameters count as set and
+    the model must be finalized again; the forward is unchanged.  (The N-rank semantics are ncclBroadcast's own.)"""
+    import ctypes as C
+    from mcvd_pytorch_amd import _lib
+    rccl = C.CDLL("librccl.so.1")
+    comm = C.c_void_p()
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, (C.c_int * 1)(torch.cuda.current_device())) == 0
+    try:
+        config, sd, net = _net("tiny")
+        x, cond = synth.make_inputs(config, 2, seed=0)
+        t = torch.tensor([990, 130]).cuda()
+        a = net(x.cuda(), t, cond=cond.cuda()).clone()
+        _lib.check(_lib.lib.mcvd_model_broadcast_params(net._model, comm, 0), "broadcast_params")
+        _lib.check(_lib.lib.mcvd_model_finalize(net._model), "finalize")
+        b = net(x.cuda(), t, cond=cond.cuda()).clone()
+        assert torch.equal(a, b)
+        assert _lib.lib.mcvd_model_broadcast_params(net._model, None, 0) != 0          # NULL communicator: an error code, not a crash
+    finally:
+        rccl.ncclCommDestroy(comm)
