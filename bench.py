@@ -329,11 +329,19 @@ def main():
                     forward_ms_events=round(fwd_ms, 3),
                     forward_ms_events_note="sum of per-op event intervals of ONE instrumented forward: upper bound (event gaps, ~3 %)",
                     breakdown=breakdown)
+    n1x1 = n1x1_h2 = 0
+    for i in range(n):
+        if kinds[i] == 3 and kss[i] == 1 and ms[i] != 0.0:
+            _lib.check(_lib.lib.mcvd_model_op_info(net._model, i, info), "op_info")
+            n1x1 += 1
+            n1x1_h2 += 1 if ((info[6] >> 12) and ((info[6] >> 4) & 15) == 14) else 0
     arith = "f32"
-    if fam["wino_f16x2"]["launches"]:
-        arith = ("f32 storage and accumulation; %d of %d 3x3 convs multiply operands rounded to two fp16 pieces (22 significant bits, 3 piece "
-                 "products, fp32 accumulate; parity fixtures hold at the fp32 tolerances, error vs fp64 measured next to the fp32-MFMA kernel in "
-                 "tests/test_gpu_parity.py::test_conv_f16x2_accuracy); everything else f32 MFMA / f32 VALU" % (fam["wino_f16x2"]["launches"], c3["launches"]))
+    if fam["wino_f16x2"]["launches"] or n1x1_h2:
+        arith = ("f32 storage and accumulation; %d of %d 3x3 convs, %d of %d 1x1 convs and the attention products (head dims 32..128) multiply "
+                 "operands rounded to two fp16 pieces (22 significant bits, 3 piece products on the fp16 matrix pipe, fp32 accumulate; every parity "
+                 "fixture holds at the fp32 tolerances, error vs fp64 measured next to the fp32-MFMA kernels in tests/test_gpu_parity.py::"
+                 "test_conv_f16x2_accuracy / test_conv1x1_f16x2_accuracy: smaller in every case); everything else f32; fp32_exact_leg = the same "
+                 "run with these kernels withheld" % (fam["wino_f16x2"]["launches"], c3["launches"], n1x1_h2, n1x1))
     elif fam["wino_bf16x3"]["launches"]:
         arith = "f32 (3x3 convs: exact bf16x3 operand split, 6 piece products, f32 accumulate; everything else f32 MFMA / f32 VALU)"
 
