@@ -237,6 +237,44 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
             const float bco = a.bias[co];                     // zero-padded to CoutP
             v = (v + bco + rv) * a.out_scale;
             if (valid && co < a.Cout) *reinterpret_cast<f32x4*>(a.y + obase + (long)co * HW) = v;
+            if (a.stats && (HW >= PT || HW == 64)) {
+                // GroupNorm partials of the FINAL values (ConvArgs::stats): the 32 lanes of a half-wave hold the 128 pixels of this cout
+                // row -- one image's pixel block (HW >= 128: partial index = block of the image), or two 8x8 images of 16 lanes = one
+                // DPP row each.  Pilot-shifted moments as in conv_wino2h.cpp: plain sums merge with two DPP adds per level.
+                const bool g16 = HW == 64;
+                float pil;
+                {
+                    const int pv = __builtin_bit_cast(int, v[0]);
+                    const int s0 = __builtin_amdgcn_readlane(pv, 0), s1 = __builtin_amdgcn_readlane(pv, 16);
+                    const int s2 = __builtin_amdgcn_readlane(pv, 32), s3 = __builtin_amdgcn_readlane(pv, 48);
+                    pil = __builtin_bit_cast(float, (lane & 32) ? ((g16 && (lane & 16)) ? s3 : s2) : ((g16 && (lane & 16)) ? s1 : s0));
+                }
+                const float d0 = v[0] - pil, d1 = v[1] - pil, d2 = v[2] - pil, d3 = v[3] - pil;
+                float sm = (d0 + d1) + (d2 + d3);
+                float qm = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#define Q1_MERGE(CTRL, ROWMASK)                                                                                     \
+                {                                                                                                   \
+                    sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), CTRL, ROWMASK, 0xf, false)); \
+                    qm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qm), CTRL, ROWMASK, 0xf, false)); \
+                }
+                Q1_MERGE(0xB1, 0xf)                   // quad_perm [1,0,3,2]
+                Q1_MERGE(0x4E, 0xf)                   // quad_perm [2,3,0,1]
+                Q1_MERGE(0x124, 0xf)                  // row_ror:4
+                Q1_MERGE(0x128, 0xf)                  // row_ror:8: every lane of a row of 16 holds the row's totals
+                float sm2 = sm, qm2 = qm;             // row_bcast:15: lanes 16-31 / 48-63 add the totals of the row below (32-lane groups)
+                sm2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), 0x142, 0xa, 0xf, false));
+                qm2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qm), 0x142, 0xa, 0xf, false));
+#undef Q1_MERGE
+                if (!g16) { sm = sm2; qm = qm2; }
+                const bool writer = g16 ? (px4 & 15) == 0 : px4 == 31;
+                if (writer && valid && co < a.Cout) {
+                    const float npix = g16 ? 64.0f : 128.0f;
+                    const int np = g16 ? 1 : HW >> 7, pidx = g16 ? 0 : op >> 7;
+                    float* q = a.stats + (((long)ob * a.Cout + co) * np + pidx) * 2;
+                    q[0] = sm + npix * pil;
+                    q[1] = fmaxf(qm - sm * sm / npix, 0.0f);
+                }
+            }
         }
     }
     if (rec) {
@@ -305,7 +343,9 @@ int launch_conv1x1_h2(const ConvArgs& a, int cot, hipStream_t s) {
         case 3: rc = q1_launch<3>(a, s); break;
         default: rc = q1_launch<4>(a, s); break;
     }
-    return rc;            // no epilogue GroupNorm statistics from this kernel (last_conv_stats_np() stays 0: the norm reads the tensor)
+    const int HW = a.H * a.W;
+    if (rc == 0 && a.stats && (HW >= Q1_PT || HW == 64)) set_last_conv_stats_np(HW >= Q1_PT ? HW / Q1_PT : 1);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

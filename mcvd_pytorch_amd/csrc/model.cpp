@@ -697,7 +697,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                     a.x0 = tmp; a.x1 = nullptr; a.C0 = a.Cin; a.C1 = 0; a.coef = nullptr; a.act = 0; a.gb = nullptr; a.coef2 = nullptr;
                 }
             }
-            a.stats = (ctx->gn_stats && op.stats.kind != REF_NONE && !ctx->naive_conv && (op.ks == 3 || ctx->gn_stats >= 2))
+            // (the fp16-pipe 1x1 GEMM emits them cheaply from its transposed epilogue: shape id 14)
+            a.stats = (ctx->gn_stats && op.stats.kind != REF_NONE && !ctx->naive_conv && (op.ks == 3 || ctx->gn_stats >= 2 || a.shape_hint == 14))
                           ? resolve(op.stats, x, cond, out, B) : nullptr;
             if (ctx->naive_conv) {
                 stats_np[oi] = 0;

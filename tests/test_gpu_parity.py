@@ -308,6 +308,9 @@ def test_gn_coef(ctx, B, C0, C1, H, mode):
     (4, 288, 288, 8, 3, True, 13, 1),         # ... K split: the reduce pass emits
     (2, 192, 192, 32, 1, True, 5, 32),        # all-DMA 1x1 (NIN_3 + residual): one partial per 32-pixel run
     (3, 288, 288, 8, 1, True, 5 + 16 * 3, 2),
+    (2, 192, 192, 32, 1, True, 14 + 16 * 2, 8),      # two-piece fp16 1x1 GEMM (NIN_3 + residual): one partial per 128-pixel block
+    (3, 288, 288, 8, 1, True, 14 + 16 * 3, 1),       # ... 8x8 images: two per pixel tile, one partial per image, B odd (ragged tile)
+    (2, 96, 96, 64, 1, False, 14 + 16 * 1, 32),
     (2, 96, 96, 64, 3, True, 1, 0),           # direct tile: no statistics, consumers must read the tensor
 ], ids=lambda c: "c{}-{}_H{}_k{}_s{}".format(c[1], c[2], c[3], c[4], c[6]))
 def test_conv_epilogue_group_norm_statistics(ctx, case):
