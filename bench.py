@@ -145,6 +145,110 @@ def cpu_baseline(config, state_dict, subsample, budget_s=24.0, kept_fraction=1.0
                        f"swept thread counts ({cores} of {ncpu} hardware threads), extrapolated linearly; torch {torch.__version__} CPU")
 
 
+def roofline_of_leg(net, args, B, arith_name):
+    """Per-op HIP-event timings of ONE forward inside the leg's timed region (the first forward of its last sampler call runs op by op
+    with events around each launch, so the sum is an UPPER bound of a back-to-back forward: event gaps) -> the roofline block of the
+    leg's dominant kernel family + the arithmetic (`dtype`) string of what really ran (mcvd_model_op_kernel)."""
+    import ctypes as C
+    from mcvd_pytorch_amd import _lib
+    n = _lib.lib.mcvd_model_profile_read(net._model, None, None, None, None, None, 0)
+    kinds, kss = (C.c_int * n)(), (C.c_int * n)()
+    ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    _lib.check(0 if _lib.lib.mcvd_model_profile_read(net._model, kinds, kss, ms, fl, by, n) == n else -1, "profile_read")
+    names = {0: "temb_mlp", 1: "dense_all", 2: "gn_coef", 3: "conv", 4: "fir2", 5: "attention", 6: "nearest", 7: "coef2", 8: "spade_apply"}
+    agg = {}
+    for i in range(n):
+        if ms[i] == 0.0:          # cond-only (SPADE prep) ops are not part of the per-step forward
+            continue
+        key = names.get(kinds[i], f"op{kinds[i]}") + (f"{kss[i]}x{kss[i]}" if kinds[i] == 3 else "")
+        a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        a["launches"] += 1; a["ms"] += ms[i]; a["flops"] += fl[i]; a["bytes"] += by[i]
+    fwd_ms = sum(a["ms"] for a in agg.values())
+    breakdown = {k: dict(launches=a["launches"], ms=round(a["ms"], 3), share=round(a["ms"] / fwd_ms, 4),
+                         tflops=round(a["flops"] / a["ms"] / 1e9, 2), gbs=round(a["bytes"] / a["ms"] / 1e6, 1))
+                 for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    # ---- dominant kernel: the 3x3 convs, by the kernel family each layer REALLY ran
+    FAM3 = {4: "wino_f32", 8: "wino_f32", 10: "wino_bf16x3", 11: "wino_bf16x3", 12: "wino_f16x2", 13: "wino_f16x2"}
+    fam = {k: dict(launches=0, ms=0.0, flops=0.0, bytes=0.0) for k in ("wino_f32", "wino_bf16x3", "wino_f16x2", "direct")}
+    k1 = {}
+    for i in range(n):
+        if kinds[i] != 3 or ms[i] == 0.0:
+            continue
+        ran = _lib.lib.mcvd_model_op_kernel(net._model, i)
+        if kss[i] == 1:
+            k1[ran] = k1.get(ran, 0) + 1
+            continue
+        f = fam[FAM3.get(ran, "direct")]                      # 8 / 11 / 13: + the K-split reduce pass
+        f["launches"] += 1; f["ms"] += ms[i]; f["flops"] += fl[i]; f["bytes"] += by[i]
+    c3 = agg["conv3x3"]
+    dom_key = max(fam, key=lambda k: fam[k]["ms"])
+    dom = fam[dom_key]
+    # (kernel name, matrix-pipe flops executed per direct-form flop, peak of the pipe it runs on)
+    #   Winograd F(2x2,3x3) executes 16 of the direct form's 36 multiplies per output tile; the three-piece bf16 kernel issues SIX
+    #   piece products per fp32 product, the two-piece fp16 kernel THREE
+    FAMILY = {
+        "wino_f32": ("conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", 16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS),
+        "wino_bf16x3": ("conv_wino3_kernel (3x3 conv, Winograd F(2x2,3x3), operands split exactly into 3 bf16 pieces, weights pre-split at "
+                        "pack time, 6 piece products on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-equivalent)", 6.0 * 16.0 / 36.0,
+                        BF16_MFMA_PEAK_TFLOPS),
+        "wino_f16x2": ("conv_wino2h_kernel (3x3 conv, Winograd F(2x2,3x3), operands split into 2 fp16 pieces = 22 significant bits, weights "
+                       "pre-split at pack time, 3 piece products on v_mfma_f32_32x32x16_f16, fp32 accumulate)", 3.0 * 16.0 / 36.0, BF16_MFMA_PEAK_TFLOPS),
+        "direct": ("conv_mfma_kernel<3x3> (direct implicit GEMM, v_mfma_f32_32x32x2_f32)", 1.0, FP32_MFMA_PEAK_TFLOPS),
+    }
+    dom_name, mult_ratio, pipe_peak = FAMILY[dom_key]
+    algorithmic = dom["flops"] / dom["ms"] / 1e9
+    executed = algorithmic * mult_ratio
+    # HBM-side bytes per launch: NOT measured in this run -- read from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # tools/gpu_check.sh prof) over the same launch population of the same kernel family, when such a file exists
+    traffic, traffic_src = None, None
+    try:
+        if args.config == "smmnist_big5_ngf96" and B == 64:
+            for fn in sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")):
+                tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if tj.get("family", "wino_f32") == dom_key and "traffic_bytes_per_launch" in tj:
+                    traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/" + fn      # the latest file of the family wins
+    except Exception:
+        traffic = None
+    roofline = dict(bound="mfma", kernel=dom_name,
+                    achieved=round(executed, 2), peak=pipe_peak, unit="TFLOP/s",
+                    frac=round(executed / pipe_peak, 4), traffic=traffic, traffic_from_file=bool(traffic), traffic_source=traffic_src,
+                    note=("achieved / frac = flops the kernel EXECUTES on its matrix pipe (Winograd F(2x2,3x3): 16/36 of the "
+                          "direct-form multiplies; x6 piece products for the three-piece bf16 kernel, x3 for the two-piece fp16 kernel) / "
+                          "HIP-event time of its launches in one forward of the timed region / that pipe's dense peak, i.e. the matrix-pipe "
+                          "utilisation (agrees with PMC SQ_VALU_MFMA_BUSY_CYCLES, profiles/); algorithmic_* applies the contract's "
+                          "direct-form count 2*B*HW*Cout*Cin*9 against the FP32 matrix peak (the precision the path delivers) and may exceed 1; "
+                          "traffic is read from a committed PMC file (traffic_from_file), not measured in this run"),
+                    algorithmic_achieved=round(algorithmic, 2), algorithmic_frac=round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
+                    algorithmic_bytes_per_launch=round(dom["bytes"] / dom["launches"]),
+                    launches=dom["launches"], avg_launch_us=round(1e3 * dom["ms"] / dom["launches"], 1),
+                    hbm_gbs=(round(traffic / (1e3 * dom["ms"] / dom["launches"]) / 1e3, 1) if traffic else None), hbm_peak_gbs=HBM_PEAK_GBS,
+                    flops_per_launch_avg=dom["flops"] / dom["launches"],
+                    conv3x3_families={k: dict(launches=v["launches"], ms=round(v["ms"], 3),
+                                              algorithmic_tflops=round(v["flops"] / v["ms"] / 1e9, 2) if v["ms"] else None)
+                                      for k, v in fam.items()},
+                    conv1x1_kernels={str(k): v for k, v in sorted(k1.items())},
+                    all_conv3x3=dict(launches=c3["launches"], ms=round(c3["ms"], 3), tflops=round(c3["flops"] / c3["ms"] / 1e9, 2)),
+                    forward_ms_events=round(fwd_ms, 3),
+                    forward_ms_events_note="sum of per-op event intervals of ONE instrumented forward: upper bound (event gaps, ~3 %)",
+                    breakdown=breakdown)
+    n1 = sum(k1.values())
+    if fam["wino_f16x2"]["launches"] or k1.get(14):
+        arith = ("f16x2: f32 storage and accumulation; %d of %d 3x3 convs, %d of %d 1x1 convs (those with a GroupNorm-ed input) and the attention "
+                 "products (head dims 32..128) multiply operands rounded to two fp16 pieces (22 significant bits, fp16 exponent range, 3 piece "
+                 "products on the fp16 matrix pipe); the other convs on three exact bf16 pieces; everything else f32.  NARROWER than the "
+                 "reference's fp32: opt-in (context option f16x2 = 1), never the headline value"
+                 % (fam["wino_f16x2"]["launches"], c3["launches"], k1.get(14, 0), n1))
+    elif fam["wino_bf16x3"]["launches"] or k1.get(15):
+        arith = ("f32-equivalent: f32 storage and accumulation; %d of %d 3x3 convs, %d of %d 1x1 convs and the attention products (head dims "
+                 "32..128) as SIX bf16 piece products of operands split EXACTLY into three bf16 pieces (all 24 bits, fp32 exponent range, less "
+                 "than one fp32 rounding per product; tests/test_gpu_parity.py::test_conv_bf16x3_is_fp32_accurate, "
+                 "test_default_kernels_have_the_fp32_range); the rest on the fp32 MFMA / fp32 VALU"
+                 % (fam["wino_bf16x3"]["launches"], c3["launches"], k1.get(15, 0), n1))
+    else:
+        arith = "f32 (fp32 MFMA / fp32 VALU everywhere)"
+    return roofline, arith
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,10 +259,16 @@ def main():
     ap.add_argument("--subsample", type=int, default=None)
     ap.add_argument("--frames-pred", type=int, default=None, help="autoregressive configs: frames to keep (default 28)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MCVD_GRAPH", "1")), help="hipGraph replay of the forwards")
-    ap.add_argument("--tune-cache", default=None, help="JSON file: load the kernel-selection table if it exists, else save it")
+    ap.add_argument("--tune-cache", default=None, help="JSON file: kernel-selection table of the headline leg -- loaded if it exists, else "
+                    "written after the warm-up.  Default: profiles/tune_<config>_B<batch>_<arithmetic>.json when that file is committed "
+                    "(pinned kernels: the run executes the table the parity tests check), else the autotuner measures")
+    ap.add_argument("--save-tuning", default=None, help="directory: write the table of every leg there (tune_<config>_B<batch>_<arithmetic>.json)")
+    ap.add_argument("--no-tune-file", action="store_true", help="ignore committed tables: let the autotuner measure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the second, reported-only timing with the two-piece fp16 kernels withheld")
-    ap.add_argument("--f16x2", type=int, default=None, help="0: keep every 3x3 conv product at fp32 accuracy (do not offer the two-piece fp16 kernel)")
+    ap.add_argument("--no-f16x2-leg", "--no-fp32-leg", dest="no_second_leg", action="store_true",
+                    help="skip the second, reported-only timing with the two-piece fp16 kernels offered")
+    ap.add_argument("--f16x2", type=int, default=0, help="1: the headline leg itself offers the two-piece fp16 kernels (narrower arithmetic "
+                    "than the reference's: NOT the contract number; the default headline is the fp32-equivalent three-piece bf16 path)")
     args = ap.parse_args()
 
     cmd = plan_launch(args.gpus, os.environ)
@@ -204,12 +314,6 @@ def main():
     broadcast_weights(net, src=0)                    # ONE RCCL broadcast of the packed blob (no-op at N=1)
     net.set_option("profile", 1)
     net.set_option("graph", args.graph)
-    if args.f16x2 is not None:
-        net.set_option("f16x2", args.f16x2)
-    tuned_from_cache = False
-    if args.tune_cache and os.path.exists(args.tune_cache):
-        net.load_tuning(args.tune_cache)
-        tuned_from_cache = True
 
     total = B * world
     b0, b1 = shard_rows(total, rank, world)
@@ -232,143 +336,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        one_step(-1 - i)
-    if args.tune_cache and not tuned_from_cache and rank == 0:
-        net.save_tuning(args.tune_cache, [b1 - b0])
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        frames = one_step(i)
-    fence()
-    dt_local = time.perf_counter() - t0
-    dt, per_rank = dt_local, [round(dt_local, 4)]
-    if world > 1:
-        tt = torch.tensor([dt_local], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        allt = [torch.zeros_like(tt) for _ in range(world)]
-        dist.all_gather(allt, tt)
-        per_rank = [round(v.item(), 4) for v in allt]
-        dt = max(per_rank)
-    assert torch.isfinite(frames).all() and frames.shape[0] == total and frames.shape[1] == config.data.channels * nfp
-    value = args.steps * total * nfp / dt
+    def table_path(arith_name):
+        return os.path.join(ROOT, "profiles", f"tune_{args.config}_B{b1 - b0}_{arith_name}.json")
 
-    # ---- per-op HIP-event timings of one forward inside the timed region (first forward of the last sampler call; that
-    # forward runs op by op with events around each launch, so the sum is an UPPER bound of a back-to-back forward: event gaps)
-    import ctypes as C
-    from mcvd_pytorch_amd import _lib
-    n = _lib.lib.mcvd_model_profile_read(net._model, None, None, None, None, None, 0)
-    kinds, kss = (C.c_int * n)(), (C.c_int * n)()
-    ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
-    _lib.check(0 if _lib.lib.mcvd_model_profile_read(net._model, kinds, kss, ms, fl, by, n) == n else -1, "profile_read")
-    names = {0: "temb_mlp", 1: "dense_all", 2: "gn_coef", 3: "conv", 4: "fir2", 5: "attention", 6: "nearest", 7: "coef2", 8: "spade_apply"}
-    agg = {}
-    for i in range(n):
-        if ms[i] == 0.0:          # cond-only (SPADE prep) ops are not part of the per-step forward
-            continue
-        key = names.get(kinds[i], f"op{kinds[i]}") + (f"{kss[i]}x{kss[i]}" if kinds[i] == 3 else "")
-        a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-        a["launches"] += 1; a["ms"] += ms[i]; a["flops"] += fl[i]; a["bytes"] += by[i]
-    fwd_ms = sum(a["ms"] for a in agg.values())
-    breakdown = {k: dict(launches=a["launches"], ms=round(a["ms"], 3), share=round(a["ms"] / fwd_ms, 4),
-                         tflops=round(a["flops"] / a["ms"] / 1e9, 2), gbs=round(a["bytes"] / a["ms"] / 1e6, 1))
-                 for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
-    # ---- dominant kernel: the 3x3 convs.  Which implementation each layer runs is the autotuner's choice (op_info):
-    # shape 4 / 8 = Winograd F(2x2,3x3) (conv_wino_kernel; 8: + its K-split reduce pass), else the direct implicit GEMM.
-    info = (C.c_int * 8)()
-    fam = {k: dict(launches=0, ms=0.0, flops=0.0, bytes=0.0) for k in ("wino_f32", "wino_bf16x3", "wino_f16x2", "direct")}
-    for i in range(n):
-        if kinds[i] != 3 or kss[i] != 3 or ms[i] == 0.0:
-            continue
-        _lib.check(_lib.lib.mcvd_model_op_info(net._model, i, info), "op_info")
-        shape = ((info[6] >> 4) & 15) if (info[6] >> 12) else -1
-        f = fam["wino_f32" if shape in (4, 8) else "wino_bf16x3" if shape in (10, 11) else "wino_f16x2" if shape in (12, 13) else "direct"]   # 8 / 11 / 13: + the K-split reduce pass
-        f["launches"] += 1; f["ms"] += ms[i]; f["flops"] += fl[i]; f["bytes"] += by[i]
-    c3 = agg["conv3x3"]
-    dom_key = max(fam, key=lambda k: fam[k]["ms"])
-    dom = fam[dom_key]
-    # (kernel name, matrix-pipe flops executed per direct-form flop, peak of the pipe it runs on, arithmetic)
-    #   fp32 Winograd F(2x2,3x3): 16 of the direct form's 36 multiplies per output tile, on the fp32 MFMA
-    #   bf16x3 Winograd: the same 16/36, each product as SIX bf16 piece products (exact three-way operand split, fp32 accumulate)
-    FAMILY = {
-        "wino_f32": ("conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", 16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS),
-        "wino_bf16x3": ("conv_wino3_kernel (3x3 conv, Winograd F(2x2,3x3), operands split exactly into 3 bf16 pieces, 6 piece "
-                        "products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)", 6.0 * 16.0 / 36.0, BF16_MFMA_PEAK_TFLOPS),
-        "wino_f16x2": ("conv_wino2h_kernel (3x3 conv, Winograd F(2x2,3x3), operands split into 2 fp16 pieces = 22 significant bits, weights "
-                       "pre-split at pack time, 3 piece products on v_mfma_f32_32x32x16_f16, fp32 accumulate)", 3.0 * 16.0 / 36.0, BF16_MFMA_PEAK_TFLOPS),
-        "direct": ("conv_mfma_kernel<3x3> (direct implicit GEMM, v_mfma_f32_32x32x2_f32)", 1.0, FP32_MFMA_PEAK_TFLOPS),
-    }
-    dom_name, mult_ratio, pipe_peak = FAMILY[dom_key]
-    algorithmic = dom["flops"] / dom["ms"] / 1e9
-    executed = algorithmic * mult_ratio
-    traffic, traffic_src = None, None     # HBM-side bytes per launch from the committed PMC passes over the SAME launch population
-    try:
-        if args.config == "smmnist_big5_ngf96" and B == 64:      # the committed PMC passes are of this workload
-            for fn in sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")):
-                tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
-                if tj.get("family", "wino_f32") == dom_key and "traffic_bytes_per_launch" in tj:
-                    traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/" + fn      # the latest file of the family wins
-    except Exception:
-        traffic = None
-    roofline = dict(bound="mfma", kernel=dom_name,
-                    achieved=round(executed, 2), peak=pipe_peak, unit="TFLOP/s",
-                    frac=round(executed / pipe_peak, 4), traffic=traffic, traffic_source=traffic_src,
-                    note=("achieved / frac = flops the kernel EXECUTES on its matrix pipe (Winograd F(2x2,3x3): 16/36 of the "
-                          "direct-form multiplies; the bf16x3 kernel issues six bf16 piece products per fp32 product) / HIP-event time "
-                          "of its launches in one forward of the timed region / that pipe's dense peak, i.e. the matrix-pipe "
-                          "utilisation (agrees with PMC SQ_VALU_MFMA_BUSY_CYCLES, profiles/); algorithmic_* applies the contract's "
-                          "direct-form count 2*B*HW*Cout*Cin*9 against the FP32 matrix peak (the precision the path delivers) and may exceed 1"),
-                    algorithmic_achieved=round(algorithmic, 2), algorithmic_frac=round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
-                    algorithmic_bytes_per_launch=round(dom["bytes"] / dom["launches"]),
-                    launches=dom["launches"], avg_launch_us=round(1e3 * dom["ms"] / dom["launches"], 1),
-                    hbm_gbs=(round(traffic / (1e3 * dom["ms"] / dom["launches"]) / 1e3, 1) if traffic else None), hbm_peak_gbs=HBM_PEAK_GBS,
-                    flops_per_launch_avg=dom["flops"] / dom["launches"],
-                    conv3x3_families={k: dict(launches=v["launches"], ms=round(v["ms"], 3),
-                                              algorithmic_tflops=round(v["flops"] / v["ms"] / 1e9, 2) if v["ms"] else None)
-                                      for k, v in fam.items()},
-                    all_conv3x3=dict(launches=c3["launches"], ms=round(c3["ms"], 3), tflops=round(c3["flops"] / c3["ms"] / 1e9, 2)),
-                    forward_ms_events=round(fwd_ms, 3),
-                    forward_ms_events_note="sum of per-op event intervals of ONE instrumented forward: upper bound (event gaps, ~3 %)",
-                    breakdown=breakdown)
-    n1x1 = n1x1_h2 = 0
-    for i in range(n):
-        if kinds[i] == 3 and kss[i] == 1 and ms[i] != 0.0:
-            _lib.check(_lib.lib.mcvd_model_op_info(net._model, i, info), "op_info")
-            n1x1 += 1
-            n1x1_h2 += 1 if ((info[6] >> 12) and ((info[6] >> 4) & 15) == 14) else 0
-    arith = "f32"
-    if fam["wino_f16x2"]["launches"] or n1x1_h2:
-        arith = ("f32 storage and accumulation; %d of %d 3x3 convs, %d of %d 1x1 convs and the attention products (head dims 32..128) multiply "
-                 "operands rounded to two fp16 pieces (22 significant bits, 3 piece products on the fp16 matrix pipe, fp32 accumulate; every parity "
-                 "fixture holds at the fp32 tolerances, error vs fp64 measured next to the fp32-MFMA kernels in tests/test_gpu_parity.py::"
-                 "test_conv_f16x2_accuracy / test_conv1x1_f16x2_accuracy: smaller in every case); everything else f32; fp32_exact_leg = the same "
-                 "run with these kernels withheld" % (fam["wino_f16x2"]["launches"], c3["launches"], n1x1_h2, n1x1))
-    elif fam["wino_bf16x3"]["launches"]:
-        arith = "f32 (3x3 convs: exact bf16x3 operand split, 6 piece products, f32 accumulate; everything else f32 MFMA / f32 VALU)"
+    def run_leg(arith_name, f16x2, warmup, steps, seed0, tune_file):
+        """One timed leg under one arithmetic: W warm-up calls, then exactly K calls between fences (max over ranks)."""
+        net.set_option("f16x2", f16x2)                  # (a change of the option drops the kernel table of the other arithmetic)
+        pinned = None
+        if tune_file and os.path.exists(tune_file) and not args.no_tune_file:
+            net.load_tuning(tune_file)
+            pinned = os.path.relpath(tune_file, ROOT)
+        for i in range(warmup):
+            one_step(seed0 - 1 - i)
+        if rank == 0:
+            if tune_file and pinned is None and tune_file == args.tune_cache:
+                net.save_tuning(tune_file, [b1 - b0])
+            if args.save_tuning:
+                os.makedirs(args.save_tuning, exist_ok=True)
+                net.save_tuning(os.path.join(args.save_tuning, os.path.basename(table_path(arith_name))), [b1 - b0])
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            frames = one_step(seed0 + i)
+        fence()
+        dt_local = time.perf_counter() - t0
+        dt, per_rank = dt_local, [round(dt_local, 4)]
+        if world > 1:
+            tt = torch.tensor([dt_local], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            allt = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            per_rank = [round(v.item(), 4) for v in allt]
+            dt = max(per_rank)
+        assert torch.isfinite(frames).all() and frames.shape[0] == total and frames.shape[1] == config.data.channels * nfp
+        roofline, arith = roofline_of_leg(net, args, B, arith_name)
+        return dict(value=steps * total * nfp / dt, ms_per_step=1e3 * dt / steps, per_rank=per_rank, roofline=roofline, dtype=arith,
+                    kernel_table=pinned or "autotuned in this run (HIP-event timing per distinct layer shape)")
 
-    # ---- reported only: the same timed region with every product at fp32 accuracy (two-piece fp16 kernels withheld; N = 1 only)
-    fp32_leg = None
-    if world == 1 and not args.no_fp32_leg and fam["wino_f16x2"]["launches"]:
-        net.set_option("f16x2", 0)                       # drops the kernel table: the next call re-tunes among the fp32-accurate kernels
-        one_step(-100)
-        fence()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            one_step(500 + i)
-        fence()
-        dt1 = time.perf_counter() - t1
-        fp32_leg = dict(value=round(args.steps * total * nfp / dt1, 3), unit="frames/s", ms_per_step=round(1e3 * dt1 / args.steps, 2),
-                        note="same workload, same K steps, context option f16x2 = 0: 3x3 / 1x1 convs and attention on the fp32 MFMA or the "
-                             "exact bf16x3 split (autotuned), nothing on two-piece fp16 operands")
-        net.set_option("f16x2", 1)
+    main_arith = "f16x2" if args.f16x2 else "bf16x3"
+    main_leg = run_leg(main_arith, args.f16x2, args.warmup, args.steps, 0, args.tune_cache or table_path(main_arith))
+    # ---- reported only (N = 1): the same timed region with the two-piece fp16 kernels offered as well (narrower arithmetic: an option)
+    second = None
+    if world == 1 and not args.no_second_leg and not args.f16x2:
+        second = run_leg("f16x2", 1, 1, args.steps, 500, table_path("f16x2"))
+        net.set_option("f16x2", 0)
 
     if rank == 0:
+        import ctypes as C
+        from mcvd_pytorch_amd import _lib
         cap, rep = C.c_int64(), C.c_int64()
         _lib.lib.mcvd_model_graph_stats(net._model, C.byref(cap), C.byref(rep))
         fwd_per_step = (subsample + 1) * (n_blocks if autoreg else 1)
-        res = dict(metric=f"sampled frames/sec (whole node), {label}", value=round(value, 3),
+        res = dict(metric=f"sampled frames/sec (whole node), {label}", value=round(main_leg["value"], 3),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(1e3 * dt / args.steps, 2), higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype=arith, data="synthetic",
+                   ms_per_step=round(main_leg["ms_per_step"], 2), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype=main_leg["dtype"], data="synthetic",
                    config=dict(workload=f"{args.config}: " + (f"video_gen, {n_blocks} autoregressive blocks of " if autoreg else "")
                                + f"ddpm_sampler subsample={subsample} (+1 denoise forward), "
                                f"{config.data.image_size}x{config.data.image_size}, {config.data.num_frames_cond} cond + {nfr} pred frames"
@@ -376,14 +397,19 @@ def main():
                                + f", batch {B}/GPU, random-init weights, Philox noise",
                                global_batch=total, frames_per_step=total * nfp, forwards_per_step=fwd_per_step,
                                parallelism=f"sample-sharded x{world} (1 weight broadcast + 1 final all_gather)",
+                               kernel_table=main_leg["kernel_table"],
                                hip_graph=dict(enabled=bool(args.graph), captures=cap.value, replays=rep.value)),
-                   per_rank_s=per_rank, roofline=roofline)
-        if fp32_leg:
-            res["fp32_exact_leg"] = fp32_leg
+                   per_rank_s=main_leg["per_rank"], roofline=main_leg["roofline"])
+        if second:
+            res["f16x2_leg"] = dict(value=round(second["value"], 3), unit="frames/s", ms_per_step=round(second["ms_per_step"], 2),
+                                    dtype=second["dtype"], kernel_table=second["kernel_table"], roofline=second["roofline"],
+                                    note="same workload, same K steps, context option f16x2 = 1 (1 warm-up call: re-tune or table load): "
+                                         "reported only, narrower arithmetic than the reference's")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(config, sd, subsample, kept_fraction=nfp / (n_blocks * nfr) if autoreg else 1.0)
-                res["cpu_baseline"]["speedup"] = round(value / res["cpu_baseline"]["value"], 1)
+                res["cpu_baseline"]["speedup"] = round(main_leg["value"] / res["cpu_baseline"]["value"], 1)
+                res["cpu_baseline"]["speedup_note"] = "headline (fp32-equivalent) value / cpu_baseline value"
             except Exception as e:      # the baseline is reporting only; never lose the GPU line
                 res["cpu_baseline"] = dict(value=None, unit="frames/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e}")
         print(json.dumps(res), flush=True)

@@ -189,6 +189,12 @@ int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, doub
 /* Static description of op i of the plan: info = {kind, reference module index, conv ks, H, Cin, Cout, has_residual, has_prologue}. */
 int mcvd_model_op_info(mcvd_model* m, int i, int info[8]);
 
+/* The kernel family conv op i REALLY ran at its last launch (the ids of mcvd_last_conv_kernel: 0-3 direct implicit GEMM, 4 / 8 fp32
+ * Winograd, 5 / 6 / 9 fp32 1x1 GEMM, 10 / 11 three-piece bf16 Winograd, 12 / 13 two-piece fp16 Winograd, 14 two-piece fp16 1x1 GEMM,
+ * 15 three-piece bf16 1x1 GEMM; -2 the one-thread-per-output test kernel); -1 for an op that is not a conv or never ran.  Tests
+ * use it to assert that a forced or imported kernel table is what executed (a graph replay re-runs what its capture recorded). */
+int mcvd_model_op_kernel(mcvd_model* m, int i);
+
 /* Debug/test aid: copy the output tensor of reference module `module` (index in all_modules, ncsnpp_more.py:249) from the
  * last forward at batch size B into dst_device ([B, C, H, H], capacity in floats).  The workspace keeps every intermediate of a
  * forward, so this needs no re-execution.  Module 1 returns SiLU(temb) [B, 4*ngf] (C = 4*ngf, H = 0). */

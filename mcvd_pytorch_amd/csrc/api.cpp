@@ -105,6 +105,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "naive_attn")) ctx->naive_attn = value;
     else if (!strcmp(key, "graph")) ctx->graph = value;
     else if (!strcmp(key, "conv_shape")) ctx->conv_shape = value;
+    else if (!strcmp(key, "conv_shape1")) ctx->conv_shape1 = value;
     else if (!strcmp(key, "profile")) ctx->profile = value;
     else if (!strcmp(key, "conv_wdma")) ctx->conv_wdma = value;
     else if (!strcmp(key, "autotune")) ctx->autotune = value;
@@ -313,9 +314,13 @@ int mcvd_model_finalize(mcvd_model* m) {
                 if (int rc = launch_pack_wino_weight(m->blob + w.off, m->packed + p.wpw, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
             if (p.wph >= 0 && p.ks == 3)
                 if (int rc = launch_pack_wino2h_weight(m->blob + w.off, m->packed + p.wph, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
+            if (p.wpb >= 0 && p.ks == 3)
+                if (int rc = launch_pack_wino3_weight(m->blob + w.off, m->packed + p.wpb, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
         }
         if (p.wph >= 0 && p.ks == 1)           // from the packed fp32 matrix: every fused weight (q | k | v) and the padding are in place
-            if (int rc = launch_pack_conv1x1_h2(m->packed + p.wp, m->packed + p.wph, p.CinP, p.CoutP, s)) return rc;
+            if (int rc = launch_pack_conv1x1_h2(m->packed + p.wp, m->packed + p.wph, p.CinP, p.CoutP, s, 2)) return rc;
+        if (p.wpb >= 0 && p.ks == 1)
+            if (int rc = launch_pack_conv1x1_h2(m->packed + p.wp, m->packed + p.wpb, p.CinP, p.CoutP, s, 3)) return rc;
     }
     for (const DenseEntry& e : m->dense) {
         const ParamInfo& w = m->params[m->find_param(e.weight.c_str())];
@@ -447,9 +452,10 @@ int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* co
     MCVD_REQUIRE(n == (int)m->ops.size(), "set_tuning: %d entries for a plan of %d ops (tuning of another model?)", n, (int)m->ops.size());
     for (int i = 0; i < n; ++i) {
         const bool conv = m->ops[i].kind == OP_CONV;
-        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 14 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
+        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 15 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
                      "set_tuning: entry %d (shape %d, cout tile %d) does not fit op kind %d", i, shapes[i], cots[i], (int)m->ops[i].kind);
     }
+    if (m->ctx) m->sync_tuning_options();         // the table belongs to the options in force now; a later option change drops it
     m->tuned_cache[B] = {std::vector<int>(shapes, shapes + n), std::vector<int>(cots, cots + n)};
     if (m->tuned_B == B) m->tuned_B = 0;              // re-read on the next forward
     return 0;
@@ -525,6 +531,11 @@ int mcvd_model_op_info(mcvd_model* m, int i, int info[8]) {
     info[6] = op.res.kind != REF_NONE; info[7] = op.coef.kind != REF_NONE;
     if ((size_t)i < m->tuned_shape.size() && m->tuned_shape[i] >= 0) info[6] |= (m->tuned_shape[i] << 4) | (m->tuned_cot[i] << 8) | (1 << 12);
     return 0;
+}
+
+int mcvd_model_op_kernel(mcvd_model* m, int i) {
+    if (!m || i < 0 || i >= (int)m->ops.size() || m->ops[i].kind != OP_CONV || (size_t)i >= m->ran_kernel.size()) return -1;
+    return m->ran_kernel[i];
 }
 
 int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst, int64_t capacity, int* C, int* H) {
@@ -795,9 +806,12 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     const bool wino = (ctx->conv_shape == 4 || ctx->conv_shape == 8 || (ctx->conv_shape >= 10 && ctx->conv_shape <= 13)) &&
                       conv_wino_supported(ks, H, W);
     const bool wino_h = wino && (ctx->conv_shape == 12 || ctx->conv_shape == 13);     // fp16 pieces as well
+    const bool wino_b = wino && (ctx->conv_shape == 10 || ctx->conv_shape == 11);     // bf16 pieces as well
+    const int np1 = (ks == 1 && ctx->conv_shape == 14) ? 2 : (ks == 1 && ctx->conv_shape == 15) ? 3 : 0;      // 1x1 pieces
     const size_t ufloats = wino ? (size_t)a.CinP * 16 * a.CoutP : 0;
     const size_t hfloats = wino_h ? (size_t)((conv_wino2h_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4)
-                                  : (ks == 1 && ctx->conv_shape == 14) ? (size_t)((conv1x1_h2_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4) : 0;
+                           : wino_b ? (size_t)((conv_wino3_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4)
+                           : np1 ? (size_t)((conv1x1_h2_weight_floats(a.CinP, a.CoutP, np1) + 3) / 4 * 4) : 0;
     const size_t pfloats = (wino && (ctx->conv_shape == 8 || ctx->conv_shape == 11 || ctx->conv_shape == 13)) ? (size_t)2 * B * Cout * H * W : 0;     // K-split partial results
     if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats + hfloats + pfloats) * sizeof(float))) return rc;
     MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP + ufloats + hfloats) * sizeof(float), ctx->stream));
@@ -808,18 +822,22 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
             if (int rc = launch_pack_wino2h_weight(w, ctx->scratch + wfloats + a.CoutP + ufloats, Cout, a.Cin, a.CinP, a.CoutP, ctx->stream)) return rc;
             a.wph = ctx->scratch + wfloats + a.CoutP + ufloats;
         }
+        if (wino_b) {
+            if (int rc = launch_pack_wino3_weight(w, ctx->scratch + wfloats + a.CoutP + ufloats, Cout, a.Cin, a.CinP, a.CoutP, ctx->stream)) return rc;
+            a.wpb = ctx->scratch + wfloats + a.CoutP + ufloats;
+        }
         if (pfloats) a.part = ctx->scratch + wfloats + a.CoutP + ufloats + hfloats;
     }
     if (int rc = launch_pack_conv_weight(w, ctx->scratch, Cout, a.Cin, ks, a.CinP, a.CoutP, 0, 0, ctx->stream)) return rc;
-    if (ks == 1 && ctx->conv_shape == 14) {
-        if (int rc = launch_pack_conv1x1_h2(ctx->scratch, ctx->scratch + wfloats + a.CoutP, a.CinP, a.CoutP, ctx->stream)) return rc;
-        a.wph = ctx->scratch + wfloats + a.CoutP;
+    if (np1) {
+        if (int rc = launch_pack_conv1x1_h2(ctx->scratch, ctx->scratch + wfloats + a.CoutP, a.CinP, a.CoutP, ctx->stream, np1)) return rc;
+        (np1 == 2 ? a.wph : a.wpb) = ctx->scratch + wfloats + a.CoutP;
     }
     MCVD_HIP_CHECK(hipMemcpyAsync(ctx->scratch + wfloats, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     a.wp = ctx->scratch;
     a.bias = ctx->scratch + wfloats;
     a.shape_hint = ctx->conv_shape;
-    if ((ctx->conv_shape == 5 || ctx->conv_shape == 6 || ctx->conv_shape == 9 || ctx->conv_shape == 14) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
+    if ((ctx->conv_shape == 5 || ctx->conv_shape == 6 || ctx->conv_shape == 9 || ctx->conv_shape == 14 || ctx->conv_shape == 15) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
     a.wdma = ctx->conv_wdma;
     a.dbg = ctx->dbg;
     a.stats = ctx->naive_conv ? nullptr : ctx->stats_buf;
@@ -867,7 +885,7 @@ int mcvd_op_gn_coef(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int
 
 int mcvd_op_attention(mcvd_ctx* ctx, const float* qkv, float* out, int B, int C, int heads, int HW) {
     MCVD_REQUIRE(ctx && qkv && out, "op_attention: NULL argument");
-    return launch_attention(ctx->naive_attn, ctx->f16x2, qkv, out, B, C, heads, HW, ctx->stream);
+    return launch_attention(ctx->naive_attn, ctx->f16x2, ctx->bf16x3, qkv, out, B, C, heads, HW, ctx->stream);
 }
 
 int mcvd_op_fir2(mcvd_ctx* ctx, const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W) {

@@ -62,6 +62,8 @@ struct ConvArgs {
     const float* wpw;     // Winograd-transformed weights, operand-major (conv_wino.cpp: pack_wino_weight_kernel; 3x3 only), or null
     const float* wph;     // the weights pre-split into two fp16 pieces + header: 3x3 Winograd-transformed (conv_wino2h.cpp:
                           // launch_pack_wino2h_weight) or 1x1 (conv1x1_h2.cpp: launch_pack_conv1x1_h2), or null
+    const float* wpb;     // the weights pre-split into three bf16 pieces (exact; no header): 3x3 Winograd-transformed (conv_wino3.cpp:
+                          // launch_pack_wino3_weight) or 1x1 (launch_pack_conv1x1_h2 with np = 3), or null
     const float* bias;    // [Cout]
     const float* res;     // residual [B][Cout][H][W] or null
     float out_scale;
@@ -70,9 +72,9 @@ struct ConvArgs {
     int ks;               // 1 or 3
     int cot;              // cout tile in units of 32 channels (1..4); CoutP % (32*cot) == 0
     int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile, 3 split-K+WDB, 4 Winograd (8: with a 2-way K split), 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels per chunk),
-                          // 9 the 1x1 GEMM with 64 pixels per wave, 10 Winograd on the bf16 pipe with split operands (11: with a 2-way K split),
+                          // 9 the 1x1 GEMM with 64 pixels per wave, 10 Winograd on the bf16 pipe with three-piece operands (11: with a 2-way K split),
                           // 12 Winograd on the fp16 pipe with two-piece operands (13: with a 2-way K split), 14 the 1x1 GEMM on the fp16 pipe
-                          // with two-piece operands
+                          // with two-piece operands, 15 the 1x1 GEMM on the bf16 pipe with three-piece operands
     int ksplit;           // Winograd kernel only: 2 = two workgroups per tile contract half the input channels each into
                           // `part`, a second pass sums the halves; 0/1 = off
     float* part;          // ksplit == 2: scratch for the two partial results, 2 * B*Cout*H*W floats
@@ -101,22 +103,25 @@ int conv_wino_cout_tile(int Cout);
 bool conv_wino_usable(const ConvArgs& a);            // shape id 4 applies to this launch
 int launch_conv_wino(const ConvArgs& a, hipStream_t s);
 int launch_wino_ksplit_reduce(const ConvArgs& a, hipStream_t s);      // second pass of the 2-way K split (both Winograd kernels)
-// the same convolution with the channel contraction on the bf16 matrix pipe at fp32 accuracy (three-way split of both operands,
-// six piece products; conv_wino3.cpp): tile shape ids 10 / 11 (11: 2-way K split); shares the packed weights of shape id 4
+// the same convolution with the channel contraction on the bf16 matrix pipe at fp32 accuracy (three exact bf16 pieces per operand,
+// six piece products, weights pre-split at pack time; conv_wino3.cpp): tile shape ids 10 / 11 (11: 2-way K split); needs ConvArgs::wpb
 bool conv_wino3_usable(const ConvArgs& a);
 int launch_conv_wino3(const ConvArgs& a, hipStream_t s);
+long conv_wino3_weight_floats(int CinP, int CoutP);           // size of the wpb buffer, in floats
+int launch_pack_wino3_weight(const float* w, float* wb, int Cout, int Cin, int CinP, int CoutP, hipStream_t s);    // wb zero-filled
 // the same convolution on the fp16 matrix pipe, operands split into two fp16 pieces (22-bit operands, three piece products; weights
 // pre-split at pack time; conv_wino2h.cpp): tile shape ids 12 / 13 (13: 2-way K split); needs ConvArgs::wph
 bool conv_wino2h_usable(const ConvArgs& a);
 int launch_conv_wino2h(const ConvArgs& a, hipStream_t s);
 long conv_wino2h_weight_floats(int CinP, int CoutP);          // size of the wph buffer (header + pieces), in floats
 int launch_pack_wino2h_weight(const float* w, float* wh, int Cout, int Cin, int CinP, int CoutP, hipStream_t s);   // wh zero-filled
-// 1x1 GEMM on the fp16 matrix pipe with two-piece operands (conv1x1_h2.cpp): tile shape id 14, cout tile a.cot = 1..4; needs
-// ConvArgs::wph (launch_pack_conv1x1_h2 from the packed fp32 matrix wp)
-bool conv1x1_h2_supported(const ConvArgs& a, int cot);
-int launch_conv1x1_h2(const ConvArgs& a, int cot, hipStream_t s);
-long conv1x1_h2_weight_floats(int CinP, int CoutP);
-int launch_pack_conv1x1_h2(const float* wp, float* wh, int CinP, int CoutP, hipStream_t s);      // wh[0] zero on entry
+// 1x1 GEMM on the 16-bit matrix pipes with split operands (conv1x1_h2.cpp), cout tile a.cot = 1..4: np = 3 three bf16 pieces
+// (fp32-equivalent; tile shape id 15; needs ConvArgs::wpb), np = 2 two fp16 pieces (tile shape id 14; needs ConvArgs::wph); the
+// pieces come from the packed fp32 matrix wp (launch_pack_conv1x1_h2)
+bool conv1x1_h2_supported(const ConvArgs& a, int cot, int np);
+int launch_conv1x1_h2(const ConvArgs& a, int cot, hipStream_t s, int np);
+long conv1x1_h2_weight_floats(int CinP, int CoutP, int np);
+int launch_pack_conv1x1_h2(const float* wp, float* wh, int CinP, int CoutP, hipStream_t s, int np);      // np = 2: wh[0] zero on entry
 // all-DMA 1x1 GEMM (conv1x1_dma.cpp): tile shape ids 5 / 6; cot_req <= 0 picks the default cout tile
 bool conv1x1_dma_supported(const ConvArgs& a, int ck, int pxw = 1);     // ck: channels per chunk, 16 (shape id 5) or 32 (shape id 6); pxw = 2: 256-pixel tiles (shape id 9, ck 16)
 int conv1x1_dma_cout_tile(int CoutP);
@@ -151,12 +156,13 @@ int launch_gn_finalize(const GnArgs& a, const float* st0, int np0, const float* 
 bool attention_mfma_supported(int C, int heads, int HW);      // head dim 32..256 in steps of 32, HW % 32 == 0; else the general kernel
 int launch_attention_mfma(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
 int launch_attention_naive(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
-// the flash kernel on the fp16 matrix pipe with two-piece operands (attention_h2.cpp): head dim 32..128 in steps of 32, HW % 32 == 0
+// the flash kernel on the 16-bit matrix pipes with split operands (attention_h2.cpp; np = 3 three bf16 pieces, fp32-equivalent; np = 2
+// two fp16 pieces): head dim 32..128 in steps of 32, HW % 32 == 0
 bool attention_h2_supported(int C, int heads, int HW);
-int launch_attention_h2(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
+int launch_attention_h2(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s, int np);
 // which attention kernel a launch takes: mode = the "naive_attn" option (0 auto: the fp16-pipe kernel when f16x2 is on and it applies,
 // else the fp32 flash kernel; 1 the one-thread-per-query kernel; 2 the fp32 flash kernel; 3 the fp16-pipe kernel where it applies)
-int launch_attention(int mode, int f16x2, const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
+int launch_attention(int mode, int f16x2, int bf16x3, const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
 
 // ------------------------------------------------------------------ FIR resampling
 int launch_fir2(const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W,

@@ -1,71 +1,60 @@
-// Multi-head self-attention core (layerspp.py:237-244), the flash-style kernel of attention.cpp on the FP16 matrix pipe with every
-// MFMA operand split into TWO fp16 pieces (conv_wino2h.cpp has the arithmetic: v ~= v1 + v2, 22 significant bits, three piece
-// products a1 b2 + a2 b1 + a1 b1 accumulated in fp32).  attention.cpp is bound by the fp32 matrix pipe (MFMA-busy 0.68, waves
-// issue-stalled 76 % of the time: profiles/r02_pmc_*_f16x2.txt); three v_mfma_f32_32x32x16_f16 per 16-deep step take 3/16 of its
-// pipe time.  Same decomposition: one workgroup = 4 waves = 4 x 32 queries of one (sample, head), key tiles of 32, S^T (keys on the
-// accumulator rows) so that the softmax is in-lane and P is already the B operand of the PV product:
+// Multi-head self-attention core (layerspp.py:237-244), the flash-style kernel of attention.cpp on the 16-bit matrix pipes with every
+// MFMA operand split into pieces (pieces.h has the arithmetic):
+//   NP = 3: three bf16 pieces, six piece products -- fp32-equivalent, full fp32 range: the default attention kernel.
+//   NP = 2: two fp16 pieces, three piece products (22-bit operands; context option "f16x2").
+// attention.cpp is bound by the fp32 matrix pipe (MFMA-busy 0.68, waves issue-stalled 76 % of the time:
+// profiles/r02_pmc_*.txt); 3 (6) MFMAs of the 16x faster pipe per 16-deep step take 3/16 (6/16) of its pipe time.  Same
+// decomposition: one workgroup = 4 waves = 4 x 32 queries of one (sample, head), key tiles of 32, S^T (keys on the accumulator
+// rows) so that the softmax is in-lane and P is already the B operand of the PV product:
 //   S^T[key][query] = sum_c K[c][key] * Q[c][query]      A = K tile pieces (LDS, lane = key), B = Q pieces (registers, lane = query)
 //   O[c][query]    += sum_key V[c][key] * P[key][query]  A = V tile pieces (LDS, lane = c),   B = P pieces (registers)
-// What changes:
-//   * Q is scaled by 2^4 and split once per workgroup (the pieces take the registers the fp32 fragment took).
+// What changes against attention.cpp:
+//   * Q is split once per workgroup (the pieces take the registers the fp32 fragment took).
 //   * the threads that stage a K / V tile split it (each element once per workgroup, not once per wave) and park the pieces in the
-//     MFMA A-operand order [step][piece][64 lanes][4 dwords]: one conflict-free ds_read_b128 per operand.  K-slot conventions:
+//     MFMA A-operand order [step][piece][64 lanes][4 dwords]: one ds_read_b128 per operand.  K-slot conventions:
 //       S product : lane half h, element e of step st  <->  channel 16 st + 2e + h              (dword j = channels 4j + h, 4j + 2 + h)
 //       PV product: lane half h, element e of step s2  <->  key (r&3) + 8 (r>>2) + 4h, r = 8 s2 + e  -- the key whose probability
 //                   sits in accumulator register r of the S^T tile; a dword = two consecutive keys.
-//   * the probabilities are produced times 2^12 (folded into the exponent: exp(s - m + 12 ln 2); the row sums carry the same
-//     factor and it cancels), so their second pieces stay clear of the fp16 denormal range; K and V are staged times 2^4.  The score
-//     scale D^-0.5 absorbs the 2^-8 of the S product, the final 1 / l the 2^-4 of V.  All scales are powers of two: exact.
+//   * NP = 2 only: Q, K, V enter the pieces times 2^4 and the probabilities times 2^12 (folded into the exponent:
+//     exp(s - m + 12 ln 2); the row sums carry the same factor and it cancels), so second pieces stay clear of the fp16 denormal
+//     range.  The score scale D^-0.5 absorbs the 2^-8 of the S product, the final 1 / l the 2^-4 of V.  All scales are powers of
+//     two: exact.  Nothing is clamped: a q / k / v beyond 65504 / 16 becomes Inf and the output NaN (reported: model.cpp range guard).
+//     NP = 3 scales nothing.
+//   * LDS layouts chosen for the STAGING stores (round 2 scattered single dwords 16 bytes apart: 8-way bank conflicts on the K stores,
+//     4-way on the V stores, 62 % of the LDS-active cycles, profiles/r02_pmc_sq_wave_states_f16x2.txt):
+//       K pieces as dword planes [step][piece][dword j][64 lanes]: a staging thread owns 4 consecutive keys of a channel pair = 4
+//         consecutive dwords of one plane -> ONE ds_write_b128 per piece, 8 lanes = 128 contiguous bytes; the S product reads its
+//         operand with four conflict-free ds_read_b32.
+//       V pieces stay in operand order [sub-tile][step][piece][64 lanes][4 dwords] (one ds_read_b128 per operand); the staging lanes
+//         are permuted (lane = g | row << 1 | h << 4 | s2 << 5) so that 16 consecutive lanes write 128 contiguous bytes.
 // Head dims 32..128 (Q pieces + O accumulators + the register prefetch of the next tile fit two waves per SIMD); anything else stays
 // on attention.cpp.
 #include <math.h>
 
 #include "../common.h"
+#include "pieces.h"
 
 namespace mcvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr float AH_OP_SCALE = 16.0f;          // Q, K, V enter the fp16 pieces times 2^4
-constexpr float AH_F16_MAX = 65504.0f;
-constexpr float AH_P_LOG = 8.317766166719343f;        // 12 ln 2: probabilities times 2^12
+constexpr float AH_P_LOG = 8.317766166719343f;        // 12 ln 2: NP = 2 probabilities times 2^12
 
-__device__ __forceinline__ unsigned ah_cvt_pk(float lo, float hi) {
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-}
-// two-way fp16 split of a pair (conv_wino2h.cpp: h2_split2); CLAMP: the inputs may exceed the fp16 range
-template <bool CLAMP>
-__device__ __forceinline__ void ah_split2(float x, float y, unsigned& w1, unsigned& w2) {
-    if (CLAMP) {
-        x = __builtin_amdgcn_fmed3f(x, -AH_F16_MAX, AH_F16_MAX);
-        y = __builtin_amdgcn_fmed3f(y, -AH_F16_MAX, AH_F16_MAX);
-    }
-    w1 = ah_cvt_pk(x, y);
-    float rx, ry;
-    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(w1), "v"(x));
-    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ry) : "v"(w1), "v"(y));
-    w2 = ah_cvt_pk(rx, ry);
-}
-__device__ __forceinline__ f32x16 ah_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-template <int DT>   // head dim D = 32*DT
+template <int NP, int DT>   // head dim D = 32*DT
 __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int heads, int S,
                                                           float scale_s) {
+    typedef Pieces<NP> PX;
     constexpr int D = 32 * DT, NST = D / 16;
     constexpr int NIK = (4 * D + 255) / 256;     // K staging items per thread: (row pair, 4 keys) -> 2 float4
     constexpr int NIV = DT;                      // V staging items per thread: (channel, 4 keys) -> 1 float4   (8 D / 256)
+    constexpr float OPS = NP == 2 ? PX::ACT_SCALE : 1.0f;          // operand scale of Q, K, V
     extern __shared__ __attribute__((aligned(16))) float smem_attn_h2[];
-    unsigned* sK = reinterpret_cast<unsigned*>(smem_attn_h2);      // [NST][2 pieces][64 lanes][4]
-    unsigned* sV = sK + NST * 512;                                  // [DT][2 steps][2 pieces][64 lanes][4]
+    unsigned* sK = reinterpret_cast<unsigned*>(smem_attn_h2);      // [NST][NP pieces][4 dwords j][64 lanes]
+    unsigned* sV = sK + NST * NP * 256;                             // [DT][2 steps][NP pieces][64 lanes][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int bh = blockIdx.y;
@@ -77,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
     const bool active = q0 < S;
 
     // Q pieces: lane (query l31, half) holds channels 16 st + 2e + half, e = 0..7 of every step; dword j = elements (2j, 2j+1)
-    u32x4 q1[NST], q2[NST];
+    u32x4 qp[NST][NP];
 #pragma unroll
     for (int st = 0; st < NST; ++st)
 #pragma unroll
@@ -85,9 +74,10 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
             const int c0 = 16 * st + 4 * j + half;
             const float a0 = active ? qb[(long)c0 * S + q0 + l31] : 0.0f;
             const float a1 = active ? qb[(long)(c0 + 2) * S + q0 + l31] : 0.0f;
-            unsigned w1, w2;
-            ah_split2<true>(a0 * AH_OP_SCALE, a1 * AH_OP_SCALE, w1, w2);
-            q1[st][j] = w1; q2[st][j] = w2;
+            unsigned w[NP];
+            PX::template split<false>(a0 * OPS, a1 * OPS, w);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) qp[st][p][j] = w[p];
         }
 
     f32x16 o[DT];
@@ -98,7 +88,10 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
     float m_run = -1e30f, l_run = 0.0f;
 
     // ---- staging roles.  K item idx = i*256 + tid < 4D: row pair rp = idx >> 3 = (st, j, h) -> rows c, c + 2 with c = 16 st + 4j + h,
-    //      keys 4 kq .. 4 kq + 3 (kq = idx & 7).  V item idx = i*256 + tid: channel c = idx >> 3, keys 4q .. 4q + 3 (q = idx & 7).
+    //      keys 4 kq .. 4 kq + 3 (kq = idx & 7).  V item (i, wave, lane): channel c = 32 i + 8 wave + ((lane >> 1) & 7), keys 4q .. 4q + 3 with
+    //      q = (s2, g, h) = (lane >> 5, lane & 1, (lane >> 4) & 1): the lane order that makes the b64 stores below contiguous.
+    const int v_c = wave * 8 + ((lane >> 1) & 7), v_h = (lane >> 4) & 1, v_s2 = lane >> 5, v_g = lane & 1;
+    const int v_q = v_s2 * 4 + v_g * 2 + v_h;
     f32x4 rk0[NIK], rk1[NIK], rv[NIV];
     const int ntiles = S / 32;
     auto gload = [&](int t) {
@@ -113,8 +106,7 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
         }
 #pragma unroll
         for (int i = 0; i < NIV; ++i) {
-            const int idx = i * 256 + tid;
-            rv[i] = *reinterpret_cast<const f32x4*>(vb + (long)(idx >> 3) * S + t * 32 + (idx & 7) * 4);
+            rv[i] = *reinterpret_cast<const f32x4*>(vb + (long)(i * 32 + v_c) * S + t * 32 + v_q * 4);
         }
     };
     gload(0);
@@ -127,52 +119,53 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
             if (NIK * 256 == 4 * D || idx < 4 * D) {
                 const int rp = idx >> 3, kq = idx & 7;
                 const int st = rp >> 3, j = (rp >> 1) & 3, h = rp & 1;
-                unsigned* d1 = sK + ((st * 2 + 0) * 64 + h * 32 + kq * 4) * 4 + j;       // key kq*4 + i4: + 4 dwords each
+                // plane (st, piece, j): dwords h*32 + key; the thread's four keys are four consecutive dwords
+                unsigned* d1 = sK + (st * NP * 4 + j) * 64 + h * 32 + kq * 4;
+                unsigned w[4][NP];
 #pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
-                    unsigned w1, w2;
-                    ah_split2<true>(rk0[i][i4] * AH_OP_SCALE, rk1[i][i4] * AH_OP_SCALE, w1, w2);
-                    d1[i4 * 4] = w1;
-                    d1[i4 * 4 + 256] = w2;            // the second piece: + 64 lanes x 4 dwords
-                }
+                for (int i4 = 0; i4 < 4; ++i4) PX::template split<false>(rk0[i][i4] * OPS, rk1[i][i4] * OPS, w[i4]);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d1 + p * 256) = u32x4{w[0][p], w[1][p], w[2][p], w[3][p]};
             }
         }
 #pragma unroll
         for (int i = 0; i < NIV; ++i) {
-            const int idx = i * 256 + tid;
-            const int c = idx >> 3, q = idx & 7;
-            const int ct = c >> 5, m = c & 31, h = q & 1, s2 = q >> 2, j0 = 2 * ((q >> 1) & 1);
-            unsigned a1, a2, b1, b2;
-            ah_split2<true>(rv[i][0] * AH_OP_SCALE, rv[i][1] * AH_OP_SCALE, a1, a2);
-            ah_split2<true>(rv[i][2] * AH_OP_SCALE, rv[i][3] * AH_OP_SCALE, b1, b2);
-            unsigned* d1 = sV + (((ct * 2 + s2) * 2 + 0) * 64 + h * 32 + m) * 4 + j0;
-            *reinterpret_cast<u32x2*>(d1) = u32x2{a1, b1};
-            *reinterpret_cast<u32x2*>(d1 + 256) = u32x2{a2, b2};
+            const int c = i * 32 + v_c;
+            const int ct = c >> 5, m = c & 31, j0 = 2 * v_g;
+            unsigned wa[NP], wb[NP];
+            PX::template split<false>(rv[i][0] * OPS, rv[i][1] * OPS, wa);
+            PX::template split<false>(rv[i][2] * OPS, rv[i][3] * OPS, wb);
+            unsigned* d1 = sV + ((ct * 2 + v_s2) * NP * 64 + v_h * 32 + m) * 4 + j0;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(d1 + p * 256) = u32x2{wa[p], wb[p]};
         }
         __syncthreads();
         if (t + 1 < ntiles) gload(t + 1);
 
-        // ---- S^T tile: 32 keys x 32 queries, times 2^8
+        // ---- S^T tile: 32 keys x 32 queries (NP = 2: times 2^8)
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.0f;
-        const u32x4* sKl = reinterpret_cast<const u32x4*>(sK) + lane;
+        const unsigned* sKl = sK + lane;
 #pragma unroll
         for (int s = 0; s < NST; ++s) {
-            const u32x4 k1 = sKl[(s * 2 + 0) * 64], k2 = sKl[(s * 2 + 1) * 64];
-            st = ah_mfma(k1, q2[s], st);
-            st = ah_mfma(k2, q1[s], st);
-            st = ah_mfma(k1, q1[s], st);
+            u32x4 kp[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kp[p][j] = sKl[((s * NP + p) * 4 + j) * 64];
+#pragma unroll
+            for (int k = 0; k < PX::NPROD; ++k) st = PX::mfma(kp[PX::PA(k)], qp[s][PX::PB(k)], st);
         }
 
-        // ---- online softmax over keys (this lane: 16 keys of query l31; partner lane^32 holds the other 16); p times 2^12
+        // ---- online softmax over keys (this lane: 16 keys of query l31; partner lane^32 holds the other 16); NP = 2: p times 2^12
         float mt = -1e30f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] *= scale_s; mt = fmaxf(mt, st[r]); }
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);
         const float alpha = __expf(m_run - m_new);
-        const float shift = AH_P_LOG - m_new;
+        const float shift = (NP == 2 ? AH_P_LOG : 0.0f) - m_new;
         float ps = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = __expf(st[r] + shift); ps += st[r]; }
@@ -182,37 +175,43 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
         for (int ct = 0; ct < DT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
-        u32x4 p1[2], p2[2];                       // B operand of the PV product: step s2, dword j = registers 8 s2 + 2j, + 1
+        u32x4 pp[2][NP];                          // B operand of the PV product: step s2, dword j = registers 8 s2 + 2j, + 1
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                unsigned w1, w2;
-                ah_split2<false>(st[8 * s2 + 2 * j], st[8 * s2 + 2 * j + 1], w1, w2);      // 0 <= p <= 2^12
-                p1[s2][j] = w1; p2[s2][j] = w2;
+                unsigned w[NP];
+                PX::template split<false>(st[8 * s2 + 2 * j], st[8 * s2 + 2 * j + 1], w);      // 0 <= p <= 1 (NP = 2: 2^12)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) pp[s2][p][j] = w[p];
             }
 
         // ---- O += V * P
         const u32x4* sVl = reinterpret_cast<const u32x4*>(sV) + lane;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            u32x4 v1[DT], v2[DT];
+            // two cout sub-tiles at a time: their MFMAs alternate between two accumulators, and only 2 * NP operand quads are live
 #pragma unroll
-            for (int ct = 0; ct < DT; ++ct) {
-                v1[ct] = sVl[((ct * 2 + s2) * 2 + 0) * 64];
-                v2[ct] = sVl[((ct * 2 + s2) * 2 + 1) * 64];
+            for (int c0 = 0; c0 < DT; c0 += 2) {
+                constexpr int G = 2;
+                u32x4 vp[G][NP];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (c0 + g < DT) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) vp[g][p] = sVl[(((c0 + g) * 2 + s2) * NP + p) * 64];
+                    }
+#pragma unroll
+                for (int k = 0; k < PX::NPROD; ++k)
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (c0 + g < DT) o[c0 + g] = PX::mfma(vp[g][PX::PA(k)], pp[s2][PX::PB(k)], o[c0 + g]);
             }
-#pragma unroll
-            for (int ct = 0; ct < DT; ++ct) o[ct] = ah_mfma(v1[ct], p2[s2], o[ct]);
-#pragma unroll
-            for (int ct = 0; ct < DT; ++ct) o[ct] = ah_mfma(v2[ct], p1[s2], o[ct]);
-#pragma unroll
-            for (int ct = 0; ct < DT; ++ct) o[ct] = ah_mfma(v1[ct], p1[s2], o[ct]);
         }
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = (1.0f / AH_OP_SCALE) / l_tot;        // l carries the 2^12 of the probabilities, O the 2^12 * 2^4 of P and V
+    const float inv = (1.0f / OPS) / l_tot;      // NP = 2: l carries the 2^12 of the probabilities, O the 2^12 * 2^4 of P and V
     if (active) {
         float* ob = out + ((long)b * C + hd * D) * S + q0 + l31;
 #pragma unroll
@@ -231,26 +230,38 @@ bool attention_h2_supported(int C, int heads, int HW) {
     return D % 32 == 0 && D >= 32 && D <= 128 && HW % 32 == 0;
 }
 
-int launch_attention_h2(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s) {
-    MCVD_REQUIRE(attention_h2_supported(C, heads, HW), "attention f16x2: unsupported (C=%d heads=%d HW=%d)", C, heads, HW);
+template <int NP>
+static int attn_h2_launch(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s) {
     const int D = C / heads;
     const float scale = (float)pow((double)D, -0.5);   // int(C)**-0.5 as a Python double, then fp32 (layerspp.py:239)
-    const float scale_s = scale * (1.0f / (AH_OP_SCALE * AH_OP_SCALE));      // exact: the S product carries 2^8
+    const float ops = NP == 2 ? Pieces<2>::ACT_SCALE : 1.0f;
+    const float scale_s = scale * (1.0f / (ops * ops));      // exact: the S product carries the square of the operand scale
     dim3 grid((HW + 127) / 128, B * heads);
-    const size_t lds = (size_t)(D / 16 * 512 + D / 32 * 1024) * sizeof(unsigned);
+    const size_t lds = (size_t)(D / 16 + 2 * (D / 32)) * NP * 256 * sizeof(unsigned);
     switch (D / 32) {
-        case 1: hipLaunchKernelGGL(attn_h2_kernel<1>, grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
-        case 2: hipLaunchKernelGGL(attn_h2_kernel<2>, grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
-        case 3: hipLaunchKernelGGL(attn_h2_kernel<3>, grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
-        default: hipLaunchKernelGGL(attn_h2_kernel<4>, grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
+        case 1: hipLaunchKernelGGL((attn_h2_kernel<NP, 1>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
+        case 2: hipLaunchKernelGGL((attn_h2_kernel<NP, 2>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
+        case 3: hipLaunchKernelGGL((attn_h2_kernel<NP, 3>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
+        default: hipLaunchKernelGGL((attn_h2_kernel<NP, 4>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
     }
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-int launch_attention(int mode, int f16x2, const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s) {
+int launch_attention_h2(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s, int np) {
+    MCVD_REQUIRE(attention_h2_supported(C, heads, HW) && (np == 2 || np == 3), "split-operand attention: unsupported (C=%d heads=%d HW=%d np=%d)", C,
+                 heads, HW, np);
+    return np == 2 ? attn_h2_launch<2>(qkv, out, B, C, heads, HW, s) : attn_h2_launch<3>(qkv, out, B, C, heads, HW, s);
+}
+
+// mode = the "naive_attn" option: 0 auto (the split-operand kernel where it applies: two fp16 pieces when f16x2 is on, else three bf16
+// pieces when bf16x3 is on; else the fp32 flash kernel), 1 the one-thread-per-query kernel, 2 the fp32 flash kernel, 3 two fp16 pieces
+// where the kernel applies, 4 three bf16 pieces where it applies
+int launch_attention(int mode, int f16x2, int bf16x3, const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s) {
     if (mode == 1) return launch_attention_naive(qkv, out, B, C, heads, HW, s);
-    if ((mode == 3 || (mode == 0 && f16x2)) && attention_h2_supported(C, heads, HW)) return launch_attention_h2(qkv, out, B, C, heads, HW, s);
+    const bool sup = attention_h2_supported(C, heads, HW);
+    if (sup && (mode == 3 || (mode == 0 && f16x2))) return launch_attention_h2(qkv, out, B, C, heads, HW, s, 2);
+    if (sup && (mode == 4 || (mode == 0 && bf16x3))) return launch_attention_h2(qkv, out, B, C, heads, HW, s, 3);
     return launch_attention_mfma(qkv, out, B, C, heads, HW, s);
 }
 

@@ -22,8 +22,9 @@ static int env_int(const char* name, int dflt) {
 
 // which kernel family the last launch_conv_mfma of this thread dispatched to (tests assert a forced shape did not fall back
 // silently): 0..3 direct implicit GEMM tile shapes, 4 Winograd, 8 Winograd + K split, 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels),
-// 9 the 1x1 GEMM with 64 pixels per wave, 10 / 11 Winograd on the bf16 pipe with split operands (11: + K split), 12 / 13 Winograd on
-// the fp16 pipe with two-piece operands (13: + K split), 14 the 1x1 GEMM on the fp16 pipe with two-piece operands
+// 9 the 1x1 GEMM with 64 pixels per wave, 10 / 11 Winograd on the bf16 pipe with three-piece operands (11: + K split), 12 / 13 Winograd on
+// the fp16 pipe with two-piece operands (13: + K split), 14 the 1x1 GEMM on the fp16 pipe with two-piece operands, 15 the 1x1 GEMM on
+// the bf16 pipe with three-piece operands
 static thread_local int g_last_conv_kernel = -1;
 int last_conv_kernel() { return g_last_conv_kernel; }
 
@@ -70,7 +71,8 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
         if (conv_wino_usable(b)) { g_last_conv_kernel = 8; return launch_conv_wino(b, s); }
     }
     if ((a.shape_hint == 4 || a.shape_hint == 8 || (a.shape_hint >= 10 && a.shape_hint <= 13)) && conv_wino_usable(a)) { g_last_conv_kernel = 4; return launch_conv_wino(a, s); }   // Winograd F(2x2,3x3)
-    if (a.shape_hint == 14 && conv1x1_h2_supported(a, a.cot)) { g_last_conv_kernel = 14; return launch_conv1x1_h2(a, a.cot, s); }   // 1x1 GEMM, fp16 pipe, two-piece operands
+    if (a.shape_hint == 15 && conv1x1_h2_supported(a, a.cot, 3)) { g_last_conv_kernel = 15; return launch_conv1x1_h2(a, a.cot, s, 3); }   // 1x1 GEMM, bf16 pipe, three exact pieces
+    if (a.shape_hint == 14 && conv1x1_h2_supported(a, a.cot, 2)) { g_last_conv_kernel = 14; return launch_conv1x1_h2(a, a.cot, s, 2); }   // 1x1 GEMM, fp16 pipe, two-piece operands
     if (a.shape_hint == 5 && conv1x1_dma_supported(a, 16)) { g_last_conv_kernel = 5; return launch_conv1x1_dma(a, a.cot, 16, s); }   // all-DMA 1x1 GEMM
     if (a.shape_hint == 6 && conv1x1_dma_supported(a, 32) && a.cot != 9) { g_last_conv_kernel = 6; return launch_conv1x1_dma(a, a.cot, 32, s); }
     if (a.shape_hint == 9 && conv1x1_dma_supported(a, 16, 2)) { g_last_conv_kernel = 9; return launch_conv1x1_dma(a, a.cot, 16, s, 2); }   // 64 pixels per wave

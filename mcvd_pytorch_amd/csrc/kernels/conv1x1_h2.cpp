@@ -1,31 +1,32 @@
-// 1x1 convolution / NIN as a GEMM on the FP16 matrix pipe with both operands split into TWO fp16 pieces (conv_wino2h.cpp has the
-// arithmetic: v ~= v1 + v2, 22 significant bits per operand, three piece products u1 v2 + u2 v1 + u1 v1 accumulated in fp32):
+// 1x1 convolution / NIN as a GEMM on the 16-bit matrix pipes with split operands (pieces.h has the arithmetic):
 //   y[b][co][p] = out_scale * ( sum_ci W[ci][co] * pro(x[b][ci][p]) + bias[co] (+ res[b][co][p]) )
+// NP = 3: three bf16 pieces per operand, six piece products -- fp32-equivalent, full fp32 range; the default (shape id 15).
+// NP = 2: two fp16 pieces per operand, three piece products (22-bit operands; context option "f16x2"; shape id 14).
 // The fp32-MFMA form of this GEMM (conv1x1_dma.cpp) is bound by the matrix pipe (66 % busy with no memory traffic at all,
-// profiles/r02_conv1x1_ablation.txt); three v_mfma_f32_32x32x16_f16 per 16 channels take 3/16 of that pipe time, which leaves the
-// kernel with what a 1x1 conv should be bound by: reading the activations once.
-//   * weights: split once, when the weights are packed (launch_pack_conv1x1_h2: per layer scaled by a power of two, max |w| at
-//     2^13..2^14; the inverse folded into the epilogue), stored operand-major
+// profiles/r02_conv1x1_ablation.txt); NP * (NP + 1) / 2 MFMAs of the 16x faster pipe per 16 channels take 3/16 (6/16) of that pipe
+// time, which leaves the kernel with what a 1x1 conv should be bound by: reading the activations once.
+//   * weights: split once, when the weights are packed (launch_pack_conv1x1_h2; NP = 2: per layer scaled by a power of two, max |w|
+//     at 2^13..2^14, the inverse folded into the epilogue; NP = 3: unscaled), stored operand-major
 //         [16-channel chunk][32-cout sub-tile][piece][64 lanes][4 dwords],  dword j of lane (h, m) = K slots (2j, 2j+1) = channels
 //         (4j + h, 4j + 2 + h) of the chunk for cout m of the sub-tile (the K-slot convention of conv_wino2h.cpp),
 //     so the COT sub-tiles of a workgroup are one contiguous block per chunk: it reaches the LDS by LDS-DMA (16 B per lane) and
 //     every wave reads its A operands from there with one conflict-free ds_read_b128 per (sub-tile, piece).
 //   * pixels x[b][ci][HW]: rows are contiguous pixels (NCHW) -> LDS-DMA, as in conv1x1_dma.cpp.  A wave owns 32 pixels; lane
 //     (pixel n, half h) reads its 8 channels of a 16-channel step (ds_read_b32, conflict-free), applies the GroupNorm affine
-//     (+ SiLU) from the LDS coefficient table, scales by 2^4, clamps to the fp16 range and splits (4 VALU per channel pair).
+//     (+ SiLU) from the LDS coefficient table and splits (NP = 2: times 2^4 first; no clamp -- an input beyond the fp16 range
+//     becomes Inf and the output NaN, which the library reports: model.cpp range guard).
 //   * K loop over 16-channel chunks, ONE barrier per chunk, FOUR LDS buffers: the DMA runs three chunks ahead of the MFMAs (a
-//     chunk holds 3 * COT MFMAs = 200-400 cycles of matrix work, far less than a memory latency; with two buffers the kernel
+//     chunk holds 3-6 * COT MFMAs = 200-800 cycles of matrix work, less than a memory latency; with two buffers the kernel
 //     waited for every chunk).  The DMA groups are the only VMEM operations in flight: their waits are counted by hand.
 // Workgroup = 4 waves = 128 consecutive pixels of the flattened [B*HW] axis x 32*COT couts; block id -> (pixel tile, cout tile)
 // keeps the cout tiles of one pixel tile on one XCD (conv1x1_dma.cpp).  MFMAs and LDS traffic are compiler-scheduled builtins.
 #include "../common.h"
+#include "pieces.h"
 
 namespace mcvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_q(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -34,37 +35,17 @@ constexpr int Q1_PT = 128;       // pixels per workgroup
 constexpr int Q1_CK = 16;        // input channels per chunk (one barrier, one MFMA K step)
 constexpr int Q1_NB = 4;         // LDS buffers: the DMA runs three chunks ahead of the MFMAs
 constexpr int Q1_MAXIMG = 4;     // images a pixel tile may span (HW >= 32)
-constexpr int Q1_HDR = 4;        // header floats in front of the weight pieces: |w|max, scale, 1 / scale, -
-constexpr float Q1_ACT_SCALE = 16.0f;
-constexpr float Q1_F16_MAX = 65504.0f;
-
-__device__ __forceinline__ unsigned q1_cvt_pk(float lo, float hi) {
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-}
-// two-way fp16 split of a channel pair (conv_wino2h.cpp: h2_split2)
-__device__ __forceinline__ void q1_split2(float x, float y, unsigned& w1, unsigned& w2) {
-    x = __builtin_amdgcn_fmed3f(x, -Q1_F16_MAX, Q1_F16_MAX);
-    y = __builtin_amdgcn_fmed3f(y, -Q1_F16_MAX, Q1_F16_MAX);
-    w1 = q1_cvt_pk(x, y);
-    float rx, ry;
-    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(w1), "v"(x));
-    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ry) : "v"(w1), "v"(y));
-    w2 = q1_cvt_pk(rx, ry);
-}
-__device__ __forceinline__ f32x16 q1_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
 
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU
-template <int COT, int PRO>
+template <int NP, int COT, int PRO>
 __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptiles, int nct) {
+    typedef Pieces<NP> PX;
     constexpr int PT = Q1_PT, CK = Q1_CK, NB = Q1_NB, BCO = 32 * COT;
     constexpr int PPR = PT / 4;               // 16-byte pieces per channel row of the pixel tile
     constexpr int RPS = 256 / PPR;            // channel rows one 256-thread DMA step covers (8)
     constexpr int XSZ = CK * PT;              // floats of one pixel chunk
-    constexpr int WDW = COT * 2 * 256;        // dwords of one weight chunk: [COT][2 pieces][64 lanes][4]
-    constexpr int WPC = WDW / 4;              // its 16-byte pieces (COT * 128)
+    constexpr int WDW = COT * NP * 256;       // dwords of one weight chunk: [COT][NP pieces][64 lanes][4]
+    constexpr int WPC = WDW / 4;              // its 16-byte pieces (COT * NP * 64)
     constexpr int MAXX = XSZ / 4 / 256;       // x DMA rounds per chunk (2)
     constexpr int MAXW = (WPC + 255) / 256;   // weight DMA rounds per chunk; a partial round re-fetches pieces from the start (same data, same place)
     constexpr int G = MAXX + MAXW;            // DMA instructions per wave and chunk: the unit of the vmcnt bookkeeping below
@@ -93,8 +74,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     const int voff1 = (xb * a.C1 + x_ci) * HW + xp;               // offset inside x1
 
     // ---- weight DMA role: round s moves pieces (s*256 + wave*64 .. + 63) % WPC of the chunk's image [COT][piece][lane]; global dword
-    //      of piece q of chunk ch: (ch * NS + ctile*COT) * 512 + q*4
-    const unsigned* wbase = reinterpret_cast<const unsigned*>(a.wph) + Q1_HDR + (long)ctile * COT * 512;
+    //      of piece q of chunk ch: (ch * NS + ctile*COT) * NP*256 + q*4
+    const unsigned* wbase = reinterpret_cast<const unsigned*>(NP == 2 ? a.wph : a.wpb) + PX::HDR + (long)ctile * COT * (NP * 256);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int w_goff[MAXW], w_lds[MAXW];
 #pragma unroll
@@ -119,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
 #define Q1_DMA(ch)                                                                                              \
     {                                                                                                           \
         const int cb = (ch) * CK;                                                                               \
-        const unsigned* wsrc = wbase + (long)(ch) * NS * 512;                                                   \
+        const unsigned* wsrc = wbase + (long)(ch) * NS * (NP * 256);                                                  \
         unsigned* wdst = sW + ((ch) & (NB - 1)) * WDW;                                                          \
         _Pragma("unroll") for (int s = 0; s < MAXW; ++s)                                                        \
             __builtin_amdgcn_global_load_lds(                                                                   \
@@ -165,20 +146,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
         const u32x4* sWc = reinterpret_cast<const u32x4*>(sW + (ch & (NB - 1)) * WDW) + lane;
         const float* sXc = sX + (ch & (NB - 1)) * XSZ + wave * 32 + l31;
         const float* sCb = sC + ((long)my_img * Cin + ch * CK) * 2;
-        // every LDS read of the chunk first (one round trip): 8 pixel values, their coefficients, the 2 * COT A operands
+        // every LDS read of the chunk first (one round trip): 8 pixel values, their coefficients, the NP * COT A operands
         float bv[8];
         f32x2 cf[8];
-        u32x4 a1[COT], a2[COT];
+        u32x4 aw[COT][NP];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {         // element e of lane (n, h) = channel 2e + h of the chunk
             bv[e] = sXc[(2 * e + half) * PT];
             if (PRO != 0) cf[e] = *reinterpret_cast<const f32x2*>(sCb + (2 * e + half) * 2);
         }
 #pragma unroll
-        for (int ct = 0; ct < COT; ++ct) {
-            a1[ct] = sWc[(ct * 2 + 0) * 64];
-            a2[ct] = sWc[(ct * 2 + 1) * 64];
-        }
+        for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) aw[ct][p] = sWc[(ct * NP + p) * 64];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -186,22 +166,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
                 bv[e] = bv[e] * cf[e].x + cf[e].y;
                 if (PRO == 2) bv[e] = silu_q(bv[e]);
             }
-            bv[e] *= Q1_ACT_SCALE;
+            if (NP == 2) bv[e] *= PX::ACT_SCALE;
         }
-        u32x4 b1, b2;
+        u32x4 bp[NP];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            unsigned w1, w2;
-            q1_split2(bv[2 * j], bv[2 * j + 1], w1, w2);
-            b1[j] = w1; b2[j] = w2;
+            unsigned w[NP];
+            PX::template split<false>(bv[2 * j], bv[2 * j + 1], w);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) bp[p][j] = w[p];
         }
-        // piece-major MFMA order: consecutive MFMAs write different accumulators
+        // product-major MFMA order, smallest product first: consecutive MFMAs write different accumulators
 #pragma unroll
-        for (int ct = 0; ct < COT; ++ct) acc[ct] = q1_mfma(a1[ct], b2, acc[ct]);      // u1 v2
+        for (int k = 0; k < PX::NPROD; ++k)
 #pragma unroll
-        for (int ct = 0; ct < COT; ++ct) acc[ct] = q1_mfma(a2[ct], b1, acc[ct]);      // u2 v1
-#pragma unroll
-        for (int ct = 0; ct < COT; ++ct) acc[ct] = q1_mfma(a1[ct], b1, acc[ct]);      // u1 v1
+            for (int ct = 0; ct < COT; ++ct) acc[ct] = PX::mfma(aw[ct][PX::PA(k)], bp[PX::PB(k)], acc[ct]);
     }
 #undef Q1_DMA
     if (rec) tk2 = __builtin_amdgcn_s_memtime();
@@ -210,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     // there is 64 scattered dwords per instruction, 16 * COT instructions per wave, and the kernel spent 40 % of its time issuing them
     // (profiles/r02_conv1x1_h2_timeline.txt).  The tile goes through the LDS instead ([cout][128 pixels], the K loop's buffers are
     // free) and leaves as global_store_dwordx4: four consecutive pixels per lane, 1 KiB contiguous per wave instruction.
-    const float inv = a.wph[2] * (1.0f / Q1_ACT_SCALE);      // 1 / (weight scale * activation scale), a power of two
+    const float inv = NP == 2 ? a.wph[2] * (1.0f / PX::ACT_SCALE) : 1.0f;      // NP = 2: 1 / (weight scale * activation scale), a power of two
     float* sO = smem;                                         // [BCO][PT]
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading the chunk buffers
 #pragma unroll
@@ -291,58 +270,63 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     }
 }
 
-static size_t q1_lds_bytes(int cot, int Cin, int HW) {
+static size_t q1_lds_bytes(int np, int cot, int Cin, int HW) {
     const int nimg = HW >= Q1_PT ? 1 : Q1_PT / HW;
-    return (size_t)(Q1_NB * (cot * 2 * 256) + Q1_NB * Q1_CK * Q1_PT + nimg * Cin * 2) * sizeof(float);
+    return (size_t)(Q1_NB * (cot * np * 256) + Q1_NB * Q1_CK * Q1_PT + nimg * Cin * 2) * sizeof(float);
 }
 
-// Shape id 14 applies to this launch (cot = cout tile in 32-channel units, 1..4).
-bool conv1x1_h2_supported(const ConvArgs& a, int cot) {
+// Shape ids 15 (np = 3) / 14 (np = 2) apply to this launch (cot = cout tile in 32-channel units, 1..4).
+bool conv1x1_h2_supported(const ConvArgs& a, int cot, int np) {
     const int HW = a.H * a.W;
-    if (a.ks != 1 || !a.wph || HW % 32 != 0 || cot < 1 || cot > 4 || (a.CoutP / 32) % cot != 0) return false;
+    if (np != 2 && np != 3) return false;
+    if (a.ks != 1 || !(np == 2 ? a.wph : a.wpb) || HW % 32 != 0 || cot < 1 || cot > 4 || (a.CoutP / 32) % cot != 0) return false;
     if (!(HW % Q1_PT == 0 || (HW < Q1_PT && Q1_PT % HW == 0 && Q1_PT / HW <= Q1_MAXIMG))) return false;
     if (a.Cin % Q1_CK != 0 || a.CinP % Q1_CK != 0) return false;            // no partial chunk: every staged row is real data
     if (a.C1 > 0 && a.C0 % Q1_CK != 0) return false;                        // a chunk never straddles the concat seam
     if ((long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * HW >= (1L << 31)) return false;   // 32-bit lane offsets
     if (a.act && !a.coef) return false;
-    return q1_lds_bytes(cot, a.Cin, HW) <= 80 * 1024;                       // two workgroups per CU
+    return q1_lds_bytes(np, cot, a.Cin, HW) <= 80 * 1024;                   // two workgroups per CU
 }
 
-template <int COT>
+template <int NP, int COT>
 static int q1_launch(const ConvArgs& a, hipStream_t s) {
     const int HW = a.H * a.W;
     const long NPX = (long)a.B * HW;
     const int ptiles = (int)((NPX + Q1_PT - 1) / Q1_PT);
     const int nct = a.CoutP / (32 * COT);
-    const size_t lds = q1_lds_bytes(COT, a.Cin, HW);
+    const size_t lds = q1_lds_bytes(NP, COT, a.Cin, HW);
     const dim3 grid(((ptiles + 7) / 8) * 8 * nct);
     static PerDeviceOnce raised;
     if (lds > 48 * 1024 && raised.first_use()) {
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<COT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<COT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<COT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised.done();
     }
     if (!a.coef)
-        hipLaunchKernelGGL((conv1x1_h2_kernel<COT, 0>), grid, dim3(256), lds, s, a, ptiles, nct);
+        hipLaunchKernelGGL((conv1x1_h2_kernel<NP, COT, 0>), grid, dim3(256), lds, s, a, ptiles, nct);
     else if (!a.act)
-        hipLaunchKernelGGL((conv1x1_h2_kernel<COT, 1>), grid, dim3(256), lds, s, a, ptiles, nct);
+        hipLaunchKernelGGL((conv1x1_h2_kernel<NP, COT, 1>), grid, dim3(256), lds, s, a, ptiles, nct);
     else
-        hipLaunchKernelGGL((conv1x1_h2_kernel<COT, 2>), grid, dim3(256), lds, s, a, ptiles, nct);
+        hipLaunchKernelGGL((conv1x1_h2_kernel<NP, COT, 2>), grid, dim3(256), lds, s, a, ptiles, nct);
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-int launch_conv1x1_h2(const ConvArgs& a, int cot, hipStream_t s) {
-    MCVD_REQUIRE(conv1x1_h2_supported(a, cot), "conv1x1 f16x2: unsupported (ks=%d H=%d W=%d Cin=%d C0=%d cot=%d, weight pieces %s)", a.ks, a.H,
-                 a.W, a.Cin, a.C0, cot, a.wph ? "present" : "missing");
-    int rc;
+template <int NP>
+static int q1_launch_cot(const ConvArgs& a, int cot, hipStream_t s) {
     switch (cot) {
-        case 1: rc = q1_launch<1>(a, s); break;
-        case 2: rc = q1_launch<2>(a, s); break;
-        case 3: rc = q1_launch<3>(a, s); break;
-        default: rc = q1_launch<4>(a, s); break;
+        case 1: return q1_launch<NP, 1>(a, s);
+        case 2: return q1_launch<NP, 2>(a, s);
+        case 3: return q1_launch<NP, 3>(a, s);
+        default: return q1_launch<NP, 4>(a, s);
     }
+}
+
+int launch_conv1x1_h2(const ConvArgs& a, int cot, hipStream_t s, int np) {
+    MCVD_REQUIRE(conv1x1_h2_supported(a, cot, np), "conv1x1 split-operand GEMM: unsupported (np=%d ks=%d H=%d W=%d Cin=%d C0=%d cot=%d, weight pieces %s)",
+                 np, a.ks, a.H, a.W, a.Cin, a.C0, cot, (np == 2 ? a.wph : a.wpb) ? "present" : "missing");
+    const int rc = np == 2 ? q1_launch_cot<2>(a, cot, s) : q1_launch_cot<3>(a, cot, s);
     const int HW = a.H * a.W;
     if (rc == 0 && a.stats && (HW >= Q1_PT || HW == 64)) set_last_conv_stats_np(HW >= Q1_PT ? HW / Q1_PT : 1);
     return rc;
@@ -350,9 +334,11 @@ int launch_conv1x1_h2(const ConvArgs& a, int cot, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Weight pieces from the packed fp32 matrix wp[ci * CoutP + co] (launch_pack_conv_weight: every fused weight and the zero padding
-// are already in place).  wh = [Q1_HDR header floats][CinP * CoutP dwords]; header: max |w|, scale = 2^e (max |w| * 2^e in
-// [2^13, 2^14)), 1 / scale.  Halfword index of (ci, co, piece):
-//   (((ci/16) * NS + co/32) * 2 + piece) * 512 + (lane*4 + j) * 2 + (el & 1),   cc = ci % 16 = 2 el + h, j = el >> 1, lane = h*32 + co%32
+// are already in place).  Halfword index of (ci, co, piece):
+//   (((ci/16) * NS + co/32) * NP + piece) * 512 + (lane*4 + j) * 2 + (el & 1),   cc = ci % 16 = 2 el + h, j = el >> 1, lane = h*32 + co%32
+// np = 2: wh = [4 header floats][CinP * CoutP dwords]; header: max |w|, scale = 2^e (max |w| * 2^e in [2^13, 2^14)), 1 / scale;
+//         pieces h1 = fp16(w * scale), h2 = fp16(w * scale - h1).
+// np = 3: wh = [CinP * CoutP * 3 halfwords], no header, no scale; pieces b1 = bf16(w), b2 = bf16(w - b1), b3 = w - b1 - b2 (exact).
 __global__ void q1_absmax_kernel(const float* w, long n, unsigned* hdr) {
     float m = 0.0f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
@@ -368,7 +354,7 @@ __global__ void pack_conv1x1_h2_kernel(const float* wp, float* wh, int CinP, int
     const int e = (wmax > 0.0f && wmax < 3.0e38f) ? min(max(14 - k, -60), 60) : 0;
     const float scale = ldexpf(1.0f, e);
     if (blockIdx.x == 0 && threadIdx.x == 0) { wh[1] = scale; wh[2] = ldexpf(1.0f, -e); }
-    _Float16* dst = reinterpret_cast<_Float16*>(wh + Q1_HDR);
+    _Float16* dst = reinterpret_cast<_Float16*>(wh + Pieces<2>::HDR);
     const long n = (long)CinP * CoutP;
     const int NS = CoutP / 32;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -383,15 +369,40 @@ __global__ void pack_conv1x1_h2_kernel(const float* wp, float* wh, int CinP, int
     }
 }
 
-long conv1x1_h2_weight_floats(int CinP, int CoutP) { return Q1_HDR + (long)CinP * CoutP; }
+__global__ void pack_conv1x1_b3_kernel(const float* wp, unsigned short* dst, int CinP, int CoutP) {
+    const long n = (long)CinP * CoutP;
+    const int NS = CoutP / 32;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % CoutP), ci = (int)(i / CoutP);
+        const float u = wp[i];
+        const unsigned short h1 = px_bf16_rne(u);
+        const float r1 = u - px_bf16_f32(h1);                   // exact
+        const unsigned short h2 = px_bf16_rne(r1);
+        const float r2 = r1 - px_bf16_f32(h2);                  // exact, at most 8 significant bits
+        const unsigned short h3 = px_bf16_rne(r2);
+        const int cc = ci & 15, h = cc & 1, el = cc >> 1, lane = h * 32 + (co & 31);
+        const long o = (((long)(ci >> 4) * NS + (co >> 5)) * 3) * 512 + (lane * 4 + (el >> 1)) * 2 + (el & 1);
+        dst[o] = h1;
+        dst[o + 512] = h2;
+        dst[o + 1024] = h3;
+    }
+}
 
-// `wh` must start with a zero header word (the running maximum); every piece is written.
-int launch_pack_conv1x1_h2(const float* wp, float* wh, int CinP, int CoutP, hipStream_t s) {
-    MCVD_REQUIRE(CinP % 16 == 0 && CoutP % 32 == 0, "pack_conv1x1_h2: CinP=%d CoutP=%d", CinP, CoutP);
+long conv1x1_h2_weight_floats(int CinP, int CoutP, int np) {
+    return np == 2 ? Pieces<2>::HDR + (long)CinP * CoutP : (long)CinP * CoutP / 2 * 3;
+}
+
+// np = 2: `wh` must start with a zero header word (the running maximum).  Every piece is written.
+int launch_pack_conv1x1_h2(const float* wp, float* wh, int CinP, int CoutP, hipStream_t s, int np) {
+    MCVD_REQUIRE(CinP % 16 == 0 && CoutP % 32 == 0 && (np == 2 || np == 3), "pack_conv1x1_h2: CinP=%d CoutP=%d np=%d", CinP, CoutP, np);
     const long n = (long)CinP * CoutP;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    hipLaunchKernelGGL(q1_absmax_kernel, dim3(blocks), dim3(256), 0, s, wp, n, reinterpret_cast<unsigned*>(wh));
-    hipLaunchKernelGGL(pack_conv1x1_h2_kernel, dim3(blocks), dim3(256), 0, s, wp, wh, CinP, CoutP);
+    if (np == 2) {
+        hipLaunchKernelGGL(q1_absmax_kernel, dim3(blocks), dim3(256), 0, s, wp, n, reinterpret_cast<unsigned*>(wh));
+        hipLaunchKernelGGL(pack_conv1x1_h2_kernel, dim3(blocks), dim3(256), 0, s, wp, wh, CinP, CoutP);
+    } else {
+        hipLaunchKernelGGL(pack_conv1x1_b3_kernel, dim3(blocks), dim3(256), 0, s, wp, reinterpret_cast<unsigned short*>(wh), CinP, CoutP);
+    }
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -172,9 +172,12 @@ struct Builder {
         if (wnames.size() == 1 && !nin && conv_wino_supported(ks, op.H, op.W))
             p.wpw = alloc_packed((int64_t)p.CinP * 16 * p.CoutP);
         if (p.wpw >= 0) p.wph = alloc_packed(conv_wino2h_weight_floats(p.CinP, p.CoutP));      // two fp16 pieces (conv_wino2h.cpp)
-        if (ks == 1) p.wph = alloc_packed(conv1x1_h2_weight_floats(p.CinP, p.CoutP));      // two fp16 pieces of the packed matrix (conv1x1_h2.cpp)
+        if (p.wpw >= 0) p.wpb = alloc_packed(conv_wino3_weight_floats(p.CinP, p.CoutP));       // three bf16 pieces (conv_wino3.cpp)
+        if (ks == 1) p.wph = alloc_packed(conv1x1_h2_weight_floats(p.CinP, p.CoutP, 2));   // two fp16 pieces of the packed matrix (conv1x1_h2.cpp)
+        if (ks == 1) p.wpb = alloc_packed(conv1x1_h2_weight_floats(p.CinP, p.CoutP, 3));   // three bf16 pieces of it
         op.wpw = p.wpw;
         op.wph = p.wph;
+        op.wpb = p.wpb;
         m.packs.push_back(p);
         op.ks = ks;
         op.Cout = Cout;
@@ -652,6 +655,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.wp = packed + op.wp;
             a.wpw = op.wpw >= 0 ? packed + op.wpw : nullptr;
             a.wph = op.wph >= 0 ? packed + op.wph : nullptr;
+            a.wpb = op.wpb >= 0 ? packed + op.wpb : nullptr;
             a.bias = packed + op.bias;
             a.res = op.res.kind == REF_NONE ? nullptr : resolve(op.res, x, cond, out, B);
             a.out_scale = op.out_scale;
@@ -665,15 +669,28 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.W = op.W;
             a.ks = op.ks;
             a.cot = op.cot;
-            a.shape_hint = ctx->conv_shape;
+            a.shape_hint = (op.ks == 1 && ctx->conv_shape1 >= 0) ? ctx->conv_shape1 : ctx->conv_shape;
             a.wdma = ctx->conv_wdma;
             a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
             const size_t oi = (size_t)(&op - ops.data());
-            if (ctx->conv_shape < 0 && tuned_B == B && oi < tuned_shape.size() && tuned_shape[oi] >= 0) {
+            if (a.shape_hint == 14 || a.shape_hint == 15) {      // forced split-operand 1x1 GEMM (tests): a cout tile that kernel serves
+                const int np = a.shape_hint == 14 ? 2 : 3;
+                for (int c = 4; c >= 1 && !conv1x1_h2_supported(a, a.cot, np); --c)
+                    if (conv1x1_h2_supported(a, c, np)) a.cot = c;
+            }
+            if (a.shape_hint < 0 && tuned_B == B && oi < tuned_shape.size() && tuned_shape[oi] >= 0) {
                 a.shape_hint = tuned_shape[oi];
                 a.cot = tuned_cot[oi];
-                if (!ctx->f16x2 && a.shape_hint >= 12 && a.shape_hint <= 14) {        // an imported table from an f16x2 run: the option wins
-                    a.shape_hint = a.shape_hint == 12 ? 4 : a.shape_hint == 13 ? 8 : 5;
+                // an imported table from a run under other options: the options win.  f16x2 hints (12 / 13 / 14) go to their bf16x3
+                // counterparts (10 / 11 / 15) when f16x2 is off -- and for convs with a raw input in any case (f16x2 range guard, below);
+                // bf16x3 hints go to the fp32-MFMA kernels (4 / 8 / 5) when bf16x3 is off
+                const bool raw_in = op.coef.kind == REF_NONE;
+                if ((!ctx->f16x2 || raw_in) && a.shape_hint >= 12 && a.shape_hint <= 14) {
+                    a.shape_hint = a.shape_hint == 12 ? 10 : a.shape_hint == 13 ? 11 : 15;
+                    if (a.shape_hint == 15 && !conv1x1_h2_supported(a, a.cot, 3)) a.cot = op.cot;
+                }
+                if (!ctx->bf16x3 && (a.shape_hint == 10 || a.shape_hint == 11 || a.shape_hint == 15)) {
+                    a.shape_hint = a.shape_hint == 10 ? 4 : a.shape_hint == 11 ? 8 : 5;
                     a.cot = op.cot;
                 }
             }
@@ -697,15 +714,18 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                     a.x0 = tmp; a.x1 = nullptr; a.C0 = a.Cin; a.C1 = 0; a.coef = nullptr; a.act = 0; a.gb = nullptr; a.coef2 = nullptr;
                 }
             }
-            // (the fp16-pipe 1x1 GEMM emits them cheaply from its transposed epilogue: shape id 14)
-            a.stats = (ctx->gn_stats && op.stats.kind != REF_NONE && !ctx->naive_conv && (op.ks == 3 || ctx->gn_stats >= 2 || a.shape_hint == 14))
+            // (the split-operand 1x1 GEMM emits them cheaply from its transposed epilogue: shape ids 14 / 15)
+            a.stats = (ctx->gn_stats && op.stats.kind != REF_NONE && !ctx->naive_conv && (op.ks == 3 || ctx->gn_stats >= 2 || a.shape_hint == 14 || a.shape_hint == 15))
                           ? resolve(op.stats, x, cond, out, B) : nullptr;
+            if (ran_kernel.size() != ops.size()) ran_kernel.assign(ops.size(), -1);
             if (ctx->naive_conv) {
                 stats_np[oi] = 0;
+                ran_kernel[oi] = -2;
                 return launch_conv_naive(a, s);
             }
             const int rc = launch_conv_mfma(a, s);
             stats_np[oi] = a.stats ? last_conv_stats_np() : 0;
+            ran_kernel[oi] = last_conv_kernel();
             return rc;
         }
         case OP_FIR: {
@@ -760,8 +780,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                                       op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B),
                                       resolve(op.dst, x, cond, out, B), B, op.H * op.W, s);
         case OP_ATTN:
-            return launch_attention(ctx->naive_attn, ctx->f16x2, resolve(op.src0, x, cond, out, B), resolve(op.dst, x, cond, out, B), B, op.Cout,
-                                    op.heads, op.H * op.W, s);
+            return launch_attention(ctx->naive_attn, ctx->f16x2, ctx->bf16x3, resolve(op.src0, x, cond, out, B), resolve(op.dst, x, cond, out, B), B,
+                                    op.Cout, op.heads, op.H * op.W, s);
         default:
             set_error("forward: unknown op kind %d", (int)op.kind);
             return -1;
@@ -801,6 +821,7 @@ int mcvd_model::autotune(int B) {
             a.wp = packed + op.wp;
             a.wpw = op.wpw >= 0 ? packed + op.wpw : nullptr;
             a.wph = op.wph >= 0 ? packed + op.wph : nullptr;
+            a.wpb = op.wpb >= 0 ? packed + op.wpb : nullptr;
             a.bias = packed + op.bias;
             a.res = op.res.kind == REF_NONE ? nullptr : resolve(op.res, scratch_io, scratch_io, scratch_io, B);
             a.out_scale = op.out_scale;
@@ -851,7 +872,7 @@ int mcvd_model::autotune(int B) {
                 if (conv_wino_usable(b))
                     if (int rc = time_candidate(8, op.cot)) return rc;
             }
-            if (op.ks == 3 && ctx->winograd && ctx->bf16x3 && !spade_fused) {     // 10 / 11 = Winograd on the bf16 pipe, operands split three ways
+            if (op.ks == 3 && ctx->winograd && ctx->bf16x3 && !spade_fused) {     // 10 / 11 = Winograd on the bf16 pipe, three exact pieces per operand
                 ConvArgs b = a;
                 b.ksplit = 0;
                 if (conv_wino3_usable(b))
@@ -860,7 +881,10 @@ int mcvd_model::autotune(int B) {
                 if (conv_wino3_usable(b))
                     if (int rc = time_candidate(11, op.cot)) return rc;
             }
-            if (op.ks == 3 && ctx->winograd && ctx->f16x2 && !spade_fused) {      // 12 / 13 = Winograd on the fp16 pipe, two-piece operands
+            // f16x2 range guard: the two-piece fp16 kernels see GroupNorm-ed inputs only (a.coef set: normalised, O(1) by construction).
+            // A conv over a RAW tensor (stem, shortcuts, NIN_3) has no bound on its input and stays on the fp32-range kernels.
+            const bool f16_ok = ctx->f16x2 && a.coef != nullptr;
+            if (op.ks == 3 && ctx->winograd && f16_ok && !spade_fused) {          // 12 / 13 = Winograd on the fp16 pipe, two-piece operands
                 ConvArgs b = a;
                 b.ksplit = 0;
                 if (conv_wino2h_usable(b))
@@ -882,10 +906,15 @@ int mcvd_model::autotune(int B) {
                         if (int rc = time_candidate(ck == 16 ? 5 : 6, c)) return rc;
                     }
                 }
-                if (ctx->f16x2) {                           // 14 = the GEMM on the fp16 pipe with two-piece operands, cout tiles 1..4
+                if (f16_ok) {                               // 14 = the GEMM on the fp16 pipe with two-piece operands, cout tiles 1..4
                     for (int c = 4; c >= 1; --c)
-                        if (conv1x1_h2_supported(a, c))
+                        if (conv1x1_h2_supported(a, c, 2))
                             if (int rc = time_candidate(14, c)) return rc;
+                }
+                if (ctx->bf16x3) {                          // 15 = the GEMM on the bf16 pipe with three exact pieces per operand
+                    for (int c = 4; c >= 1; --c)
+                        if (conv1x1_h2_supported(a, c, 3))
+                            if (int rc = time_candidate(15, c)) return rc;
                 }
                 if (conv1x1_dma_supported(a, 16, 2)) {      // 9 = the same GEMM with 64 pixels per wave (256-pixel tiles), cout tiles 1 / 2
                     if (int rc = time_candidate(9, 1)) return rc;
@@ -905,17 +934,22 @@ int mcvd_model::autotune(int B) {
     return 0;
 }
 
-int mcvd_model::prepare_B(int B) {
-    if (int rc = ensure_workspace(B)) return rc;
-    // the options that decide which kernels the autotuner may offer: a table tuned (or imported) under other settings is dropped --
-    // "f16x2" = 0 must really mean that no two-piece fp16 kernel runs
+// The options that decide which kernels the autotuner may offer: tables tuned (or imported) under other settings are dropped --
+// "f16x2" = 0 must really mean that no two-piece fp16 kernel runs.  Called before a table is looked up and before one is imported
+// (mcvd_model_set_tuning stamps its table with the options in force at the import).
+void mcvd_model::sync_tuning_options() {
     const int sig = (ctx->winograd ? 1 : 0) | (ctx->conv_dma1 ? 2 : 0) | (ctx->bf16x3 ? 4 : 0) | (ctx->f16x2 ? 8 : 0) |
                     (ctx->spade_fuse ? 16 : 0) | (ctx->conv_wdma ? 32 : 0);
     if (sig != tuned_sig) {
         if (tuned_sig >= 0) { tuned_cache.clear(); tuned_B = 0; }
         tuned_sig = sig;
     }
-    if (ctx->autotune && !ctx->naive_conv && tuned_B != B) {
+}
+
+int mcvd_model::prepare_B(int B) {
+    if (int rc = ensure_workspace(B)) return rc;
+    sync_tuning_options();
+    if (!ctx->naive_conv && tuned_B != B) {
         auto it = tuned_cache.find(B);
         if (it != tuned_cache.end() && it->second.first.size() == ops.size()) {     // tuned (or imported) before: no timing launches
             tuned_shape = it->second.first;
@@ -924,6 +958,7 @@ int mcvd_model::prepare_B(int B) {
             ++epoch;
             return 0;
         }
+        if (!ctx->autotune) return 0;             // no table for this batch size and no permission to measure: the dispatcher's heuristics
         if (int rc = autotune(B)) return rc;
         tuned_cache[B] = {tuned_shape, tuned_cot};
         cond_cache_valid = false;                 // the tuner scribbles over the workspace

@@ -17,11 +17,16 @@ struct mcvd_ctx {
     hipStream_t cap = nullptr;     // private capture stream (the caller's stream may be the legacy default stream, which
                                    //    cannot be captured)
     unsigned epoch = 0;            // bumped by every option change: invalidates captured graphs
-    int conv_shape = -1;           // -1 auto, 0/1/2 force a conv tile shape (tests)
+    int conv_shape = -1;           // -1 auto, else force a conv tile shape / kernel family (tests)
+    int conv_shape1 = -1;          // >= 0: the shape forced for the 1x1 convs only (they follow conv_shape otherwise): lets a test put
+                                   //    every 3x3 conv AND every 1x1 conv of a model on chosen kernels at once
     int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
     int conv_cot = 0;              // > 0 with conv_shape 5: cout tile (32-channel units) mcvd_op_conv2d requests (tests)
-    int bf16x3 = 1;                // offer the split-operand bf16 Winograd kernel (conv_wino3.cpp, fp32-accurate) to the autotuner
-    int f16x2 = 1;                 // offer the two-piece fp16 Winograd kernel (conv_wino2h.cpp: 22-bit operands, fp32 accumulate) to the autotuner
+    int bf16x3 = 1;                // offer the three-piece bf16 kernels (conv_wino3.cpp, conv1x1_h2.cpp, attention_h2.cpp with NP = 3: fp32-equivalent
+                                   //    arithmetic, full fp32 range) to the autotuner / the attention dispatch.  On by default.
+    int f16x2 = 0;                 // offer the two-piece fp16 kernels (conv_wino2h.cpp, conv1x1_h2.cpp, attention_h2.cpp with NP = 2: 22-bit operands,
+                                   //    fp16 exponent range, fp32 accumulate) as well.  OFF by default: narrower arithmetic than the reference's.
+                                   //    Convs with a raw (not normalised) input never take them; see model.cpp "f16x2 range guard"
     int conv_dma1 = 1;             // offer the all-DMA 1x1 GEMM kernel (conv1x1_dma.cpp) to the autotuner
     int conv_wdma = 1;             // weight chunks by LDS-DMA (1) or register staging (0)
     int side_stream = 0;           // 1: run the ResBlock shortcut 1x1 convs on a second stream (measured -2 %: off by default)
@@ -79,7 +84,8 @@ struct Op {
     // conv
     int64_t wp = -1, bias = -1;    // packed blob offsets
     int64_t wpw = -1;              // Winograd-transformed weights (3x3 convs at supported resolutions), else -1
-    int64_t wph = -1;              // the same, pre-split into two fp16 pieces (conv_wino2h.cpp), else -1
+    int64_t wph = -1;              // the same, pre-split into two fp16 pieces (conv_wino2h.cpp / conv1x1_h2.cpp), else -1
+    int64_t wpb = -1;              // the same, pre-split into three bf16 pieces (conv_wino3.cpp / conv1x1_h2.cpp), else -1
     int CinP = 0, CoutP = 0, cot = 0;
     float out_scale = 1.f;
     // fir
@@ -113,6 +119,7 @@ struct ConvPack {
     int64_t wp, bias;
     int64_t wpw = -1;
     int64_t wph = -1;
+    int64_t wpb = -1;
     bool zero_bias = false;             // the packed bias stays zero (the shortcut GEMM of an up block: its bias is added elsewhere)
     std::string extra_bias;             // a second bias parameter added into this conv's packed bias (that shortcut's)
 };
@@ -164,12 +171,15 @@ struct mcvd_model {
 
     // conv tile choice per op for the batch size it was tuned at: (shape, cot); filled by autotune()
     std::vector<int> stats_np;        // per op: partials per (sample, channel) its last launch wrote (0: none)
+    std::vector<int> ran_kernel;      // per conv op: the kernel family its last launch REALLY ran (last_conv_kernel(); -2 the naive kernel,
+                                      //    -1 never launched): what mcvd_model_op_kernel reports
     std::vector<int> tuned_shape, tuned_cot;
     int tuned_B = 0;
     int tuned_sig = -1;            // the kernel-offer options (winograd, conv_dma1, bf16x3, f16x2, spade_fuse, conv_wdma) the tables were tuned under
     // every batch size tuned (or imported through mcvd_model_set_tuning) so far: alternating batch sizes do not re-tune
     std::map<int, std::pair<std::vector<int>, std::vector<int>>> tuned_cache;
     int autotune(int B);
+    void sync_tuning_options();
 
     // per-op HIP event timing (bench.py roofline): events are recorded on the ctx stream around each op of ONE forward
     std::vector<hipEvent_t> ev;

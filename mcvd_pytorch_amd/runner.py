@@ -10,67 +10,85 @@ import torch
 from .samplers import get_sampler
 
 
+def _frames_to_channels(frames):
+    """[B, T, C, H, W] -> [B, T*C, H, W]: frame-major channel stacking (channel index t*C + c), the layout every tensor of the
+    sampling path uses."""
+    return frames.flatten(1, 2)
+
+
+def _keep_mask(n, p_drop, device):
+    """Per-sample Bernoulli keep mask (True with probability 1 - p_drop), one torch.rand draw per call as the reference's masks."""
+    return torch.rand(n, device=device) > p_drop
+
+
 def conditioning_fn(config, X, num_frames_pred=0, prob_mask_cond=0.0, prob_mask_future=0.0, conditional=True):
-    """Frames -> (pred, cond, cond_mask): frame-major channel stacking `t*C + c`, cond = [past..., future...]
-    (reference: runners/ncsn_runner.py:104-147)."""
-    imsize = config.data.image_size
+    """Clip [B, T, C, H, W] -> (pred, cond, cond_mask) in the channel layout of the network: pred = the `num_frames_pred` frames after
+    the past, cond = [past frames | future frames] with whole samples zeroed by the conditioning masks.  Behaviour of
+    NCSNRunner's conditioning_fn (runners/ncsn_runner.py:104-147), including its draw order (cond mask, then future mask), so a
+    seeded reference script sees the same masks; `conditional=False` returns the flattened clip alone."""
+    d = config.data
     if not conditional:
-        return X.reshape(len(X), -1, imsize, imsize), None, None
-    cond = config.data.num_frames_cond
-    train = config.data.num_frames
-    pred = num_frames_pred
-    future = getattr(config.data, "num_frames_future", 0)
-    pred_frames = X[:, cond:cond + pred].reshape(len(X), -1, imsize, imsize)
-    cond_frames = X[:, :cond].reshape(len(X), -1, imsize, imsize)
+        return _frames_to_channels(X), None, None
+    n_past, n_train, n_future = d.num_frames_cond, d.num_frames, getattr(d, "num_frames_future", 0)
+    B, dev = X.shape[0], X.device
+    pred = _frames_to_channels(X[:, n_past:n_past + num_frames_pred])
+    blocks = [_frames_to_channels(X[:, :n_past])]
+    cond_mask = None
     if prob_mask_cond > 0.0:
-        cond_mask = (torch.rand(X.shape[0], device=X.device) > prob_mask_cond)
-        cond_frames = cond_mask.reshape(-1, 1, 1, 1) * cond_frames
-        cond_mask = cond_mask.to(torch.int32)
-    else:
-        cond_mask = None
-    if future > 0:
-        if prob_mask_future == 1.0:
-            future_frames = torch.zeros(len(X), config.data.channels * future, imsize, imsize, device=X.device)
+        keep = _keep_mask(B, prob_mask_cond, dev)
+        blocks[0] = blocks[0] * keep.view(B, 1, 1, 1)
+        cond_mask = keep.to(torch.int32)
+    if n_future > 0:
+        if prob_mask_future == 1.0:                   # the future block is dropped for everybody: zeros, whatever the clip holds
+            fut = torch.zeros(B, d.channels * n_future, d.image_size, d.image_size, device=dev)
         else:
-            future_frames = X[:, cond + train:cond + train + future].reshape(len(X), -1, imsize, imsize)
+            start = n_past + n_train
+            fut = _frames_to_channels(X[:, start:start + n_future])
             if prob_mask_future > 0.0:
-                if getattr(config.data, "prob_mask_sync", False):
-                    future_mask = cond_mask
+                if getattr(d, "prob_mask_sync", False):
+                    if cond_mask is None:
+                        raise AttributeError("prob_mask_sync needs prob_mask_cond > 0 (the reference reuses the cond mask there)")
+                    keep_f = cond_mask
                 else:
-                    future_mask = (torch.rand(X.shape[0], device=X.device) > prob_mask_future)
-                future_frames = future_mask.reshape(-1, 1, 1, 1) * future_frames
-        cond_frames = torch.cat([cond_frames, future_frames], dim=1)
-    return pred_frames, cond_frames, cond_mask
+                    keep_f = _keep_mask(B, prob_mask_future, dev)
+                fut = fut * keep_f.view(B, 1, 1, 1)
+        blocks.append(fut)
+    return pred, torch.cat(blocks, dim=1) if len(blocks) > 1 else blocks[0], cond_mask
+
+
+def _mean_image(config, like):
+    m = getattr(config, "image_mean", None)
+    return None if m is None else m.to(like.device)[None, ...]
 
 
 def data_transform(config, X):
-    """[0,1] frames -> network range (reference: datasets/__init__.py:235-249)."""
+    """[0, 1] frames -> the range the network was trained on: the `config.data` switches of datasets/__init__.py:235-249
+    (dequantisation noise, `rescaled` to [-1, 1] or the logit transform, minus the dataset's mean image when one is configured)."""
     d = config.data
     if getattr(d, "uniform_dequantization", False):
-        X = X / 256. * 255. + torch.rand_like(X) / 256.
+        X = X / 256.0 * 255.0 + torch.rand_like(X) / 256.0
     if getattr(d, "gaussian_dequantization", False):
-        X = X + torch.randn_like(X) * 0.01
+        X = X + 0.01 * torch.randn_like(X)
     if getattr(d, "rescaled", False):
-        X = 2 * X - 1.
+        X = 2.0 * X - 1.0
     elif getattr(d, "logit_transform", False):
-        lam = 1e-6
-        X = lam + (1 - 2 * lam) * X
-        X = torch.log(X) - torch.log1p(-X)
-    if hasattr(config, "image_mean"):
-        return X - config.image_mean.to(X.device)[None, ...]
-    return X
+        Y = 1e-6 + (1.0 - 2.0 * 1e-6) * X
+        X = torch.log(Y) - torch.log1p(-Y)
+    mean = _mean_image(config, X)
+    return X if mean is None else X - mean
 
 
 def inverse_data_transform(config, X):
-    """Network range -> [0,1] (reference: datasets/__init__.py:252-261)."""
+    """The inverse map back to [0, 1], clamped (datasets/__init__.py:252-261)."""
     d = config.data
-    if hasattr(config, "image_mean"):
-        X = X + config.image_mean.to(X.device)[None, ...]
+    mean = _mean_image(config, X)
+    if mean is not None:
+        X = X + mean
     if getattr(d, "logit_transform", False):
         X = torch.sigmoid(X)
     elif getattr(d, "rescaled", False):
-        X = (X + 1.) / 2.
-    return torch.clamp(X, 0.0, 1.0)
+        X = 0.5 * (X + 1.0)
+    return X.clamp(0.0, 1.0)
 
 
 @torch.no_grad()
@@ -90,8 +108,13 @@ def video_gen(config, scorenet, cond, num_frames_pred=None, init_noise_fn=None, 
         follow the reference's expressions literally (they index dim 0 there);
       * result: cat(blocks, dim=1)[:, :C*num_frames_pred] (:1569).
 
-    `init_noise_fn(block_index, shape, device)` supplies z (default torch.randn on the device).  A `seed=` kwarg (on-device Philox
-    step noise) is advanced by one per block, so blocks never share a noise stream."""
+      * `config.model.gamma` (:1470-1474, :1518, :1545-1549): every sampler call gets `gamma=True` and the initial z of every block is the
+        centred gamma variate Gamma(k_cum[0], rate 1 / theta_t[0]) - k_cum[0] * theta_t[0].  With `data_init` as well the reference
+        divides by an undefined `used_alphas` (:1494, NameError): that combination is refused here too.
+
+    `init_noise_fn(block_index, shape, device)` supplies z (default: torch.randn on the device, or the centred gamma variate for a
+    `model.gamma` config).  A `seed=` kwarg (on-device Philox step noise) is advanced by one per block, so blocks never share a
+    noise stream."""
     d, s = config.data, config.sampling
     C, nf, nc, S = d.channels, d.num_frames, d.num_frames_cond, d.image_size
     nfp = int(num_frames_pred if num_frames_pred is not None else s.num_frames_pred)
@@ -104,7 +127,20 @@ def video_gen(config, scorenet, cond, num_frames_pred=None, init_noise_fn=None, 
     else:
         B = int(sampler_kwargs.pop("batch_size", getattr(s, "batch_size", 1)))
     shape = (B, C * nf, S, S)
-    init_noise_fn = init_noise_fn or (lambda i, shp, dv: torch.randn(shp, device=dv))
+    gamma = bool(getattr(config.model, "gamma", False))
+    if gamma and data_init is not None:
+        raise NameError("name 'used_alphas' is not defined (runners/ncsn_runner.py:1494: the reference cannot run model.gamma with "
+                        "sampling.data_init; refused here as well)")
+    if init_noise_fn is None:
+        if gamma:
+            k0, th0 = float(scorenet.k_cum[0]), float(scorenet.theta_t[0])
+
+            def init_noise_fn(i, shp, dv):
+                g = torch.distributions.gamma.Gamma(torch.full(shp, k0, device=dv), torch.full(shp, 1.0 / th0, device=dv)).sample()
+                return g - k0 * th0
+        else:
+            def init_noise_fn(i, shp, dv):
+                return torch.randn(shp, device=dv)
     t_min = getattr(s, "init_prev_t", -1)
     n_iter = nfp if one_at_a_time else ceil(nfp / nf)                                  # :1501-1504
     seed = sampler_kwargs.pop("seed", None)
@@ -128,7 +164,7 @@ def video_gen(config, scorenet, cond, num_frames_pred=None, init_noise_fn=None, 
             kw["seed"] = int(seed) + i
         out = sampler(x0, scorenet, cond=cond, cond_mask=None, final_only=True, denoise=getattr(s, "denoise", True),
                       subsample_steps=getattr(s, "subsample", None), clip_before=getattr(s, "clip_before", True),
-                      t_min=t_min, verbose=verbose, log=log, **kw)
+                      t_min=t_min, gamma=gamma, verbose=verbose, log=log, **kw)
         gen = out[-1].reshape(B, C * nf, S, S)                                          # :1521-1522
         preds.append(gen)
         if i == n_iter - 1:

@@ -91,10 +91,13 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
             raise RuntimeError(f"cond missing or mis-shaped: got {None if cond is None else tuple(cond.shape)}, expected {cwant}")
     elif cond is not None:
         raise RuntimeError("this model takes no conditioning frames (num_frames_cond == 0) but cond was passed")
-    L_all = d.num_classes if (subsample_steps is None or subsample_steps >= d.num_classes) else \
-        len(range(0, d.num_classes, d.num_classes // int(subsample_steps)))
+    # the steps the loop will run: schedule subsampling (:229-237), then the frac_steps cut (:249-256: the tail of the step list; the
+    # t_min test below compares against the CUT length, as the reference's `len(alphas)` does), then the t_min skip (:269-270)
     skip_all = d.num_classes // int(subsample_steps) if (subsample_steps is not None and subsample_steps < d.num_classes) else 1
-    n_exec = sum(1 for st in range(0, d.num_classes, skip_all) if not (st < t_min * L_all))      # steps the loop runs (:269-270)
+    step_list = list(range(0, d.num_classes, skip_all))
+    if frac_steps is not None and kind == _lib.SAMPLER_DDPM:
+        step_list = step_list[int((1 - frac_steps) * len(step_list)):]
+    n_exec = sum(1 for st in step_list if not (st < t_min * len(step_list)))
     if noise is not None:
         need = (max(n_exec - 1, 0) if kind == _lib.SAMPLER_DDPM else 0) + (1 if (t_min > 0 and n_exec > 0) else 0)
         if noise.dim() != 5 or tuple(noise.shape[1:]) != tuple(x.shape) or noise.shape[0] < need:
@@ -293,6 +296,11 @@ def fpndm_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, su
     if (d.num_frames_cond > 0) != (cond is not None) or (cond is not None and tuple(cond.shape) !=
                                                          (B, d.channels * d.num_frames_cond, d.image_size, d.image_size)):
         raise RuntimeError("cond missing or mis-shaped")
+    T_all = int(d.num_classes)
+    if (T_all - 1) // (T_all // int(subsample_steps)) * (T_all // int(subsample_steps)) + 1 >= T_all:
+        # the reference builds alphas.index_select(0, steps + 1) BEFORE its loop (models/__init__.py:74): a step list whose last entry is
+        # T - 1 fails there, up front, with torch's IndexError
+        raise IndexError("index out of range in self")
     if final_only and not getattr(net, "noise_in_cond", False):
         # the whole loop inside the library (the reference never logs in this sampler, so verbose / log change nothing)
         with torch.cuda.device(dev):

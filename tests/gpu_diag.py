@@ -341,14 +341,9 @@ def w3exp(f):
     B = 64
     kshape = int(os.environ.get("MCVD_WEXP_SHAPE", "10"))         # 10: conv_wino3.cpp (bf16x3), 12: conv_wino2h.cpp (f16x2)
     envname = "MCVD_WINO3_EXP" if kshape == 10 else "MCVD_WINO2H_EXP"
-    if kshape == 10:
-        labels = {0: "baseline", 1: "no transform (WRITE_V)", 2: "no patch activation/park (WRITE_P)", 4: "no VMEM in the loop",
-                  64: "no weight split", 15: "weight split + MFMA only", 79: "MFMA only", 16: "everything but the MFMAs",
-                  80: "no MFMA, no weight split", 27: "VMEM + weight split only", 91: "VMEM only",
-                  128: "phase order by wave parity", 256: "no patch loads", 512: "no weight loads"}
-    else:
-        labels = {0: "baseline", 1: "no transform (WRITE_V)", 2: "no patch activation/park (WRITE_P)", 3: "neither", 4: "no VMEM in the loop",
-                  16: "everything but the MFMAs", 15: "MFMA only", 27: "VMEM only", 11: "VMEM + MFMA only"}
+    # (the ablations exist in a -DMCVD_DIAG build only: python mcvd_pytorch_amd/csrc/build.py --diag; the production library ignores the env)
+    labels = {0: "baseline", 1: "no transform (WRITE_V)", 2: "no patch activation/park (WRITE_P)", 3: "neither", 4: "no VMEM in the loop",
+              16: "everything but the MFMAs", 15: "MFMA only", 27: "VMEM only", 11: "VMEM + MFMA only"}
     cases = [(96, 96, 64), (192, 192, 32), (480, 192, 32), (576, 288, 16)]
     if os.environ.get("MCVD_WEXP_CASES", "all") != "all":
         cases = [cases[int(v)] for v in os.environ["MCVD_WEXP_CASES"].split(",")]
@@ -501,6 +496,9 @@ def convops(f):
     config = synth.make_config(os.environ.get("CFG", "smmnist_big5_ngf96")); config.device = "cuda:0"
     sd = synth.make_state_dict(config, seed=123)
     net = HipScoreNet(config); net.load_state_dict({"module." + k: v for k, v in sd.items()}, strict=False); net.eval()
+    for kv in os.environ.get("OPTS", "").split(","):                 # e.g. OPTS=f16x2=1 or OPTS=conv_shape=10,conv_shape1=15
+        if kv:
+            net.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     x, cond = synth.make_inputs(config, B, seed=0)
     x, cond = x.cuda(), cond.cuda()
     t = torch.full((B,), 500, dtype=torch.long, device="cuda")
@@ -520,7 +518,7 @@ def convops(f):
         if kinds[i] != 3 or ms[i] == 0.0:
             continue
         _lib.lib.mcvd_model_op_info(net._model, i, info)
-        shape = (info[6] >> 4) & 15 if (info[6] >> 12) else -1
+        shape = _lib.lib.mcvd_model_op_kernel(net._model, i)          # the kernel family that really ran
         key = (kss[i], shape)
         tot[key] = tot.get(key, 0.0) + ms[i]
         f.write(f"op {i:3d} {kss[i]}x{kss[i]} H{info[3]:3d} cin{info[4]:4d} cout{info[5]:4d} shape {shape:2d} cot {(info[6] >> 8) & 15}: {ms[i] * 1e3:7.1f} us  {fl[i] / ms[i] / 1e9:6.1f} TF/s  {by[i] / ms[i] / 1e6:7.1f} GB/s\n")

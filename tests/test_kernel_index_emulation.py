@@ -122,25 +122,34 @@ def _mfma_32x32x16(A, Bm):
     return np.einsum("mhe,nhe->mn", A, Bm)
 
 
+PIECE_F = {2: (1.0, 7.0), 3: (1.0, 7.0, 11.0)}               # weight piece markers
+PIECE_G = {2: (1.0, 3.0), 3: (1.0, 3.0, 13.0)}               # activation piece markers
+PRODUCTS = {2: ((0, 1), (1, 0), (0, 0)),                      # pieces.h: (weight piece, activation piece), smallest product first
+            3: ((0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0))}
+
+
+@pytest.mark.parametrize("NP", [2, 3], ids=["f16x2", "bf16x3"])
 @pytest.mark.parametrize("COT,Cout,Cin,CinP", [(3, 192, 40, 48), (2, 128, 32, 32), (1, 32, 16, 16)])
-def test_wino2h_operand_layout(COT, Cout, Cin, CinP):
+def test_wino_split_operand_layout(NP, COT, Cout, Cin, CinP):
+    """conv_wino2h.cpp (NP = 2) / conv_wino3.cpp (NP = 3): pack_wino{2h,3}_weight_kernel vs *_LOAD_A / *_MF1, and *_WRITE_V vs *_LOAD_B."""
     rng = np.random.default_rng(0)
     BCO, CoutP, nch = 32 * COT, Cout, CinP // 16
+    NQ, PW = NP * COT, 16 * 2 * 4 * 32
     U = rng.standard_normal((Cout, CinP, 16))
     U[:, Cin:] = 0
-    mem = np.zeros(CinP * 16 * CoutP * 2)                       # halfwords behind the header (pack_wino2h_weight_kernel)
+    mem = np.zeros(CinP * 16 * CoutP * NP)                      # halfwords (behind the header for NP = 2)
     for co in range(Cout):
         for ci in range(Cin):
             cotile, ct, cc = co // BCO, (co % BCO) // 32, ci & 15
             h, el = cc & 1, cc >> 1
             lane = h * 32 + (co & 31)
-            base = (((cotile * nch + (ci >> 4)) * 16) * COT + ct) * 1024 + (lane * 4 + (el >> 1)) * 2 + (el & 1)
+            base = (((cotile * nch + (ci >> 4)) * 16) * COT + ct) * (NP * 512) + (lane * 4 + (el >> 1)) * 2 + (el & 1)
             for xi in range(16):
-                mem[base + xi * COT * 1024] = U[co, ci, xi]
-                mem[base + xi * COT * 1024 + 512] = 7.0 * U[co, ci, xi]
+                for p in range(NP):
+                    mem[base + xi * COT * NP * 512 + p * 512] = PIECE_F[NP][p] * U[co, ci, xi]
     chunk = nch - 1
     V = rng.standard_normal((16, 16, 32))                       # [channel in chunk][position][tile]
-    sV = np.zeros((2 * 16 * 2 * 4 * 32, 2))                     # H2_WRITE_V: words [piece][position][half][pair][tile] = (lo, hi)
+    sV = np.zeros((NP * PW, 2))                                 # *_WRITE_V: words [piece][position][half][pair][tile] = (lo, hi)
     for tid in range(512):
         rg, s_tile, s_cp = (tid >> 6) >> 2, tid & 31, (tid & 255) >> 5
         s_ca = 4 * (s_cp >> 1) + (s_cp & 1)
@@ -148,49 +157,54 @@ def test_wino2h_operand_layout(COT, Cout, Cin, CinP):
         for row in range(2):
             for q in range(4):
                 xi = (2 * rg + row) * 4 + q
-                sV[v_wr + (row * 4 + q) * 256] = (V[s_ca, xi, s_tile], V[s_ca + 2, xi, s_tile])
-                sV[v_wr + (row * 4 + q) * 256 + 4096] = (3 * V[s_ca, xi, s_tile], 3 * V[s_ca + 2, xi, s_tile])
+                for p in range(NP):
+                    g = PIECE_G[NP][p]
+                    sV[v_wr + (row * 4 + q) * 256 + p * PW] = (g * V[s_ca, xi, s_tile], g * V[s_ca + 2, xi, s_tile])
     for cotile in range(Cout // BCO):
         for wave in range(8):
             for i in range(2):
                 xi = 2 * wave + i
                 for ct in range(COT):
-                    for pa, pb, f in ((0, 1, 3.0), (1, 0, 7.0), (0, 0, 1.0)):          # u1 v2, u2 v1, u1 v1
+                    for pa, pb in PRODUCTS[NP]:
+                        f = PIECE_F[NP][pa] * PIECE_G[NP][pb]
                         A, Bm = np.zeros((32, 2, 8)), np.zeros((32, 2, 8))
                         for lane in range(64):
                             half, l31 = lane >> 5, lane & 31
-                            q = (i * COT + ct) * 2 + pa                                 # H2_LOAD_A / H2_MF1: quad of (position, sub-tile, piece)
-                            dw0 = (cotile * nch * 16 + 2 * wave) * COT * 512 + chunk * (16 * COT * 512) + q * 256 + lane * 4
+                            q = (i * COT + ct) * NP + pa                                # *_LOAD_A / *_MF1: quad of (position, sub-tile, piece)
+                            dw0 = (cotile * nch * 16 + 2 * wave) * (NQ * 256) + chunk * (16 * NQ * 256) + q * 256 + lane * 4
                             A[l31, half] = [mem[(dw0 + j) * 2 + k] for j in range(4) for k in range(2)]
-                            qb = (((2 * wave + i) * 2 + half) * 4) * 32 + l31           # H2_LOAD_B
-                            Bm[l31, half] = [sV[pb * 4096 + qb + jp * 32][k] for jp in range(4) for k in range(2)]
+                            qb = (((2 * wave + i) * 2 + half) * 4) * 32 + l31           # *_LOAD_B
+                            Bm[l31, half] = [sV[pb * PW + qb + jp * 32][k] for jp in range(4) for k in range(2)]
                         co0 = cotile * BCO + ct * 32
                         want = f * np.einsum("mc,cn->mn", U[co0:co0 + 32, chunk * 16:chunk * 16 + 16, xi], V[:, xi, :])
                         assert np.allclose(_mfma_32x32x16(A, Bm), want), (cotile, wave, i, ct, pa, pb)
 
 
+@pytest.mark.parametrize("NP", [2, 3], ids=["f16x2", "bf16x3"])
 @pytest.mark.parametrize("COT,CinP,CoutP", [(3, 32, 192), (2, 16, 128), (1, 32, 96), (4, 16, 128)])
-def test_conv1x1_h2_operand_layout(COT, CinP, CoutP):
+def test_conv1x1_split_operand_layout(NP, COT, CinP, CoutP):
+    """conv1x1_h2.cpp: pack_conv1x1_{h2,b3}_kernel vs the DMA rounds (Q1_DMA) and the A-operand reads."""
     rng = np.random.default_rng(1)
-    NS, WPC = CoutP // 32, COT * 128
+    NS, WPC = CoutP // 32, COT * NP * 64
     W = rng.standard_normal((CinP, CoutP))
-    mem = np.zeros(CinP * CoutP * 2)                            # pack_conv1x1_h2_kernel
+    mem = np.zeros(CinP * CoutP * NP)
     for ci in range(CinP):
         for co in range(CoutP):
             cc = ci & 15
             h, el = cc & 1, cc >> 1
             lane = h * 32 + (co & 31)
-            o = (((ci >> 4) * NS + (co >> 5)) * 2) * 512 + (lane * 4 + (el >> 1)) * 2 + (el & 1)
-            mem[o], mem[o + 512] = W[ci, co], 5.0 * W[ci, co]
+            o = (((ci >> 4) * NS + (co >> 5)) * NP) * 512 + (lane * 4 + (el >> 1)) * 2 + (el & 1)
+            for p in range(NP):
+                mem[o + p * 512] = PIECE_F[NP][p] * W[ci, co]
     X = rng.standard_normal((CinP, 128))
     for ctile in range(CoutP // (32 * COT)):
         for ch in range(CinP // 16):
-            lds = np.full(COT * 2 * 256 * 2, np.nan)            # the chunk's LDS image, filled by the DMA rounds (Q1_DMA)
+            lds = np.full(COT * NP * 256 * 2, np.nan)           # the chunk's LDS image, filled by the DMA rounds (Q1_DMA)
             for s in range((WPC + 255) // 256):
                 for wave in range(4):
                     q0 = (s * 256 + wave * 64) % WPC
                     for lane in range(64):
-                        g = (ch * NS + ctile * COT) * 512 + (q0 + lane) * 4             # global dword of the lane's 16 bytes
+                        g = (ch * NS + ctile * COT) * (NP * 256) + (q0 + lane) * 4      # global dword of the lane's 16 bytes
                         lds[(q0 + lane) * 8:(q0 + lane) * 8 + 8] = mem[g * 2:g * 2 + 8]
             assert not np.isnan(lds).any()
             Bm = np.zeros((128, 2, 8))
@@ -198,14 +212,78 @@ def test_conv1x1_h2_operand_layout(COT, CinP, CoutP):
                 for h in range(2):
                     Bm[n, h] = [X[ch * 16 + 2 * e + h, n] for e in range(8)]
             for ct in range(COT):
-                for piece, f in ((0, 1.0), (1, 5.0)):
+                for piece in range(NP):
                     A = np.zeros((32, 2, 8))
                     for lane in range(64):
-                        idx = ((ct * 2 + piece) * 64 + lane) * 8
+                        idx = ((ct * NP + piece) * 64 + lane) * 8
                         A[lane & 31, lane >> 5] = lds[idx:idx + 8]
                     co0 = (ctile * COT + ct) * 32
-                    want = f * np.einsum("cm,cn->mn", W[ch * 16:ch * 16 + 16, co0:co0 + 32], X[ch * 16:ch * 16 + 16])
+                    want = PIECE_F[NP][piece] * np.einsum("cm,cn->mn", W[ch * 16:ch * 16 + 16, co0:co0 + 32], X[ch * 16:ch * 16 + 16])
                     assert np.allclose(_mfma_32x32x16(A, Bm), want), (ctile, ch, ct, piece)
+
+
+@pytest.mark.parametrize("NP,D", [(2, 64), (3, 96), (3, 32)])
+def test_attention_split_operand_staging_layout(NP, D):
+    """attention_h2.cpp: the K planes [step][piece][dword j][64 lanes] (one b128 store of 4 consecutive keys per piece) against the S
+    product's four b32 reads, and the permuted V staging lanes against the PV product's b128 read; both as the MFMA contracts them."""
+    rng = np.random.default_rng(2)
+    NST, DT = D // 16, D // 32
+    K, V = rng.standard_normal((D, 32)), rng.standard_normal((D, 32))       # one key tile: [channel][key]
+    sK = np.full((NST * NP * 4 * 64, 2), np.nan)                # dwords = (lo, hi)
+    NIK = (4 * D + 255) // 256
+    for tid in range(256):
+        for i in range(NIK):
+            idx = i * 256 + tid
+            if idx >= 4 * D:
+                continue
+            rp, kq = idx >> 3, idx & 7
+            st, j, h = rp >> 3, (rp >> 1) & 3, rp & 1
+            c = 16 * st + 4 * j + h                             # rows c, c + 2 (gload)
+            for p in range(NP):
+                d1 = (st * NP * 4 + j) * 64 + h * 32 + kq * 4 + p * 256
+                for i4 in range(4):
+                    g = PIECE_G[NP][p]
+                    sK[d1 + i4] = (g * K[c, 4 * kq + i4], g * K[c + 2, 4 * kq + i4])
+    assert not np.isnan(sK).any()
+    Q = rng.standard_normal((D, 32))                            # [channel][query]
+    for s in range(NST):
+        for p in range(NP):
+            A, Bm = np.zeros((32, 2, 8)), np.zeros((32, 2, 8))
+            for lane in range(64):
+                half, l31 = lane >> 5, lane & 31
+                A[l31, half] = [sK[((s * NP + p) * 4 + j) * 64 + lane][k] for j in range(4) for k in range(2)]
+                Bm[l31, half] = [Q[16 * s + 4 * j + half + 2 * k, l31] for j in range(4) for k in range(2)]      # qp: dword j = channels c0, c0 + 2
+            want = PIECE_G[NP][p] * np.einsum("ck,cq->kq", K[16 * s:16 * s + 16], Q[16 * s:16 * s + 16])
+            assert np.allclose(_mfma_32x32x16(A, Bm), want), (s, p)
+    sV = np.full((DT * 2 * NP * 64 * 4, 2), np.nan)
+    for tid in range(256):
+        wave, lane = tid >> 6, tid & 63
+        v_c, v_h, v_s2, v_g = wave * 8 + ((lane >> 1) & 7), (lane >> 4) & 1, lane >> 5, lane & 1
+        v_q = v_s2 * 4 + v_g * 2 + v_h
+        for i in range(DT):
+            c = i * 32 + v_c
+            ct, m, j0 = c >> 5, c & 31, 2 * v_g
+            for p in range(NP):
+                g = PIECE_G[NP][p]
+                d1 = ((ct * 2 + v_s2) * NP * 64 + v_h * 32 + m) * 4 + j0 + p * 256
+                sV[d1] = (g * V[c, 4 * v_q], g * V[c, 4 * v_q + 1])
+                sV[d1 + 1] = (g * V[c, 4 * v_q + 2], g * V[c, 4 * v_q + 3])
+    assert not np.isnan(sV).any()
+    P = rng.standard_normal((32, 32))                           # [key][query]
+    for ct in range(DT):
+        for p in range(NP):
+            acc = np.zeros((32, 32))
+            for s2 in range(2):
+                A, Bm = np.zeros((32, 2, 8)), np.zeros((32, 2, 8))
+                for lane in range(64):
+                    half, l31 = lane >> 5, lane & 31
+                    base = (((ct * 2 + s2) * NP + p) * 64 + lane) * 4
+                    A[l31, half] = [sV[base + j][k] for j in range(4) for k in range(2)]
+                    keys = [((r & 3) + 8 * (r >> 2) + 4 * half) for r in range(8 * s2, 8 * s2 + 8)]      # accumulator register r of S^T
+                    Bm[l31, half] = [P[k, l31] for k in keys]
+                acc += _mfma_32x32x16(A, Bm)
+            want = PIECE_G[NP][p] * np.einsum("ck,kq->cq", V[ct * 32:ct * 32 + 32], P)
+            assert np.allclose(acc, want), (ct, p)
 
 
 def test_attention_h2_key_slot_convention():

@@ -29,6 +29,56 @@ def test_conditioning_fn_layout_is_frame_major():
     assert cond0[:, C:].abs().max() == 0                                        # :130-131 all-zero future block
 
 
+def test_conditioning_masks_zero_whole_samples_and_keep_the_draw_order():
+    """prob_mask_cond / prob_mask_future (runners/ncsn_runner.py:119-145): per-sample keep masks, cond mask drawn before the future
+    mask, int32 cond_mask returned, `prob_mask_sync` reuses the cond mask for the future block."""
+    r = _runner()
+    cfg = synth.make_config("tiny_spade")           # past = 1, future = 1
+    d = cfg.data
+    B, C, S = 64, d.channels, d.image_size
+    T = d.num_frames_cond + d.num_frames + d.num_frames_future
+    X = 1.0 + torch.rand(B, T, C, S, S)
+    torch.manual_seed(5)
+    pred, cond, mask = r.conditioning_fn(cfg, X, num_frames_pred=d.num_frames, prob_mask_cond=0.5, prob_mask_future=0.5)
+    torch.manual_seed(5)
+    m1 = torch.rand(B) > 0.5
+    m2 = torch.rand(B) > 0.5
+    assert mask.dtype == torch.int32 and torch.equal(mask.bool(), m1)
+    past, fut = cond[:, :C], cond[:, C:]
+    assert torch.equal(past.flatten(1).abs().sum(1) > 0, m1) and torch.equal(fut.flatten(1).abs().sum(1) > 0, m2)
+    assert torch.equal(pred, X[:, d.num_frames_cond:d.num_frames_cond + d.num_frames].flatten(1, 2))
+    d.prob_mask_sync = True
+    torch.manual_seed(5)
+    _, cond_s, mask_s = r.conditioning_fn(cfg, X, num_frames_pred=d.num_frames, prob_mask_cond=0.5, prob_mask_future=0.5)
+    assert torch.equal(cond_s[:, C:].flatten(1).abs().sum(1) > 0, mask_s.bool())
+    d.prob_mask_sync = False
+    flat, none_c, none_m = r.conditioning_fn(cfg, X, conditional=False)
+    assert none_c is None and none_m is None and torch.equal(flat, X.flatten(1, 2))
+
+
+def test_data_transform_switches():
+    """uniform dequantisation stays inside [0, 1), the logit transform inverts through the sigmoid, a mean image is removed and
+    restored (datasets/__init__.py:235-261)."""
+    r = _runner()
+    cfg = synth.make_config("tiny")
+    d = cfg.data
+    X = torch.rand(2, 4, 1, 8, 8)
+    d.rescaled, d.logit_transform = False, True
+    Y = r.data_transform(cfg, X)
+    lam = 1e-6
+    Xl = lam + (1 - 2 * lam) * X
+    assert torch.equal(Y, torch.log(Xl) - torch.log1p(-Xl))
+    assert torch.allclose(r.inverse_data_transform(cfg, Y), Xl, atol=1e-6)
+    d.logit_transform, d.rescaled, d.uniform_dequantization = False, False, True
+    Y = r.data_transform(cfg, X)
+    assert (Y >= X / 256. * 255.).all() and (Y < X / 256. * 255. + 1 / 256. + 1e-7).all()
+    d.uniform_dequantization, d.rescaled = False, True
+    cfg.image_mean = torch.full((4, 1, 8, 8), 0.25)
+    Y = r.data_transform(cfg, X)
+    assert torch.allclose(Y, 2 * X - 1 - 0.25) and torch.allclose(r.inverse_data_transform(cfg, Y), X, atol=1e-6)
+    del cfg.image_mean
+
+
 def test_data_transform_round_trip():
     r = _runner()
     cfg = synth.make_config("tiny")

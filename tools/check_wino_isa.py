@@ -10,13 +10,11 @@ the destination registers of those loads are pending.  That is only sound if, in
      plus, in the SPADE-prologue instantiations (PRO 3), two LDS-DMA loads per patch load (gamma | beta), which the vmcnt counts include.
 This script compiles the file to gfx950 assembly and verifies 1-3 for every instantiation of conv_wino_kernel.
 
-conv_wino3.cpp (the split-operand bf16 form of the same convolution) counts its VMEM the same way: its K loops (two per kernel,
-one per phase order) must hold exactly 4*COT weight loads + 6 patch loads, no scratch traffic, and keep the load destinations
-untouched up to the next vmcnt wait.
-
-conv_wino2h.cpp (two fp16 pieces per operand, pre-split weights) has the same two K loops and the same load counts; its MFMAs are
-inline asm that read their A operand straight out of the load destinations, so in addition nothing but MFMAs may touch an
-accumulator register inside a K loop (the compiler does not know they are MFMA results and would not insert the wait states).
+conv_wino2h.cpp (two fp16 pieces per operand, pre-split weights) and conv_wino3.cpp (three bf16 pieces, pre-split weights) count
+their VMEM the same way: their K loops (two per kernel, one per phase order) must hold exactly 4*COT (6*COT) weight loads + 6 patch
+loads, no scratch traffic, and keep the load destinations untouched up to a vmcnt wait that covers them.  Their MFMAs are inline
+asm that read their A operand straight out of the load destinations, so in addition nothing but MFMAs may touch an accumulator
+register inside a K loop (the compiler does not know they are MFMA results and would not insert the wait states).
 """
 import os
 import re
@@ -126,8 +124,9 @@ def _dest_untouched_covering(name, loop, problems):
             problems.append(f"{name}: no wait covers `{l}`")
 
 
-def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=False, expect=9):
-    """conv_wino3_kernel<COT, PRO, 0> / conv_wino2h_kernel<COT, PRO, 0>: every loop that holds MFMAs is a K loop."""
+def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_per_cot=6):
+    """conv_wino3_kernel<COT, PRO, G8, 0> / conv_wino2h_kernel<COT, PRO, G8, 0>: every loop that holds MFMAs is a K loop; a K loop
+    holds wl_per_cot * COT weight loads (NP pieces x 2 positions) + 6 patch loads."""
     problems, seen = [], 0
     for m in re.finditer(r"^(_ZN4mcvd" + kernel + r"ILi(\d)ELi(\d)E(?:Lb[01]E)?Li0EEEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
         name, cot, body = m.group(1), int(m.group(2)), m.group(4)
@@ -156,8 +155,8 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=False, expect=9):
                 problems.append(f"{name}: a vmcnt(0) wait inside a K loop (the loop's loads are meant to stay in flight)")
             wl = [l for l in vmem if re.match(r"^global_load_dwordx4 v", l)]
             pl = [l for l in vmem if re.match(r"^global_load_dword v", l)]
-            if len(wl) != 4 * cot or len(pl) != 6 or len(wl) + len(pl) != len(vmem):
-                problems.append(f"{name}: expected {4 * cot} weight + 6 patch loads and no other VMEM in a K loop, found {len(wl)} + {len(pl)} of {len(vmem)}")
+            if len(wl) != wl_per_cot * cot or len(pl) != 6 or len(wl) + len(pl) != len(vmem):
+                problems.append(f"{name}: expected {wl_per_cot * cot} weight + 6 patch loads and no other VMEM in a K loop, found {len(wl)} + {len(pl)} of {len(vmem)}")
             _dest_untouched_covering(name, loop, problems)
             if asm_mfma:      # accumulators: written and read by MFMAs only
                 acc = set()
@@ -211,7 +210,7 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=False, expect=9):
 
 
 def check2h(asm_text):
-    return check3(asm_text, kernel="18conv_wino2h_kernel", asm_mfma=True, expect=18)      # x {8x16 regions, 8x8 images}
+    return check3(asm_text, kernel="18conv_wino2h_kernel", asm_mfma=True, expect=18, wl_per_cot=4)      # x {8x16 regions, 8x8 images}
 
 
 def main():
