@@ -10,7 +10,8 @@ import torch  # noqa: F401  -- MUST precede the CDLL: libmcvd_hip.so then binds 
 #                              (two libamdhip64 copies in one process do not both see the device)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcvd_hip.so")
+# MCVD_LIB_PATH: diagnostics only (tests/gpu_diag.py loads libmcvd_hip_diag.so, the -DMCVD_DIAG build with the ablation kernels)
+LIB_PATH = os.environ.get("MCVD_LIB_PATH") or os.path.join(_HERE, "libmcvd_hip.so")
 
 MAX_LEVELS = 8
 

@@ -716,8 +716,10 @@ int mcvd_fpndm_run(mcvd_model* m, float* x, const float* cond, int subsample_ste
     };
     int n_ets = 0;
     int t_prev = -1;
-    const char* ms_env = getenv("MCVD_FPNDM_MAXSTEPS");          // diagnostics: stop after this many steps
-    int steps_left = ms_env ? atoi(ms_env) : (1 << 30);
+    int steps_left = 1 << 30;
+#ifdef MCVD_DIAG
+    if (const char* ms_env = getenv("MCVD_FPNDM_MAXSTEPS")) steps_left = atoi(ms_env);          // diagnostics build: stop after this many steps
+#endif
     for (int t = 0; t < T && steps_left > 0; t += skip, --steps_left) {
         MCVD_REQUIRE(t + 1 < T, "fpndm_run: index %d is out of bounds for the alpha table of size %d (the reference fails the same way "
                      "when num_classes is not a multiple of subsample_steps)", t + 1, T);

@@ -31,31 +31,35 @@ def headers():
             + glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.abspath(__file__)])
 
 
-def compile_one(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+def compile_one(src, force, diag=False):
+    obj = os.path.join(OBJ + ("_diag" if diag else ""), os.path.basename(src)[:-4] + ".o")
     newest_dep = max(os.path.getmtime(p) for p in [src] + headers())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest_dep:
         return obj, None
-    cmd = [HIPCC] + FLAGS + HOST_ONLY_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + (["-DMCVD_DIAG"] if diag else []) + HOST_ONLY_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
     return obj, r.stderr.strip()
 
 
-def build(force=False, jobs=None, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, jobs=None, verbose=True, diag=False):
+    """diag=True: the diagnostics library libmcvd_hip_diag.so (-DMCVD_DIAG: env hooks MCVD_DBG_WAVE / MCVD_WINO*_EXP / MCVD_FPNDM_MAXSTEPS and
+    the timing-only ablation kernels, which produce WRONG results); tests/gpu_diag.py loads it through MCVD_LIB_PATH.  The product
+    library has none of that."""
+    lib = os.path.join(PKG, "libmcvd_hip_diag.so") if diag else LIB
+    os.makedirs(OBJ + ("_diag" if diag else ""), exist_ok=True)
     srcs = sources()
     objs, rebuilt, wino_rebuilt = [], 0, False
     with cf.ThreadPoolExecutor(max_workers=jobs or os.cpu_count()) as ex:
-        for obj, log in ex.map(lambda s: compile_one(s, force), srcs):
+        for obj, log in ex.map(lambda s: compile_one(s, force, diag), srcs):
             objs.append(obj)
             if log is not None:
                 rebuilt += 1
                 wino_rebuilt |= os.path.basename(obj) in ("conv_wino.o", "conv_wino3.o", "conv_wino2h.o")
                 if log and verbose:
                     print(log, file=sys.stderr)
-    if wino_rebuilt:
+    if wino_rebuilt and not diag:
         # conv_wino.cpp manages its VMEM waits by hand; the generated code must keep the invariants that makes sound
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_wino_isa.py")], capture_output=True, text=True)
         if r.returncode != 0:
@@ -63,19 +67,20 @@ def build(force=False, jobs=None, verbose=True):
             raise RuntimeError("conv_wino.cpp: generated code violates the asm-load invariants\n" + r.stderr)
         if verbose:
             print(r.stdout.strip())
-    if rebuilt or not os.path.exists(LIB) or force:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    if rebuilt or not os.path.exists(lib) or force:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stderr))
     if verbose:
-        print("libmcvd_hip.so: %d/%d objects rebuilt -> %s" % (rebuilt, len(srcs), LIB))
-    return LIB
+        print("%s: %d/%d objects rebuilt -> %s" % (os.path.basename(lib), rebuilt, len(srcs), lib))
+    return lib
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("-j", type=int, default=None)
+    ap.add_argument("--diag", action="store_true", help="build libmcvd_hip_diag.so (-DMCVD_DIAG) instead")
     a = ap.parse_args()
-    build(force=a.force, jobs=a.j)
+    build(force=a.force, jobs=a.j, diag=a.diag)

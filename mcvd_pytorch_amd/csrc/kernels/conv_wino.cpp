@@ -615,6 +615,7 @@ static size_t wino_lds_bytes(int Cin, bool g8, bool spade = false) {
     return k > epi ? k : epi;
 }
 
+#ifdef MCVD_DIAG
 template <int EXP>
 static int wino_launch_exp1(const ConvArgs& k, dim3 grid, size_t lds, hipStream_t s) {
     static PerDeviceOnce raised;
@@ -650,6 +651,7 @@ static int wino_launch_exp(int e, const ConvArgs& k, dim3 grid, size_t lds, hipS
         default: mcvd::set_error("MCVD_WINO_EXP=%d is not a built ablation", e); return -1;
     }
 }
+#endif
 
 // Second pass of the 2-way K split (conv_wino.cpp and conv_wino3.cpp): y = s * (p0 + p1 + bias + res), with the GroupNorm partials of
 // the final values where the plane size allows (one partial per (sample, channel) plane).
@@ -688,15 +690,20 @@ static int wino_launch3(const ConvArgs& a, hipStream_t s) {
     const int ksp = a.ksplit == 2 ? 2 : 1;
     dim3 grid(((nreg + 7) / 8) * 8 * (a.CoutP / BCO), ksp);
     ConvArgs k = a;
+    if (k.dbg) k.wdma = 0;                 // wave 0 records its phase times
+#ifdef MCVD_DIAG
+    // diagnostics build only (build.py --diag): which wave records, and the timing-only ablations of the K loop (WRONG RESULTS; the
+    // production library has neither the env hooks nor the ablation kernels)
     if (k.dbg) {
-        const char* w = getenv("MCVD_DBG_WAVE");       // which wave records its phase times (diagnostics)
+        const char* w = getenv("MCVD_DBG_WAVE");
         k.wdma = w ? atoi(w) : 0;
     }
-    const char* exp_s = getenv("MCVD_WINO_EXP");           // read per launch: the diagnostics script flips it between runs
+    const char* exp_s = getenv("MCVD_WINO_EXP");
     const int exp_env = exp_s ? atoi(exp_s) : 0;
-    if (COT == 3 && PRO == 2 && !G8 && exp_env != 0) {      // timing-only ablations (tests/gpu_diag.py wexp)
+    if (COT == 3 && PRO == 2 && !G8 && exp_env != 0) {      // tests/gpu_diag.py wexp
         if (int rc = wino_launch_exp(exp_env, k, grid, lds, s)) return rc;
     } else
+#endif
     hipLaunchKernelGGL((conv_wino_kernel<COT, PRO, G8>), grid, dim3(WR_NT), lds, s, k);
     MCVD_HIP_CHECK(hipGetLastError());
     if (ksp == 2) {

@@ -53,9 +53,10 @@ constexpr int H2_PP = 24;        // LDS patch row pitch (conv_wino.cpp: WR_PP)
 constexpr int H2_VW = 2 * 16 * 2 * 4 * H2_T;      // 32-bit words of one V chunk: [piece][position][half][pair][tile]
 constexpr int H2_HDR = 4;        // header floats in front of the packed weight pieces: |w|max, scale, 1 / scale, -
 constexpr float H2_ACT_SCALE = 16.0f;             // activations enter the patch times 2^4 (exact): transformed values of the
-                                                  // order 10..1e3, second pieces clear of the fp16 denormal range; the clamp
-                                                  // below caps |B^T d B| at 65504 / 16 ~ 4094 (GroupNorm-ed inputs cannot get there)
-constexpr float H2_F16_MAX = 65504.0f;
+                                                  // order 10..1e3, second pieces clear of the fp16 denormal range.  |B^T d B| must
+                                                  // stay below 65504 / 16 ~ 4094 (GroupNorm-ed inputs -- the only ones the library
+                                                  // gives this kernel -- cannot get there); beyond it the result is NaN, not a
+                                                  // saturated number
 
 // (lo, hi) -> packed fp16 pair, round to nearest even (v_cvt_pk_f16_f32)
 __device__ __forceinline__ unsigned h2_cvt_pk(float lo, float hi) {
@@ -65,8 +66,8 @@ __device__ __forceinline__ unsigned h2_cvt_pk(float lo, float hi) {
 // two-way split of two fp32 values into packed fp16 pairs: w1 = fp16(v), w2 = fp16(v - w1); v - w1 is exact (v_fma_mix_f32
 // reads the fp16 half it subtracts straight out of the packed pair)
 __device__ __forceinline__ void h2_split2(f32x2 v, unsigned& w1, unsigned& w2) {
-    v.x = __builtin_amdgcn_fmed3f(v.x, -H2_F16_MAX, H2_F16_MAX);
-    v.y = __builtin_amdgcn_fmed3f(v.y, -H2_F16_MAX, H2_F16_MAX);
+    // no clamp: a transformed value beyond the fp16 range becomes Inf here and NaN in the accumulator -- loud, where a clamp would
+    // saturate silently (the library keeps raw, unbounded tensors away from this kernel and reports non-finite results)
     w1 = h2_cvt_pk(v.x, v.y);
     float rx, ry;
     asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(w1), "v"(v.x));
@@ -76,7 +77,7 @@ __device__ __forceinline__ void h2_split2(f32x2 v, unsigned& w1, unsigned& w2) {
 
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU (the GroupNorm / temb prologue of conv_wino.cpp)
 // a.ksplit == 2 (grid.y = 2): half of the input channels per workgroup, raw partial result to a.part[half] (conv_wino.cpp).
-// EXP != 0: timing-only ablations of the K loop (wrong results; env MCVD_WINO2H_EXP, tests/gpu_diag.py w3exp): bit 0 no tile
+// EXP != 0 (built with -DMCVD_DIAG only): timing-only ablations of the K loop (wrong results; env MCVD_WINO2H_EXP, tests/gpu_diag.py w3exp): bit 0 no tile
 //     transform, bit 1 no patch activation/park, bit 2 no VMEM in the loop, bit 3 no B-operand reads, bit 4 no MFMA.
 // G8: 8x8 images -- the 32 tiles of a workgroup are TWO whole images (16 tiles each, image i at patch columns 10 i .. 10 i + 9); every
 //     halo element is zero padding, so only the 2 x 64 interior pixels per channel are loaded (slots 0-3 of the six; the other two
@@ -592,14 +593,18 @@ static int wino2h_launch2(const ConvArgs& a, hipStream_t s) {
     const int ksp = a.ksplit == 2 ? 2 : 1;
     dim3 grid(((nreg + 7) / 8) * 8 * (a.CoutP / BCO), ksp);
     ConvArgs k = a;
+    int rc = 0;
+    if (k.dbg) k.wdma = 0;                 // wave 0 records its phase times
+#ifdef MCVD_DIAG
+    // diagnostics build only (build.py --diag): which wave records, and the timing-only ablations of the K loop (WRONG RESULTS; the
+    // production library has neither the env hooks nor the ablation kernels)
     if (k.dbg) {
-        const char* w = getenv("MCVD_DBG_WAVE");       // which wave records its phase times (diagnostics)
+        const char* w = getenv("MCVD_DBG_WAVE");
         k.wdma = w ? atoi(w) : 0;
     }
-    const char* exp_s = getenv("MCVD_WINO2H_EXP");         // read per launch: the diagnostics script flips it between runs
+    const char* exp_s = getenv("MCVD_WINO2H_EXP");
     const int e = exp_s ? atoi(exp_s) : 0;
-    int rc = 0;
-    if (COT == 3 && PRO == 2 && !G8 && e != 0) {           // timing-only ablations (tests/gpu_diag.py w3exp)
+    if (COT == 3 && PRO == 2 && !G8 && e != 0) {           // tests/gpu_diag.py w3exp
         switch (e) {
             case 1: rc = wino2h_launch_k<3, 2, false, 1>(k, grid, lds, s); break;        // no transform
             case 2: rc = wino2h_launch_k<3, 2, false, 2>(k, grid, lds, s); break;        // no patch activation / park
@@ -611,7 +616,9 @@ static int wino2h_launch2(const ConvArgs& a, hipStream_t s) {
             case 11: rc = wino2h_launch_k<3, 2, false, 11>(k, grid, lds, s); break;      // VMEM + MFMA only
             default: mcvd::set_error("MCVD_WINO2H_EXP=%d is not a built ablation", e); return -1;
         }
-    } else {
+    } else
+#endif
+    {
         rc = wino2h_launch_k<COT, PRO, G8, 0>(k, grid, lds, s);
     }
     if (rc) return rc;

@@ -22,7 +22,8 @@
 //     STRAIGHT INTO THE MFMA A-OPERAND REGISTERS (named registers the compiler does not allocate, v184-v255: see W3_LOAD_A) and
 //     reloaded for the next chunk as soon as the position's MFMAs have been issued: prefetch distance = one chunk.
 //   * K-slot convention of the 32x32x16 MFMA (both operands): lane half h, element e  <->  channel 2e + h of the chunk.
-//   * activations: patch in LDS, channel pairs interleaved; the transform runs on packed fp32, splits three ways
+//   * activations: raw patch fetched four pixels per lane (global_load_dwordx4) + one halo pixel, activated and parked in LDS with the
+//     channels of a pair interleaved; the transform runs on packed fp32, splits three ways
 //     (v_cvt_pk_bf16_f32, expand, v_pk_add_f32 per level: 9 VALU per channel pair and position) and parks three bf16 planes
 //     [piece][position][k half][k pair][tile].
 //   * the two waves of a SIMD run the chunk in opposite orders (patch + transform | MFMAs), one barrier per chunk.
@@ -76,24 +77,34 @@ __device__ __forceinline__ void w3_split3(f32x2 v, unsigned& w1, unsigned& w2, u
 //     halo element is zero padding, so only the 2 x 64 interior pixels per channel are loaded (slots 0-3 of the six; the other two
 //     fetch a dummy) and the halo of both patch buffers is zeroed once.  The coefficient table holds both samples.
 template <int COT, int PRO, bool G8, int EXP = 0>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void conv_wino3_kernel(ConvArgs a) {
-    // amdgpu_num_vgpr(178): registers the compiler may allocate; v178-v255 hold the in-flight loads and the A operands (W3_LOAD_A)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv_wino3_kernel(ConvArgs a) {
+    // amdgpu_num_vgpr(86): the compiler may allocate v0-v171; v172-v255 hold the in-flight loads and the A operands (W3_LOAD_A).
+    // On gfx90a+ LLVM DOUBLES the requested number (unified VGPR + AGPR file) before it checks it against the occupancy bound and
+    // drops it silently when the doubled value exceeds 256: amdgpu_num_vgpr(172) would be ignored, amdgpu_num_vgpr(86) caps the
+    // allocator at 172 registers (this kernel uses no AGPRs).  tools/check_wino_isa.py verifies the outcome on the generated code.
     constexpr int NT = W3_NT, CK = W3_CK, T = W3_T, BCO = 32 * COT, PP = W3_PP, VW = W3_VW, PW = W3_PW;
     constexpr int PSZ = CK * 10 * PP;           // activated input patch of one chunk: [CK][10 rows][PP]
-    constexpr int PBUF = PSZ + 4;               // + dump space for unused patch slots
-    constexpr int PCOUNT = G8 ? CK * 2 * 64 : CK * 10 * 18;     // patch elements loaded per chunk
-    constexpr int MAXP = 6;                                     // load slots per thread and chunk (G8 uses four of them)
+    constexpr int PBUF = PSZ + 8;               // + dump space for unused patch slots (four floats, two apart)
+    // patch-load slots per thread and chunk.  A row of the patch is 16 interior pixels (64-byte aligned in the image: four 16-byte loads)
+    // plus one halo pixel on each side: 16 channels x 10 rows x 4 = 640 four-pixel items (slot 0: item tid; slot 1: item 512 + tid for
+    // tid < 128) and 16 x 10 x 2 = 320 halo items (slot 2: item tid for tid < 320).  Round 3's first form loaded 2880 single pixels in six
+    // dword slots: 48 wave instructions per chunk where this takes 15, and the vector memory path -- 64 bytes per clock and CU, which the
+    // weight stream alone keeps busy 2304 of a chunk's cycles -- had 768 more cycles of work per chunk (profiles/r03_wino3_kloop.txt).
+    // G8: 16 channels x 2 images x 8 rows x 2 = 512 four-pixel items, one per thread, no halo loads (the halo is zero padding).
+    constexpr int NPL = G8 ? 1 : 3;                             // load instructions per thread and chunk
+    constexpr int NPV = G8 ? 4 : 9;                             // values they bring
     constexpr int NQ = 3 * COT;                                 // weight quads per position: COT cout sub-tiles x 3 pieces
     constexpr int NA = 2 * NQ;                                  // weight loads per wave and chunk
-    constexpr int VM_A = NQ + MAXP;                             // see W3_MFMA_PHASE
-    static_assert(MAXP == 6 && NA <= 18, "named-register map below: v178-v183 patch, v184-v255 eighteen weight quads");
+    constexpr int VM_A = NQ + NPL;                              // see W3_MFMA_PHASE
+    constexpr int PQ = 5;                                       // weight quads whose registers hold the first two patches in the prologue
+    static_assert(NA <= 18 && NA > PQ, "named-register map below: v172-v180 patch, v184-v255 eighteen weight quads");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned* sV = reinterpret_cast<unsigned*>(smem);           // [2][VW]
     float* sP = smem + 2 * VW;                  // [2][PBUF]
     float* sCo = sP + 2 * PBUF;                 // [Cin][2] prologue coefficients (A_c, B_c) of this sample (PRO only; G8: [2][Cin][2])
-    unsigned* sOff = reinterpret_cast<unsigned*>(sCo + (G8 ? 4 : 2) * a.Cin);      // [MAXP][NT] byte offsets of the patch-load slots (read by their owner only)
+    unsigned* sOff = reinterpret_cast<unsigned*>(sCo + (G8 ? 4 : 2) * a.Cin);      // [NPL][NT] byte offsets of the patch-load slots (read by their owner only)
 
-    {   // the kernel descriptor must allocate all 256 registers: the asm statements below name v178-v255 in their text only
+    {   // the kernel descriptor must allocate all 256 registers: the asm statements below name v172-v255 in their text only
         float top;
         asm volatile("" : "={v255}"(top));
     }
@@ -133,37 +144,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
     // word of (piece 0, position 8*rg, half, pair, tile); one position further = 256 words, one piece = PW
     const int v_wr = ((8 * rg * 2 + (s_cp & 1)) * 4 + (s_cp >> 1)) * T + s_tile;
 
-    // ---- patch-load slots (chunk invariant): p_pk = LDS float index of the element (12 bits) | channel code << 12, code = channel
-    // in chunk, + CK when the element is padding / unused (| G8: image of the region << 20); sOff[sl][tid] = byte offset of the
-    // (clamped) pixel from the chunk's first channel plane (parked in LDS: six registers the MFMA phase needs more)
-    unsigned p_pk[MAXP];
+    // ---- patch-load slots (chunk invariant): p_pk = LDS float index of the slot's FIRST element (12 bits; a four-pixel item continues at
+    // + 2, + 4, + 6: the patch interleaves the two channels of a pair) | channel code << 12, code = channel in chunk, + CK when the slot is
+    // padding / unused (| G8: image of the region << 20); sOff[sl][tid] = byte offset of the (clamped) first pixel from the chunk's first
+    // channel plane (parked in LDS: registers the MFMA phase needs more)
+    unsigned p_pk[NPL];
 #pragma unroll
-    for (int sl = 0; sl < MAXP; ++sl) {
-        const int e = sl * NT + tid;
-        if (G8) {
-            if (e < PCOUNT) {                   // e -> (channel, image, row, col) of an interior pixel
-                const int ci = e >> 7, img = (e >> 6) & 1, r = (e >> 3) & 7, c = e & 7;
-                const bool valid = b + img < a.B;
+    for (int sl = 0; sl < NPL; ++sl) {
+        p_pk[sl] = (unsigned)PSZ | ((unsigned)CK << 12);        // unused: a dummy load, parked in the dump space
+        unsigned off = 0;
+        if (G8) {                               // item tid -> (channel, image, row, half row) of interior pixels
+            const int e = tid, ci = e >> 5, img = (e >> 4) & 1, r = (e >> 1) & 7, c = (e & 1) * 4;
+            const bool valid = b + img < a.B;
+            const int cp = (ci >> 2) * 2 + (ci & 1), ce = (ci >> 1) & 1;
+            p_pk[sl] = (unsigned)(((cp * 10 + r + 1) * PP + img * 10 + c + 1) * 2 + ce) | ((unsigned)(ci + (valid ? 0 : CK)) << 12) |
+                       ((unsigned)(valid ? img : 0) << 20);
+            off = (unsigned)(ci * HW + r * 8 + c) * 4u;
+        } else if (sl < 2) {                    // four interior pixels of a row
+            const int e = sl * NT + tid;
+            if (e < CK * 40) {
+                const int ci = e / 40, rem = e - ci * 40, r = rem >> 2, c = (rem & 3) * 4;
+                const int y = oy0 - 1 + r;
+                const bool inside = y >= 0 && y < H;
                 const int cp = (ci >> 2) * 2 + (ci & 1), ce = (ci >> 1) & 1;
-                p_pk[sl] = (unsigned)(((cp * 10 + r + 1) * PP + img * 10 + c + 1) * 2 + ce) | ((unsigned)(ci + (valid ? 0 : CK)) << 12) |
-                           ((unsigned)(valid ? img : 0) << 20);
-                sOff[sl * NT + tid] = (unsigned)(ci * HW + r * 8 + c) * 4u;
-            } else {
-                p_pk[sl] = (unsigned)PSZ | ((unsigned)CK << 12);
-                sOff[sl * NT + tid] = 0;
+                p_pk[sl] = (unsigned)(((cp * 10 + r) * PP + c + 1) * 2 + ce) | ((unsigned)(ci + (inside ? 0 : CK)) << 12);
+                off = (unsigned)(ci * HW + min(max(y, 0), H - 1) * W + ox0 + c) * 4u;
             }
-        } else if (e < PCOUNT) {
-            const int ci = e / 180, rem = e - ci * 180;
-            const int r = rem / 18, c = rem - r * 18;
+        } else if (tid < CK * 20) {             // one halo pixel: left (column 0) or right (column 17) of a row
+            const int e = tid, ci = e / 20, rem = e - ci * 20, r = rem >> 1, c = (rem & 1) * 17;
             const int y = oy0 - 1 + r, x = ox0 - 1 + c;
             const bool inside = y >= 0 && y < H && x >= 0 && x < W;
             const int cp = (ci >> 2) * 2 + (ci & 1), ce = (ci >> 1) & 1;
             p_pk[sl] = (unsigned)(((cp * 10 + r) * PP + c) * 2 + ce) | ((unsigned)(ci + (inside ? 0 : CK)) << 12);
-            sOff[sl * NT + tid] = (unsigned)(ci * HW + min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)) * 4u;
-        } else {
-            p_pk[sl] = (unsigned)PSZ | ((unsigned)CK << 12);
-            sOff[sl * NT + tid] = 0;
+            off = (unsigned)(ci * HW + min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)) * 4u;
         }
+        sOff[sl * NT + tid] = off;
     }
 
     // ---- weight fetch: the NA quads of a wave per chunk are contiguous: quad q = (i * COT + ct) * 3 + piece of positions 2w + i at
@@ -172,8 +187,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
     const unsigned* wr_base = reinterpret_cast<const unsigned*>(a.wpb) + ((long)cotile * (a.CinP / CK) * 16 + 2 * wave_u) * (NQ * 256);
     const unsigned wr_voff = (unsigned)lane * 16u;
 
-    /* IN-FLIGHT DATA LIVES IN REGISTERS THE COMPILER DOES NOT ALLOCATE.  The kernel is compiled with amdgpu_num_vgpr(178): v178-v255 are
-       never touched by generated code.  The asm loads write them (weight quad q: v[184 + 4q : 187 + 4q]; patch slots: v178-v183), the
+    /* IN-FLIGHT DATA LIVES IN REGISTERS THE COMPILER DOES NOT ALLOCATE.  The kernel is compiled with amdgpu_num_vgpr(86): v172-v255 are
+       never touched by generated code.  The asm loads write them (weight quad q: v[184 + 4q : 187 + 4q]; patch slots: v[172:175], v[176:179], v180), the
        waits are bare s_waitcnt, the MFMAs name their A operand in the instruction text.  (Loads whose results are compiler-visible
        values are not safe here: the register allocator may assign the result and the operand of the later wait to different registers
        and copy between them while the load is still in flight -- it did, a wrong result once in ~10^4 launches.)
@@ -189,36 +204,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
         _Pragma("unroll") for (int qq = 0; qq < NQ; ++qq) { W3_QUADS(W3_LD1, (i) * NQ + qq, ua + qq * 256, 0) } \
     }
     /* prologue: quads Q0 .. Q1-1 of chunk `ch`, issued behind the instructions that produced DEP (which read the registers) */
-#define W3_LD1D(K, R, q, P, DEP) if ((q) == K) asm volatile("global_load_dwordx4 " R ", %0, %1" :: "v"(wr_voff), "s"(P), "v"(DEP[0]), "v"(DEP[1]), "v"(DEP[2]), "v"(DEP[3]), "v"(DEP[4]), "v"(DEP[5]) : "memory");
+#define W3_LD1D(K, R, q, P, DEP) if ((q) == K) asm volatile("global_load_dwordx4 " R ", %0, %1" :: "v"(wr_voff), "s"(P), "v"(DEP) : "memory");
 #define W3_LOAD_A_RANGE(ch, Q0, Q1, DEP)                                                                        \
     {                                                                                                           \
         const unsigned* ua = wr_base + (long)(ch) * (16 * NQ * 256);                                            \
         _Pragma("unroll") for (int qq = (Q0); qq < (Q1); ++qq) { W3_QUADS(W3_LD1D, qq, ua + qq * 256, DEP) }    \
     }
 #define W3_WAIT(N) asm volatile("s_waitcnt vmcnt(%1)\n\ts_mov_b32 %0, 0" : "=s"(vtok) : "n"(N) : "memory");
-    /* unconditional, clamped raw loads of the patch of chunk `ch` (conv_wino.cpp: WR_LOAD_P) */
-#define W3_READ_OFF(OFS) { _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) OFS[sl] = sOff[sl * NT + tid]; }
-#define W3_LOAD_P(ch, DEP, OFS) W3_LOAD_PR(ch, DEP, OFS, "v178", "v179", "v180", "v181", "v182", "v183")
-#define W3_LOAD_PR(ch, DEP, OFS, R0, R1, R2, R3, R4, R5)                                                        \
+    /* unconditional, clamped raw loads of the patch of chunk `ch`: RA / RB = the two four-pixel slots, RH = the halo slot; DEP = a value
+       computed from the previous contents of those registers (ordering) */
+#define W3_READ_OFF(OFS) { _Pragma("unroll") for (int sl = 0; sl < NPL; ++sl) OFS[sl] = sOff[sl * NT + tid]; }
+#define W3_LOAD_P(ch, DEP, OFS) W3_LOAD_PR(ch, DEP, OFS, "v[172:175]", "v[176:179]", "v180")
+#define W3_LOAD_PR(ch, DEP, OFS, RA, RB, RH)                                                                    \
     {                                                                                                           \
         const int cb = min((ch) * CK, Cin - 1);                                                                 \
-        const unsigned lim = (unsigned)((Cin - cb) * HW - 1) * 4u;                                              \
+        const unsigned lim4 = (unsigned)((Cin - cb) * HW - 4) * 4u, lim1 = (unsigned)((Cin - cb) * HW - 1) * 4u; \
         const bool second = cb >= a.C0;                                                                         \
         const float* srcb = second ? a.x1 + ((long)b * a.C1 + (cb - a.C0)) * HW : a.x0 + ((long)b * a.C0 + cb) * HW; \
         const unsigned istride = (unsigned)((second ? a.C1 : a.C0) * HW) * 4u;      /* G8: distance to the region's second sample */ \
-        unsigned off[MAXP];                                                                                     \
-        _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl)                                                     \
-            off[sl] = min(OFS[sl], lim) + (G8 ? ((p_pk[sl] >> 20) & 1u) * istride : 0u);      /* channels past the last one are zeroed at the write: any address inside the source will do */ \
-        asm volatile("global_load_dword " R0 ", %0, %6\n\tglobal_load_dword " R1 ", %1, %6\n\tglobal_load_dword " R2 ", %2, %6\n\t" \
-                     "global_load_dword " R3 ", %3, %6\n\tglobal_load_dword " R4 ", %4, %6\n\tglobal_load_dword " R5 ", %5, %6"       \
-                     :: "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "s"(srcb),           \
-                        "v"(DEP[0]), "v"(DEP[1]), "v"(DEP[2]), "v"(DEP[3]), "v"(DEP[4]), "v"(DEP[5]) : "memory");           \
+        /* channels past the last one are zeroed at the write: any (aligned) address inside the source will do */ \
+        if constexpr (G8) {                                                                                     \
+            const unsigned o0 = min(OFS[0], lim4) + ((p_pk[0] >> 20) & 1u) * istride;                           \
+            asm volatile("global_load_dwordx4 " RA ", %0, %1" :: "v"(o0), "s"(srcb), "v"(DEP) : "memory");     \
+        } else {                                                                                                \
+            const unsigned o0 = min(OFS[0], lim4), o1 = min(OFS[NPL > 1 ? 1 : 0], lim4), o2 = min(OFS[NPL > 2 ? 2 : 0], lim1); \
+            asm volatile("global_load_dwordx4 " RA ", %0, %3\n\tglobal_load_dwordx4 " RB ", %1, %3\n\tglobal_load_dword " RH ", %2, %3" \
+                         :: "v"(o0), "v"(o1), "v"(o2), "s"(srcb), "v"(DEP) : "memory");                           \
+        }                                                                                                       \
     }
-    /* activate once per pixel (coefficients from the LDS table) and park the patch in LDS; zero padding applies AFTER     \
-       the activation */                                                                                           \
+    /* activate once per pixel (coefficients from the LDS table: one pair per slot, a slot is one channel) and park the patch in LDS;  \
+       zero padding applies AFTER the activation */                                                                \
 #define W3_READ_C(ch, cfv)                                                                                      \
     {                                                                                                           \
-        _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
+        _Pragma("unroll") for (int sl = 0; sl < NPL; ++sl) {                                                    \
             cfv[sl] = f32x2{1.0f, 0.0f};                                                                        \
             if (PRO >= 1) {                                                                                     \
                 const int cch = min((ch) * CK + (int)((p_pk[sl] >> 12) & (CK - 1)), Cin - 1) + (G8 ? (int)((p_pk[sl] >> 20) & 1u) * Cin : 0); \
@@ -226,21 +244,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
             }                                                                                                   \
         }                                                                                                       \
     }
-#define W3_WRITE_P(ch, PV, cfv) W3_WRITE_PR(ch, PV, cfv, "v178", "v179", "v180", "v181", "v182", "v183")
-#define W3_WRITE_PR(ch, PV, cfv, R0, R1, R2, R3, R4, R5)                                                        \
+#define W3_WRITE_P(ch, PV, cfv) W3_WRITE_PR(ch, PV, cfv, "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180")
+#define W3_WRITE_PR(ch, PV, cfv, A0, A1, A2, A3, B0, B1, B2, B3, H0)                                            \
     {                                                                                                           \
         float* sPw = sP + (((ch) & 1) ? PBUF : 0);                                                              \
         const int nvalid = Cin - (ch) * CK;                                                                     \
-        /* v = A * raw + B straight out of the patch registers (PRO 0: A = 1, B = 0, exact) */                  \
-        asm("v_fma_f32 %0, " R0 ", %6, %7\n\tv_fma_f32 %1, " R1 ", %8, %9\n\tv_fma_f32 %2, " R2 ", %10, %11\n\t"             \
-                     "v_fma_f32 %3, " R3 ", %12, %13\n\tv_fma_f32 %4, " R4 ", %14, %15\n\tv_fma_f32 %5, " R5 ", %16, %17"     \
-            : "=&v"(PV[0]), "=&v"(PV[1]), "=&v"(PV[2]), "=&v"(PV[3]), "=&v"(PV[4]), "=&v"(PV[5])                          \
-            : "v"(cfv[0].x), "v"(cfv[0].y), "v"(cfv[1].x), "v"(cfv[1].y), "v"(cfv[2].x), "v"(cfv[2].y),                   \
-              "v"(cfv[3].x), "v"(cfv[3].y), "v"(cfv[4].x), "v"(cfv[4].y), "v"(cfv[5].x), "v"(cfv[5].y), "s"(vtok));       \
-        _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) {                                                   \
-            float v = PV[sl];                                                                                   \
+        /* v = A * raw + B straight out of the patch registers (PRO 0: A = 1, B = 0, exact): the only reads of those registers */ \
+        if constexpr (G8) {                                                                                     \
+            asm("v_fma_f32 %0, " A0 ", %4, %5\n\tv_fma_f32 %1, " A1 ", %4, %5\n\tv_fma_f32 %2, " A2 ", %4, %5\n\tv_fma_f32 %3, " A3 ", %4, %5" \
+                : "=&v"(PV[0]), "=&v"(PV[1]), "=&v"(PV[2]), "=&v"(PV[3]) : "v"(cfv[0].x), "v"(cfv[0].y), "s"(vtok)); \
+        } else {                                                                                                \
+            asm("v_fma_f32 %0, " A0 ", %9, %10\n\tv_fma_f32 %1, " A1 ", %9, %10\n\tv_fma_f32 %2, " A2 ", %9, %10\n\tv_fma_f32 %3, " A3 ", %9, %10\n\t" \
+                "v_fma_f32 %4, " B0 ", %11, %12\n\tv_fma_f32 %5, " B1 ", %11, %12\n\tv_fma_f32 %6, " B2 ", %11, %12\n\tv_fma_f32 %7, " B3 ", %11, %12\n\t" \
+                "v_fma_f32 %8, " H0 ", %13, %14"                                                                  \
+                : "=&v"(PV[0]), "=&v"(PV[1]), "=&v"(PV[2]), "=&v"(PV[3]), "=&v"(PV[4]), "=&v"(PV[5]), "=&v"(PV[6]), "=&v"(PV[7]), "=&v"(PV[NPV > 8 ? 8 : 0]) \
+                : "v"(cfv[0].x), "v"(cfv[0].y), "v"(cfv[NPL > 1 ? 1 : 0].x), "v"(cfv[NPL > 1 ? 1 : 0].y), "v"(cfv[NPL > 2 ? 2 : 0].x), \
+                  "v"(cfv[NPL > 2 ? 2 : 0].y), "s"(vtok));                                                        \
+        }                                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < NPV; ++e) {                                                       \
+            const int sl = e >> 2;                            /* values 0-3: slot 0, 4-7: slot 1, 8: slot 2 */   \
+            float v = PV[e];                                                                                    \
             if (PRO >= 2) v = silu_w3(v);                                                                       \
-            sPw[p_pk[sl] & 0xfff] = ((int)((p_pk[sl] >> 12) & 0xff) < min(nvalid, CK)) ? v : 0.0f;              \
+            sPw[(p_pk[sl] & 0xfff) + 2 * (e & 3)] = ((int)((p_pk[sl] >> 12) & 0xff) < min(nvalid, CK)) ? v : 0.0f; \
         }                                                                                                       \
     }
     /* rows 2rg and 2rg+1 of B^T d for the two channels of the pair (packed fp32: .x = channel s_ca, .y = s_ca + 2), (.) B,      \
@@ -287,11 +312,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
        MFMAs ordered product-major (u1 v3, u3 v1, u2 v2, u1 v2, u2 v1, u1 v1: smallest first; consecutive MFMAs write different       \
        accumulators), then -- NEXT -- the same NQ quads are reloaded for chunk ch+1 (the matrix pipe has read its A operands by the     \
        time the wave gets past the MFMA: it issues in order).  In-order VMEM bookkeeping: when the quads of a position are needed, the \
-       loads issued after them are the other position's NQ quads and one patch group: vmcnt(NQ + MAXP), in both phase orders. */      \
+       loads issued after them are the other position's NQ quads and one patch group: vmcnt(NQ + NPL), in both phase orders. */      \
 #define W3_MFMA_PHASE(ch, NEXT)                                                                                 \
     {                                                                                                           \
         const unsigned* sVc = sV + (((ch) & 1) ? VW : 0);                                                       \
         u32x4 bq[2][3];                                                                                         \
+        W3_TS(7)                                                                                                \
         if (!(EXP & 8)) { W3_LOAD_B(0, bq[0]) W3_LOAD_B(1, bq[1]) }                                             \
         else { _Pragma("unroll") for (int p = 0; p < 3; ++p) { bq[0][p] = u32x4{1, 2, 3, 4}; bq[1][p] = u32x4{5, 6, 7, 8}; } } \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
@@ -304,6 +330,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
                     acc[i][ct][0] += __builtin_bit_cast(float, bq[i][0][0] ^ bq[i][1][1] ^ bq[i][2][2] ^ bq[i][1][3]); \
             }                                                                                                   \
             if (NEXT && !(EXP & 4)) W3_LOAD_A((ch) + 1, i)                                                      \
+            W3_TS(4 + i)                                                                                        \
         }                                                                                                       \
     }
     /* patch of chunk ch+2 -> LDS, raw patch of chunk ch+3 requested, V(ch+1) -> LDS.  Two LDS round trips (coefficients + load offsets,   \
@@ -312,20 +339,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
 #define W3_VALU_PHASE(ch, RG)                                                                                   \
     {                                                                                                           \
         {                                                                                                       \
-            f32x2 cfv[MAXP];                                                                                    \
-            unsigned ofs[MAXP];                                                                                 \
+            f32x2 cfv[NPL];                                                                                     \
+            unsigned ofs[NPL];                                                                                  \
+            W3_TS(7)                                                                                            \
             if (!(EXP & 2)) W3_READ_C((ch) + 2, cfv)                                                            \
             if (!(EXP & 4)) W3_READ_OFF(ofs)                                                                    \
             if (!(EXP & 4)) W3_WAIT(NA)                                                                         \
-            float pv[MAXP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                    \
+            W3_TS(0)                                                                                            \
+            float pv[NPV];                                                                                      \
+            _Pragma("unroll") for (int e = 0; e < NPV; ++e) pv[e] = 0.0f;                                       \
             if (!(EXP & 2)) W3_WRITE_P((ch) + 2, pv, cfv)                                                       \
-            if (!(EXP & 4)) W3_LOAD_P((ch) + 3, pv, ofs)                                                        \
+            W3_TS(1)                                                                                            \
+            if (!(EXP & 4)) W3_LOAD_P((ch) + 3, pv[0], ofs)                                                     \
+            W3_TS(2)                                                                                            \
         }                                                                                                       \
         if (!(EXP & 1)) {                                                                                       \
             f32x2 rw[3][4];                                                                                     \
             W3_READ_R((ch) + 1, rw)                                                                             \
             W3_WRITE_V((ch) + 1, RG, rw)                                                                        \
         }                                                                                                       \
+        W3_TS(3)                                                                                                \
     }
 
     f32x16 acc[2][COT];
@@ -337,7 +370,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
             for (int r = 0; r < 16; ++r) acc[i][ct][r] = 0.0f;
 
     // diagnostics (mcvd_ctx_set_debug_buffer): shader-clock time the wave a.wdma spends per phase
-    const bool rec = a.dbg != nullptr && wave == (a.wdma & 63);
+    const bool rec = a.dbg != nullptr && wave == (a.wdma & 7);
     const bool sub = (a.wdma & 64) != 0;           // record prologue / epilogue sub-phase stamps instead of the wall clock
     unsigned long long sp[3] = {0, 0, 0};
     unsigned long long tk0 = 0, tprev = 0, dt[2] = {0, 0}, rt0 = 0;
@@ -351,19 +384,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
         dt[i] += now - tprev;                                                                                   \
         tprev = now;                                                                                            \
     }
+#ifdef MCVD_DIAG
+    /* diagnostics build, MCVD_DBG_WAVE >= 128: cycles the recording wave spends per sub-phase of the K loop (slot 7 = discarded: the
+       time up to the phase start; 0 C/OFF reads + patch wait, 1 activation + park, 2 patch-load issue, 3 transform + split + stores,
+       4 / 5 B reads + weight wait + MFMAs + reload of position 0 / 1, 6 barrier) */
+    const bool tsub = rec && (a.wdma & 128) != 0;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tsp = 0;
+#define W3_TS(i)                                                                                                \
+    if (tsub) {                                                                                                 \
+        const unsigned long long now = __builtin_amdgcn_s_memtime();                                            \
+        ts[i] += now - tsp;                                                                                     \
+        tsp = now;                                                                                              \
+    }
+#else
+#define W3_TS(i)
+#endif
 
     // ---- chunk range of this workgroup (a.ksplit == 2: blockIdx.y picks one half of the input channels)
     const int nch_all = a.CinP / CK;
     const int ksp = a.ksplit == 2 ? 2 : 1, kh = ksp == 2 ? (int)blockIdx.y : 0;
     const int c_begin = kh * (nch_all / ksp), c_end = c_begin + nch_all / ksp;
 
-    // ---- prologue.  Issue order = need order: the raw patches of the first two chunks (into the registers of weight quads 0-2, which
-    // are not needed before the first MFMA phase), the patch of the third chunk, then the weight quads 3.. of the first chunk.  The
-    // first two patches are activated and parked as soon as THEY have landed (the weights, most of the bytes, are still in flight);
-    // quads 0-2 follow once their registers have been read.
+    // ---- prologue.  Issue order = need order: the raw patches of the first two chunks (into the registers of weight quads 0 .. PQ-1,
+    // which are not needed before the first MFMA phase), the patch of the third chunk, then the weight quads PQ.. of the first chunk.
+    // The first two patches are activated and parked as soon as THEY have landed (the weights, most of the bytes, are still in flight);
+    // quads 0 .. PQ-1 follow once their registers have been read.
     int vtok = 0;                                       // ordering token: written by every VMEM wait, an operand of the register reads
     {
-        float nodep[MAXP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float nodep = 0.0f;
         if (PRO) {                         // (the compiler waits for the coefficient loads here: nothing else is in flight yet)
 #pragma unroll
             for (int k = 0; k < 2; ++k)
@@ -375,27 +423,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
         if (G8)                            // the halo of both patch buffers is zero padding for the whole kernel
             for (int i = tid; i < 2 * PBUF; i += NT) sP[i] = 0.0f;
         {
-            unsigned ofs[MAXP];
+            unsigned ofs[NPL];
             W3_READ_OFF(ofs)
-            W3_LOAD_PR(c_begin, nodep, ofs, "v184", "v185", "v186", "v187", "v188", "v189")
-            W3_LOAD_PR(c_begin + 1, nodep, ofs, "v190", "v191", "v192", "v193", "v194", "v195")
+            // the first two patches land in the registers of weight quads 0 .. PQ-1 (v184-v203)
+            W3_LOAD_PR(c_begin, nodep, ofs, "v[184:187]", "v[188:191]", "v192")
+            W3_LOAD_PR(c_begin + 1, nodep, ofs, "v[194:197]", "v[198:201]", "v202")
             W3_LOAD_P(c_begin + 2, nodep, ofs)
         }
-        W3_LOAD_A_RANGE(c_begin, 3, NA, nodep)
+        W3_LOAD_A_RANGE(c_begin, PQ, NA, nodep)
         if (PRO || G8) __syncthreads();    // coefficient table (and the zeroed halo) visible
         if (rec) sp[0] = __builtin_amdgcn_s_memtime() - tk0;      // loads issued
-        W3_WAIT(MAXP + NA - 3)             // the two patches have landed; younger: patch(c_begin + 2), quads 3..
+        W3_WAIT(NPL + NA - PQ)             // the two patches have landed; younger: patch(c_begin + 2), quads PQ..
         if (rec) sp[1] = __builtin_amdgcn_s_memtime() - tk0;      // first patches landed
         {
-            float pv0[MAXP], pv1[MAXP];
-            f32x2 cf0[MAXP], cf1[MAXP];
+            float pv0[NPV], pv1[NPV];
+            f32x2 cf0[NPL], cf1[NPL];
             W3_READ_C(c_begin, cf0)
             W3_READ_C(c_begin + 1, cf1)
-            W3_WRITE_PR(c_begin, pv0, cf0, "v184", "v185", "v186", "v187", "v188", "v189")
-            W3_WRITE_PR(c_begin + 1, pv1, cf1, "v190", "v191", "v192", "v193", "v194", "v195")
-            float dep[MAXP];
-            _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) dep[sl] = pv0[sl] + pv1[sl];
-            W3_LOAD_A_RANGE(c_begin, 0, 3, dep)
+            W3_WRITE_PR(c_begin, pv0, cf0, "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192")
+            W3_WRITE_PR(c_begin + 1, pv1, cf1, "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202")
+            const float dep = pv0[0] + pv1[0];
+            W3_LOAD_A_RANGE(c_begin, 0, PQ, dep)
         }
     }
     __syncthreads();                       // the first two patches visible
@@ -409,12 +457,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
     W3_STAMP(0)
 
     // ---- K loop.  VMEM issue order of a wave per chunk c (in-order vmcnt counter; nothing else is outstanding):
-    //   waves 0-3:  [patch(c+3): MAXP loads] [weights(c+1): NQ loads behind the MFMAs of each position]      waves 4-7:  weights, then patch
+    //   waves 0-3:  [patch(c+3): NPL loads] [weights(c+1): NQ loads behind the MFMAs of each position]      waves 4-7:  weights, then patch
     // wait points (the same counts in both orders):
     //   patch(c+2) before its write: one chunk's weight loads were issued after it                              vmcnt(NA)
     //   weights(c) of a position before its MFMAs: see W3_MFMA_PHASE                                            vmcnt(VM_A)
     // (the loads still in flight when a loop is left target registers the compiler does not know: one wait behind the loops)
-    W3_WAIT(0)                             // weight quads 0-2 were issued last: the loop's in-order counts start from an empty queue
+    W3_WAIT(0)                             // weight quads 0 .. PQ-1 were issued last: the loop's in-order counts start from an empty queue
     const int ph = rg;                     // phase order of the wave
     if (ph == 0) {
         for (int c = c_begin; c + 1 < c_end; ++c) {
@@ -422,12 +470,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
             W3_MFMA_PHASE(c, true)
             // chunk c read by every wave; V(c+1), patch(c+2) visible.  LDS traffic only: no VMEM wait at the barrier.
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            W3_TS(6)
         }
     } else {
         for (int c = c_begin; c + 1 < c_end; ++c) {
             W3_MFMA_PHASE(c, true)
             W3_VALU_PHASE(c, rg)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            W3_TS(6)
         }
     }
     W3_WAIT(0)
@@ -540,12 +590,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
             d[0] = dt[0]; d[1] = dt[1]; d[2] = rt0; d[3] = __builtin_amdgcn_s_memrealtime();
             d[4] = ((unsigned long long)xcc << 32) | hwid;          // which CU ran it (gpu_diag.py w2htl: per-CU timeline)
             if (sub) { d[2] = sp[0]; d[3] = sp[1]; d[4] = sp[2]; }   // MCVD_DBG_WAVE >= 64: prologue sub-phases (cycles from the start)
+#ifdef MCVD_DIAG
+            if (tsub) { d[0] = ts[0]; d[1] = ts[1]; d[2] = ts[2]; d[3] = ts[3]; d[4] = ts[4]; d[5] = ts[5]; d[7] = ts[6]; }
+#endif
             d[5] = now - tprev;            // epilogue
             d[6] = (unsigned long long)(c_end - c_begin);
             d[7] = now - tk0;
         }
     }
 #undef W3_STAMP
+#undef W3_TS
 #undef W3_LOAD_A
 #undef W3_QUADS
 #undef W3_LD1
@@ -568,7 +622,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(178))) void con
 }
 
 static size_t wino3_lds_bytes(int Cin, bool g8) {
-    return (size_t)(2 * W3_VW + 2 * (W3_CK * 10 * W3_PP + 4) + (g8 ? 4 : 2) * Cin + 6 * W3_NT) * sizeof(float);
+    return (size_t)(2 * W3_VW + 2 * (W3_CK * 10 * W3_PP + 8) + (g8 ? 4 : 2) * Cin + (g8 ? 1 : 3) * W3_NT) * sizeof(float);
 }
 
 // the K-split second pass lives in conv_wino.cpp

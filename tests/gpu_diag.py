@@ -343,7 +343,8 @@ def w3exp(f):
     envname = "MCVD_WINO3_EXP" if kshape == 10 else "MCVD_WINO2H_EXP"
     # (the ablations exist in a -DMCVD_DIAG build only: python mcvd_pytorch_amd/csrc/build.py --diag; the production library ignores the env)
     labels = {0: "baseline", 1: "no transform (WRITE_V)", 2: "no patch activation/park (WRITE_P)", 3: "neither", 4: "no VMEM in the loop",
-              16: "everything but the MFMAs", 15: "MFMA only", 27: "VMEM only", 11: "VMEM + MFMA only"}
+              16: "everything but the MFMAs", 15: "MFMA only", 27: "VMEM only", 11: "VMEM + MFMA only",
+              128: "two-phase loop (first form)", 132: "two-phase loop, no VMEM"}
     cases = [(96, 96, 64), (192, 192, 32), (480, 192, 32), (576, 288, 16)]
     if os.environ.get("MCVD_WEXP_CASES", "all") != "all":
         cases = [cases[int(v)] for v in os.environ["MCVD_WEXP_CASES"].split(",")]
@@ -395,6 +396,37 @@ def w3exp(f):
                     f" | wave7 pro {per[1][0]:6.0f} loop/chunk {per[1][1]:6.0f} epi {per[1][2]:6.0f} total {per[1][3]:7.0f}\n")
             f.flush()
     os.environ[envname] = "0"
+    ctx.opt("conv_shape", -1)
+
+
+def w3sub(f):
+    """conv_wino3.cpp (diagnostics library): cycles per chunk the recording wave spends in each sub-phase of the K loop
+    (MCVD_DBG_WAVE = 128 + wave)."""
+    from tests.hiputil import Ctx, P
+    ctx = Ctx()
+    B = 64
+    names = ["C/OFF reads + patch wait", "activation + park", "patch-load issue", "transform + split + stores", "pos 0: B reads + weight wait + MFMAs + reload",
+             "pos 1: same", "barrier"]
+    for cin, cout, H in [(96, 96, 64), (480, 192, 32)]:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda")
+        ctx.opt("conv_shape", 10)
+        for wv in (0, 3, 4, 7):
+            os.environ["MCVD_DBG_WAVE"] = str(128 + wv)
+            dbg = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+            _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
+            d = dbg.view(-1, 8).cpu().double()
+            d = d[d[:, 6] > 0]
+            n = (d[:, 6] - 1).clamp(min=1)                # chunks the loop ran
+            vals = [(d[:, i] / n).mean().item() for i in (0, 1, 2, 3, 4, 5, 7)]
+            f.write(f"cin{cin} cout{cout} H{H} wave {wv}: " + " | ".join(f"{nm} {v:6.0f}" for nm, v in zip(names, vals)) + f" | sum {sum(vals):6.0f}\n")
+    os.environ["MCVD_DBG_WAVE"] = "0"
     ctx.opt("conv_shape", -1)
 
 
@@ -530,6 +562,6 @@ if __name__ == "__main__":
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "convops": convops, "sweep1": sweep1, "w2htl": w2htl, "w2hsub": w2hsub}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "w3sub": w3sub, "convops": convops, "sweep1": sweep1, "w2htl": w2htl, "w2hsub": w2hsub}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 

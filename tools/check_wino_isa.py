@@ -124,27 +124,30 @@ def _dest_untouched_covering(name, loop, problems):
             problems.append(f"{name}: no wait covers `{l}`")
 
 
-def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_per_cot=6):
+def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_per_cot=6, nloops=2, npatch=(3, 1), wreg0=184):
     """conv_wino3_kernel<COT, PRO, G8, 0> / conv_wino2h_kernel<COT, PRO, G8, 0>: every loop that holds MFMAs is a K loop; a K loop
-    holds wl_per_cot * COT weight loads (NP pieces x 2 positions) + 6 patch loads."""
+    holds wl_per_cot * COT weight loads (NP pieces x 2 positions; destinations from register `wreg0` up) + npatch[G8] patch loads
+    (destinations below `wreg0`)."""
     problems, seen = [], 0
-    for m in re.finditer(r"^(_ZN4mcvd" + kernel + r"ILi(\d)ELi(\d)E(?:Lb[01]E)?Li0EEEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
-        name, cot, body = m.group(1), int(m.group(2)), m.group(4)
+    for m in re.finditer(r"^(_ZN4mcvd" + kernel + r"ILi(\d)ELi(\d)E(?:Lb([01])E)?Li0EEEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
+        name, cot, g8, body = m.group(1), int(m.group(2)), int(m.group(4) or 0), m.group(5)
         seen += 1
         lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
         kloops = 0
-        i = 0
-        while i < len(lines):
-            hm = re.match(r"^\.LBB(\d+)_(\d+):.*Loop Header", lines[i])
-            if not hm:
-                i += 1
-                continue
+        # loops: a header label ("Loop Header") plus every block the compiler marks "in Loop: Header=<that label>"; the compiler may lay
+        # rotated blocks out BEFORE the header, so the loop is the contiguous label range that covers all of them (the in-order wait
+        # analysis below walks the lines cyclically: where the cycle is entered does not matter)
+        headers = [(k, re.match(r"^\.LBB(\d+)_(\d+):", l)) for k, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:.*Loop Header", l)]
+        label_idx = [k for k, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l) or re.match(r"^; %bb\.", l)]
+        spans = []
+        for k, hm in headers:
             tag = f"Header=BB{hm.group(1)}_{hm.group(2)} "
-            j = i + 1
-            while j < len(lines) and not (re.match(r"^\.LBB", lines[j]) and tag not in lines[j] + " "):
-                j += 1
-            loop = [l for l in lines[i:j] if not re.match(r"^\.LBB", l)]
-            i0, i = i, j
+            members = [k] + [q for q, l in enumerate(lines) if (re.match(r"^\.LBB", l) or l.startswith("; %bb.")) and tag in l + " "]
+            lo, hi_start = min(members), max(members)
+            nxt = [q for q in label_idx if q > hi_start]
+            spans.append((lo, nxt[0] if nxt else len(lines)))
+        for i0, j in spans:
+            loop = [l for l in lines[i0:j] if not re.match(r"^\.LBB", l) and not l.startswith("; %bb.")]
             if not any(l.startswith("v_mfma") for l in loop):
                 continue
             kloops += 1
@@ -153,10 +156,11 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_
                 problems.append(f"{name}: spill code inside a K loop")
             if any(re.match(r"^s_waitcnt.*vmcnt\(0\)", l) for l in loop):
                 problems.append(f"{name}: a vmcnt(0) wait inside a K loop (the loop's loads are meant to stay in flight)")
-            wl = [l for l in vmem if re.match(r"^global_load_dwordx4 v", l)]
-            pl = [l for l in vmem if re.match(r"^global_load_dword v", l)]
-            if len(wl) != wl_per_cot * cot or len(pl) != 6 or len(wl) + len(pl) != len(vmem):
-                problems.append(f"{name}: expected {wl_per_cot * cot} weight + 6 patch loads and no other VMEM in a K loop, found {len(wl)} + {len(pl)} of {len(vmem)}")
+            ld = [l for l in vmem if re.match(r"^global_load_dword(x4)? v", l)]
+            wl = [l for l in ld if min(_regs(l.split(",")[0])) >= wreg0]
+            pl = [l for l in ld if min(_regs(l.split(",")[0])) < wreg0]
+            if len(wl) != wl_per_cot * cot or len(pl) != npatch[g8] or len(wl) + len(pl) != len(vmem):
+                problems.append(f"{name}: expected {wl_per_cot * cot} weight + {npatch[g8]} patch loads and no other VMEM in a K loop, found {len(wl)} + {len(pl)} of {len(vmem)}")
             _dest_untouched_covering(name, loop, problems)
             if asm_mfma:      # accumulators: written and read by MFMAs only
                 acc = set()
@@ -202,15 +206,15 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_
                 if len(ops) > 1 and not t.startswith("s_waitcnt") and _regs(ops[1]) & dests:
                     problems.append(f"{name}: `{t}` touches a K-loop load destination after the loop, before vmcnt(0)")
                     break
-        if kloops != 2:
-            problems.append(f"{name}: expected 2 K loops (one per phase order), found {kloops}")
+        if kloops != nloops:
+            problems.append(f"{name}: expected {nloops} K loop(s), found {kloops}")
     if seen != expect:
         problems.append(f"expected {expect} instantiations of {kernel}<COT, PRO, ..., 0>, found {seen}")
     return problems
 
 
 def check2h(asm_text):
-    return check3(asm_text, kernel="18conv_wino2h_kernel", asm_mfma=True, expect=18, wl_per_cot=4)      # x {8x16 regions, 8x8 images}
+    return check3(asm_text, kernel="18conv_wino2h_kernel", asm_mfma=True, expect=18, wl_per_cot=4, nloops=2, npatch=(6, 6), wreg0=208)      # x {8x16 regions, 8x8 images}; one loop per phase order
 
 
 def main():
