@@ -127,61 +127,100 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, rt0 = 0;
     if (rec) { rt0 = __builtin_amdgcn_s_memrealtime(); tk0 = __builtin_amdgcn_s_memtime(); }
 
-    // K loop: NB = 4 LDS buffers, the DMA of chunk ch + 3 is issued while chunk ch is computed (prefetch distance 3 chunks).  Every
-    // wave issues exactly G DMA instructions per chunk, in order, and nothing else: chunk ch has landed when at most the groups issued
-    // after it (chunks ch+1, ch+2) are outstanding.  The barrier behind the wait makes every wave's part visible and certifies that
-    // every wave is done with chunk ch - 1, whose buffer the next DMA overwrites.
+    // K loop: NB = 4 LDS buffers, the DMA of chunk k + 3 is issued while chunk k is staged (prefetch distance 3 chunks).  Every wave
+    // issues exactly G DMA instructions per chunk, in order, and nothing else: chunk k has landed when at most the groups issued after
+    // it (chunks k+1, k+2) are outstanding.  The barrier behind the wait makes every wave's part visible and certifies that every wave
+    // has READ chunk k - 1 (its LDS reads were waited for: lgkmcnt(0)), whose buffer the next DMA overwrites.
+    // The loop is software-pipelined in registers: while the MFMAs of chunk k run (B pieces split one iteration earlier), chunk k + 1 is
+    // staged -- its pixel / coefficient reads are issued first, its affine / SiLU / split (the other B register set) is independent of
+    // the MFMAs and the compiler interleaves the two.  Round 2's loop did LDS reads -> VALU -> MFMAs of ONE chunk in sequence between
+    // two barriers: 2.3 k cycles per chunk with 0.58 k of matrix work per wave (profiles/r03_timeline_wino3_conv1x1_b3.txt).
     const int nchunks = Cin / CK;          // Cin % CK == 0 (launch check): the zero rows that pad the weights are never staged
     Q1_DMA(0);
     if (nchunks > 1) Q1_DMA(1);
     if (nchunks > 2) Q1_DMA(2);
     if (rec) tk1 = __builtin_amdgcn_s_memtime();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int after = nchunks - 1 - ch;
-        if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * G) : "memory");
-        else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (ch + 3 < nchunks) Q1_DMA(ch + 3);
-        const u32x4* sWc = reinterpret_cast<const u32x4*>(sW + (ch & (NB - 1)) * WDW) + lane;
-        const float* sXc = sX + (ch & (NB - 1)) * XSZ + wave * 32 + l31;
-        const float* sCb = sC + ((long)my_img * Cin + ch * CK) * 2;
-        // every LDS read of the chunk first (one round trip): 8 pixel values, their coefficients, the NP * COT A operands
+    /* chunk k becomes visible, chunk k + 3 is requested, the LDS reads of chunk k are issued: 8 pixel values, their coefficients, the
+       NP * COT A operands */
+#define Q1_STAGE(k, BV, CF)                                                                                     \
+    {                                                                                                           \
+        const int after = nchunks - 1 - (k);                                                                    \
+        if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * G) : "memory");                           \
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G) : "memory");                          \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
+        if ((k) + 3 < nchunks) Q1_DMA((k) + 3);                                                                 \
+        const float* sXc = sX + ((k) & (NB - 1)) * XSZ + wave * 32 + l31;                                       \
+        const float* sCb = sC + ((long)my_img * Cin + (k) * CK) * 2;                                            \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {         /* element e of lane (n, h) = channel 2e + h of the chunk */ \
+            BV[e] = sXc[(2 * e + half) * PT];                                                                   \
+            if (PRO != 0) CF[e] = *reinterpret_cast<const f32x2*>(sCb + (2 * e + half) * 2);                    \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    }
+    /* the NP * COT A operands of chunk k (visible since its Q1_STAGE): ONE register set -- read behind the MFMAs of the previous chunk,
+       the latency passes under the split of this one (two sets cost 36 registers more than the kernel has at COT = 3) */
+#define Q1_READ_AW(k, AW)                                                                                       \
+    {                                                                                                           \
+        const u32x4* sWc = reinterpret_cast<const u32x4*>(sW + ((k) & (NB - 1)) * WDW) + lane;                  \
+        _Pragma("unroll") for (int ct = 0; ct < COT; ++ct)                                                      \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) AW[ct][p] = sWc[(ct * NP + p) * 64];                 \
+    }
+    /* GroupNorm affine (+ SiLU), split into pieces: the B operand of the chunk */
+#define Q1_PREP(BV, CF, BP)                                                                                     \
+    {                                                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                         \
+            if (PRO != 0) {                                                                                     \
+                BV[e] = BV[e] * CF[e].x + CF[e].y;                                                              \
+                if (PRO == 2) BV[e] = silu_q(BV[e]);                                                            \
+            }                                                                                                   \
+            if (NP == 2) BV[e] *= PX::ACT_SCALE;                                                                \
+        }                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            unsigned w[NP];                                                                                     \
+            PX::template split<false>(BV[2 * j], BV[2 * j + 1], w);                                             \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) BP[p][j] = w[p];                                     \
+        }                                                                                                       \
+    }
+    /* product-major MFMA order, smallest product first: consecutive MFMAs write different accumulators */
+#define Q1_MMA(AW, BP)                                                                                          \
+    {                                                                                                           \
+        _Pragma("unroll") for (int k = 0; k < PX::NPROD; ++k)                                                   \
+            _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) acc[ct] = PX::mfma(AW[ct][PX::PA(k)], BP[PX::PB(k)], acc[ct]); \
+    }
+    /* one pipeline step (k + 1 < nchunks): chunk k + 1 staged, then -- ONE basic block, no fences, so that the scheduler interleaves them
+       -- the MFMAs of chunk k (pieces BPC) with the split of chunk k + 1 (-> BPN), then the A operands of chunk k + 1 */
+#define Q1_STEP(k, BPC, BPN)                                                                                    \
+    {                                                                                                           \
+        Q1_STAGE((k) + 1, bv, cf)                                                                               \
+        Q1_MMA(aw, BPC)                                                                                         \
+        Q1_PREP(bv, cf, BPN)                                                                                    \
+        Q1_READ_AW((k) + 1, aw)                                                                                 \
+    }
+    {
         float bv[8];
         f32x2 cf[8];
-        u32x4 aw[COT][NP];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {         // element e of lane (n, h) = channel 2e + h of the chunk
-            bv[e] = sXc[(2 * e + half) * PT];
-            if (PRO != 0) cf[e] = *reinterpret_cast<const f32x2*>(sCb + (2 * e + half) * 2);
+        u32x4 aw[COT][NP], bpA[NP], bpB[NP];
+        Q1_STAGE(0, bv, cf)
+        Q1_READ_AW(0, aw)
+        Q1_PREP(bv, cf, bpA)
+        int ch = 0;                        // invariant at the top: aw and bpA belong to chunk ch
+        for (; ch + 2 < nchunks; ch += 2) {
+            Q1_STEP(ch, bpA, bpB)
+            Q1_STEP(ch + 1, bpB, bpA)
         }
-#pragma unroll
-        for (int ct = 0; ct < COT; ++ct)
-#pragma unroll
-            for (int p = 0; p < NP; ++p) aw[ct][p] = sWc[(ct * NP + p) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (PRO != 0) {
-                bv[e] = bv[e] * cf[e].x + cf[e].y;
-                if (PRO == 2) bv[e] = silu_q(bv[e]);
-            }
-            if (NP == 2) bv[e] *= PX::ACT_SCALE;
+        if (ch + 1 < nchunks) {
+            Q1_STEP(ch, bpA, bpB)
+            Q1_MMA(aw, bpB)
+        } else {
+            Q1_MMA(aw, bpA)
         }
-        u32x4 bp[NP];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned w[NP];
-            PX::template split<false>(bv[2 * j], bv[2 * j + 1], w);
-#pragma unroll
-            for (int p = 0; p < NP; ++p) bp[p][j] = w[p];
-        }
-        // product-major MFMA order, smallest product first: consecutive MFMAs write different accumulators
-#pragma unroll
-        for (int k = 0; k < PX::NPROD; ++k)
-#pragma unroll
-            for (int ct = 0; ct < COT; ++ct) acc[ct] = PX::mfma(aw[ct][PX::PA(k)], bp[PX::PB(k)], acc[ct]);
     }
+#undef Q1_STEP
+#undef Q1_STAGE
+#undef Q1_READ_AW
+#undef Q1_PREP
+#undef Q1_MMA
 #undef Q1_DMA
     if (rec) tk2 = __builtin_amdgcn_s_memtime();
 

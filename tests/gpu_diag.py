@@ -430,6 +430,39 @@ def w3sub(f):
     ctx.opt("conv_shape", -1)
 
 
+def hostloop(f):
+    """What `verbose=True` / `log=True` cost: those kwargs (the reference's video_gen passes them, runners/ncsn_runner.py:1516-1519) take
+    the host loop of samplers.py (one forward + one fused update per step driven from Python, the ten log lines computed with torch)
+    instead of the device loop mcvd_sampler_run.  Headline workload (config 2, B = 64, 100 steps + denoise), 2 calls each after a warm-up."""
+    import io
+    import logging
+    from contextlib import redirect_stdout
+    config, sd, net = mk("smmnist_big5_ngf96")
+    B = 64
+    x, cond = synthetic.random_inputs(config, 0, B)
+    x, cond = x.cuda(), cond.cuda()
+    net.set_option("graph", 1)
+    logging.getLogger().setLevel(logging.ERROR)
+
+    def run(verbose, log, final_only=True):
+        with redirect_stdout(io.StringIO()):
+            return ddpm_sampler(x, net, cond=cond, final_only=final_only, denoise=True, subsample_steps=100, clip_before=True,
+                                verbose=verbose, log=log, seed=7)
+    res = {}
+    for name, kw in (("device loop (verbose=False, log=False)", dict(verbose=False, log=False)),
+                     ("host loop (verbose=True, log=True)", dict(verbose=True, log=True))):
+        run(**kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            run(**kw)
+        torch.cuda.synchronize()
+        res[name] = (time.perf_counter() - t0) / 2
+        f.write(f"{name}: {res[name] * 1e3:.1f} ms per sampler call, {B * 5 / res[name]:.1f} frames/s\n")
+    a, b = list(res.values())
+    f.write(f"host-loop overhead: {(b - a) * 1e3:.1f} ms per call = {(b - a) / 101 * 1e3:.3f} ms per step ({100 * (b - a) / a:.2f} %)\n")
+
+
 def w2htl(f):
     """Per-CU timeline of conv_wino2h_kernel launches: every workgroup records its start / end on the 100 MHz wall clock, its
     shader-cycle count and the CU it ran on.  Answers: what is the shader clock under this kernel, and how long does a CU sit
@@ -438,6 +471,8 @@ def w2htl(f):
     ctx = Ctx()
     B = 64
     cases = [(96, 96, 64, 3, 12, 0), (480, 192, 32, 3, 12, 0), (192, 576, 32, 1, 14, 2), (192, 576, 32, 1, 14, 3), (288, 96, 64, 1, 14, 3), (384, 1152, 8, 1, 14, 3)]
+    if os.environ.get("MCVD_TL_B3", "1") != "0":          # the three-piece bf16 kernels (default) instead of the two-piece fp16 ones
+        cases = [(a, b_, c, d, {12: 10, 14: 15}[e], g) for a, b_, c, d, e, g in cases]
     if os.environ.get("MCVD_TL_CASES"):
         cases = [cases[int(v)] for v in os.environ["MCVD_TL_CASES"].split(",")]
     for cin, cout, H, ks, shp, cot in cases:
@@ -562,6 +597,6 @@ if __name__ == "__main__":
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "w3sub": w3sub, "convops": convops, "sweep1": sweep1, "w2htl": w2htl, "w2hsub": w2hsub}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "w3sub": w3sub, "hostloop": hostloop, "convops": convops, "sweep1": sweep1, "w2htl": w2htl, "w2hsub": w2hsub}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 

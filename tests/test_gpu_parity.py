@@ -1078,6 +1078,72 @@ def test_full_width_sampler_vs_reference_golden(golden_dir, fx, path):
     assert err <= 1e-4, f"{fx} [{path}]: final frames max-abs err {err:.3e}"
 
 
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
+def test_bench_kernel_table_vs_reference_golden(golden_dir, arith):
+    """The kernel table bench.py pins for the headline workload (profiles/tune_smmnist_big5_ngf96_B64_<arith>.json: tuned at B = 64 on
+    an MI355X, committed, loaded by bench.py by default) installed at B = 2 through mcvd_model_set_tuning: EVERY conv op must run the
+    kernel the table names (mcvd_model_op_kernel; VERDICT r2: the bench's table had never been compared with a reference fixture), the
+    forward must reproduce the reference's epsilon and every module tap of the oracle, and the full 100-step ddpm_sampler + denoise the
+    reference's final frames -- at the unchanged tolerances."""
+    import ctypes as C
+    import json
+    from mcvd_pytorch_amd import _lib
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    from tests.hiputil import module_output
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(golden_dir))), "profiles", f"tune_smmnist_big5_ngf96_B64_{arith}.json")
+    table = json.load(open(path))["64"]
+    g = torch.load(os.path.join(golden_dir, "smmnist_big5_ngf96_b2.pt"), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    B = g["batch"]
+    net.set_option("f16x2", 1 if arith == "f16x2" else 0)
+    net.set_tuning(B, table)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = g["fwd_t"]
+    eps = net(x.cuda(), t.cuda(), cond=cond.cuda())
+    torch.cuda.synchronize()
+    n = _lib.lib.mcvd_model_profile_read(net._model, None, None, None, None, None, 0)
+    assert n == len(table)
+    info = (C.c_int * 8)()
+    n1 = n3 = 0
+    for i in range(n):
+        _lib.check(_lib.lib.mcvd_model_op_info(net._model, i, info), "op_info")
+        if info[0] != 3:
+            continue
+        ran, want = _lib.lib.mcvd_model_op_kernel(net._model, i), table[i][0]
+        assert ran == want, f"op {i} ({info[2]}x{info[2]} {info[4]}->{info[5]} @{info[3]}): ran kernel {ran}, the bench table names {want}"
+        n1 += info[2] == 1
+        n3 += info[2] == 3
+    assert n1 == 41 and n3 == 58
+    on15 = sum(1 for i in range(n) if table[i][0] == 15)
+    if arith == "bf16x3":
+        assert on15 == 41, f"{on15} of 41 1x1 convs on the three-piece bf16 GEMM"
+    taps = {}
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t, cond, taps=taps)
+    bad = []
+    for i in sorted(taps):
+        if i == 0 or i == len(taps) - 1:
+            continue
+        want = unet_ref.silu(taps[1]) if i == 1 else taps[i]
+        try:
+            got = module_output(net, i, B)
+        except RuntimeError:
+            continue
+        sc = max(want.abs().max().item(), 1e-6)
+        err = (got.cpu() - want).abs().max().item()
+        if err > 2e-5 + 1e-4 * sc:
+            bad.append((i, err, sc))
+    assert not bad, f"modules off (index, max-abs err, scale): {bad[:8]}"
+    assert (eps.cpu() - g["fwd_eps"]).abs().max().item() <= 1e-4 * g["fwd_eps"].abs().max().item()
+    noise = synth.make_noise(config, B, 101, seed=2)
+    out = ddpm_sampler(x.cuda(), net, cond=cond.cuda(), denoise=True, subsample_steps=100, clip_before=True, verbose=False, log=False,
+                       noise=noise.cuda(), final_only=True)[-1:].cpu()
+    ref_out = g["sampler_ddpm_100"]["result"]
+    assert out.shape == ref_out.shape
+    err = (out - ref_out).abs().max().item()
+    assert err <= 1e-4, f"100-step sampler under the bench table [{arith}]: final frames max-abs err {err:.3e}"
+
+
 def test_video_gen_config5_vs_reference_golden(golden_dir):
     """BASELINE config 5 (cityscapes 128x128, nc=2 < nf=5): `runner.video_gen` -- two autoregressive blocks, cond shift of
     runners/ncsn_runner.py:1537-1539, crop to 8 frames (:1569) -- vs the same loop driven by the REAL reference sampler
@@ -1458,3 +1524,39 @@ def test_direct_rccl_weight_broadcast_single_rank():
         assert _lib.lib.mcvd_model_broadcast_params(net._model, None, 0) != 0          # NULL communicator: an error code, not a crash
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+def test_direct_rccl_weight_broadcast_two_ranks(tmp_path):
+    """mcvd_model_broadcast_params on a TWO-rank RCCL communicator (ncclGetUniqueId / ncclCommInitRank, one process per GPU, no torch
+    distributed): rank 1 starts from different weights and must produce rank 0's epsilon bit for bit after the broadcast.  Needs two
+    GPUs: skipped on a one-GPU box (VERDICT r2 task 10: readiness for the 8-GPU node)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_bcast_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(tmp_path)], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    a, b = torch.load(tmp_path / "eps0.pt"), torch.load(tmp_path / "eps1.pt")
+    assert torch.equal(a, b)
+
+
+def test_bench_two_gpus(tmp_path):
+    """`bench.py --gpus 2` (self-launch, one rank per GPU over RCCL): the JSON line must report n_gpus 2, twice the frames of N = 1 per
+    step, both ranks' times, and the two ranks must not differ by more than 10 %.  Needs two GPUs: skipped on a one-GPU box."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--subsample", "5",
+                        "--batch", "8", "--no-cpu-baseline", "--no-f16x2-leg"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16 and d["config"]["frames_per_step"] == 80
+    assert len(d["per_rank_s"]) == 2 and max(d["per_rank_s"]) <= 1.1 * min(d["per_rank_s"]), d["per_rank_s"]
