@@ -44,6 +44,8 @@ extern "C" {
 #define MCVD_EHIP (-2)     /* HIP runtime error */
 #define MCVD_ESTATE (-3)   /* call order violated (e.g. forward before finalize, missing parameter) */
 #define MCVD_ENOMEM (-4)
+#define MCVD_ERANGE (-5)   /* option "f16x2" only: a network output was not finite -- an activation left the fp16 range of the two-piece
+                              kernels (|x| beyond ~1e3 behind a GroupNorm), or the model diverged.  Rerun with f16x2 = 0 (the default) */
 
 #define MCVD_MAX_LEVELS 8
 
@@ -102,6 +104,12 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  * replayed afterwards; mcvd_sampler_run presents the same set on every step.  Any option change, re-tune, workspace growth or
  * mcvd_model_finalize drops the captured graph.  Also MCVD_GRAPH=1 in the environment at mcvd_ctx_create). */
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value);
+/* Option "f16x2" only (the default three-piece bf16 arithmetic has the fp32 range and needs no guard): every UNet forward run while the
+ * option is on is followed by a scan of its epsilon for non-finite values (nothing is clamped in the two-piece fp16 kernels: an
+ * out-of-range activation becomes Inf, then NaN).  This call synchronises the context's stream, returns MCVD_ERANGE (and a message in
+ * mcvd_last_error) if any forward since the last call produced one, else 0, and clears the record.  mcvd_sampler_run / mcvd_fpndm_run
+ * call it themselves before they return; a caller of mcvd_unet_forward* calls it when it wants the verdict. */
+int mcvd_ctx_check_range(mcvd_ctx* ctx);
 /* Diagnostics: when set (device pointer to [n_blocks][8] uint64, or NULL to disable), mcvd_op_conv2d's MFMA kernel records per
  * block the shader cycles wave 0 spent in {prologue, MFMA phases, barrier after MFMA, staging writes, second barrier, split-K
  * reduction, epilogue, total}. */

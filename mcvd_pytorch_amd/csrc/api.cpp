@@ -66,6 +66,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
 void mcvd_ctx_destroy(mcvd_ctx* ctx) {
     if (!ctx) return;
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->range_flag) (void)hipFree(ctx->range_flag);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->cap) (void)hipStreamDestroy(ctx->cap);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -96,6 +97,21 @@ int mcvd_ctx_set_stats_buffer(mcvd_ctx* ctx, float* device_floats) {
     MCVD_REQUIRE(ctx, "ctx is NULL");
     ctx->stats_buf = device_floats;
     return 0;
+}
+
+int mcvd_ctx_check_range(mcvd_ctx* ctx) {
+    API_TRY
+    MCVD_REQUIRE(ctx, "ctx is NULL");
+    if (!ctx->range_flag) return 0;                // no forward has run under f16x2
+    int hit = 0;
+    MCVD_HIP_CHECK(hipMemcpyAsync(&hit, ctx->range_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MCVD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (!hit) return 0;
+    MCVD_HIP_CHECK(hipMemsetAsync(ctx->range_flag, 0, sizeof(int), ctx->stream));
+    set_error("f16x2: a UNet forward produced non-finite values -- an activation left the fp16 range of the two-piece kernels, or the model "
+              "diverged; rerun with the option f16x2 = 0 (the default three-piece bf16 arithmetic has the fp32 range)");
+    return MCVD_ERANGE;
+    API_CATCH
 }
 
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
@@ -661,7 +677,7 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
         if (int rc = m->forward(x, m->labels, cond, m->eps_buf, B)) return rc;
         if (int rc = launch_axpy_out(x, m->eps_buf, sqrtf(1.0f - al[L - 1]), n, s)) return rc;
     }
-    return 0;
+    return m->ctx->f16x2 ? mcvd_ctx_check_range(m->ctx) : 0;      // f16x2 range guard: a non-finite epsilon anywhere in the loop is an error
     API_CATCH
 }
 
@@ -749,7 +765,7 @@ int mcvd_fpndm_run(mcvd_model* m, float* x, const float* cond, int subsample_ste
         if (int rc = transfer(x, x, (float)t, (float)t_next, comb)) return rc;            // pndm.py:51 (in place: elementwise)
         t_prev = t;
     }
-    return 0;
+    return m->ctx->f16x2 ? mcvd_ctx_check_range(m->ctx) : 0;      // f16x2 range guard
     API_CATCH
 }
 

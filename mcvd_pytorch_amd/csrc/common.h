@@ -196,6 +196,7 @@ int launch_sampler_update(int kind, float* x, const float* eps, const float* noi
 int launch_renoise(float* x, const float* noise, float ca, float cb, int64_t n, int use_philox, uint64_t seed,
                    uint64_t sample_offset, uint64_t draw, int64_t per_sample, hipStream_t s);
 int launch_axpy_out(float* x, const float* eps, float c, int64_t n, hipStream_t s);   // x -= c * eps
+int launch_nonfinite_flag(const float* v, int64_t n, int* flag, hipStream_t s);          // *flag = 1 if any v[i] is Inf / NaN (f16x2 range guard)
 int launch_pack_frames_u8(const float* in, uint8_t* out, int B, int T, int C, int HW, hipStream_t s);
 int launch_randn(float* out, uint64_t seed, uint64_t sample_offset, uint64_t draw, int B, int64_t per_sample,
                  hipStream_t s);

@@ -20,6 +20,8 @@
 //     waited for every chunk).  The DMA groups are the only VMEM operations in flight: their waits are counted by hand.
 // Workgroup = 4 waves = 128 consecutive pixels of the flattened [B*HW] axis x 32*COT couts; block id -> (pixel tile, cout tile)
 // keeps the cout tiles of one pixel tile on one XCD (conv1x1_dma.cpp).  MFMAs and LDS traffic are compiler-scheduled builtins.
+#include <stdlib.h>
+
 #include "../common.h"
 #include "pieces.h"
 
@@ -37,7 +39,9 @@ constexpr int Q1_NB = 4;         // LDS buffers: the DMA runs three chunks ahead
 constexpr int Q1_MAXIMG = 4;     // images a pixel tile may span (HW >= 32)
 
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU
-template <int NP, int COT, int PRO>
+// EXP != 0 (built with -DMCVD_DIAG only; env MCVD_Q1_EXP): timing-only ablations of the K loop, wrong results: bit 0 no DMA behind the
+// first three chunks, bit 1 no MFMA, bit 2 no affine / SiLU / split, bit 3 no barrier
+template <int NP, int COT, int PRO, int EXP = 0>
 __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptiles, int nct) {
     typedef Pieces<NP> PX;
     constexpr int PT = Q1_PT, CK = Q1_CK, NB = Q1_NB, BCO = 32 * COT;
@@ -148,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
         if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * G) : "memory");                           \
         else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G) : "memory");                          \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
-        if ((k) + 3 < nchunks) Q1_DMA((k) + 3);                                                                 \
+        if (!(EXP & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                        \
+        if ((k) + 3 < nchunks && !(EXP & 1)) Q1_DMA((k) + 3);                                                   \
         const float* sXc = sX + ((k) & (NB - 1)) * XSZ + wave * 32 + l31;                                       \
         const float* sCb = sC + ((long)my_img * Cin + (k) * CK) * 2;                                            \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {         /* element e of lane (n, h) = channel 2e + h of the chunk */ \
@@ -168,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     }
     /* GroupNorm affine (+ SiLU), split into pieces: the B operand of the chunk */
 #define Q1_PREP(BV, CF, BP)                                                                                     \
+    if (EXP & 4) { _Pragma("unroll") for (int p = 0; p < NP; ++p) _Pragma("unroll") for (int j = 0; j < 4; ++j) BP[p][j] = __builtin_bit_cast(unsigned, BV[2 * j]); } else \
     {                                                                                                           \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                         \
             if (PRO != 0) {                                                                                     \
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     }
     /* product-major MFMA order, smallest product first: consecutive MFMAs write different accumulators */
 #define Q1_MMA(AW, BP)                                                                                          \
+    if (EXP & 2) { _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) acc[ct][0] += __builtin_bit_cast(float, AW[ct][0][0] ^ BP[0][1] ^ AW[ct][NP - 1][2] ^ BP[NP - 1][3]); } else \
     {                                                                                                           \
         _Pragma("unroll") for (int k = 0; k < PX::NPROD; ++k)                                                   \
             _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) acc[ct] = PX::mfma(AW[ct][PX::PA(k)], BP[PX::PB(k)], acc[ct]); \
@@ -342,6 +348,34 @@ static int q1_launch(const ConvArgs& a, hipStream_t s) {
         MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised.done();
     }
+#ifdef MCVD_DIAG
+    {   // diagnostics build only: timing-only ablations (WRONG RESULTS), tests/gpu_diag.py w2htl with MCVD_Q1_EXP
+        const char* es = getenv("MCVD_Q1_EXP");
+        const int e = es ? atoi(es) : 0;
+        if (e != 0 && NP == 3 && COT == 3) {
+            static PerDeviceOnce raised2;
+            if (raised2.first_use()) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, 3, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, 3, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, 3, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, 3, 1, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, 3, 1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, 3, 1, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                raised2.done();
+            }
+            switch (e) {      // (all with the affine prologue instantiation: the caller passes coef)
+                case 1: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 1>), grid, dim3(256), lds, s, a, ptiles, nct); break;
+                case 2: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 2>), grid, dim3(256), lds, s, a, ptiles, nct); break;
+                case 4: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 4>), grid, dim3(256), lds, s, a, ptiles, nct); break;
+                case 6: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 6>), grid, dim3(256), lds, s, a, ptiles, nct); break;
+                case 7: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 7>), grid, dim3(256), lds, s, a, ptiles, nct); break;
+                default: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 15>), grid, dim3(256), lds, s, a, ptiles, nct); break;
+            }
+            MCVD_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
+#endif
     if (!a.coef)
         hipLaunchKernelGGL((conv1x1_h2_kernel<NP, COT, 0>), grid, dim3(256), lds, s, a, ptiles, nct);
     else if (!a.act)

@@ -273,6 +273,27 @@ int launch_axpy_out(float* x, const float* eps, float c, int64_t n, hipStream_t 
     return 0;
 }
 
+// f16x2 range guard: the two-piece fp16 kernels clamp nothing -- an activation beyond the fp16 range becomes Inf, the accumulators NaN,
+// GroupNorm spreads it over the sample -- so a scan of the forward's epsilon sees every overflow.  One flag word, written only on a hit.
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* v, int64_t n, int* flag) {
+    const int64_t n4 = n >> 2;
+    bool bad = false;
+    for (int64_t i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 e = reinterpret_cast<const float4*>(v)[i];
+        // exponent all ones <=> Inf or NaN
+        bad |= ((__float_as_uint(e.x) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(e.y) & 0x7f800000u) == 0x7f800000u) |
+               ((__float_as_uint(e.z) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(e.w) & 0x7f800000u) == 0x7f800000u);
+    }
+    if (bad) *flag = 1;
+}
+
+int launch_nonfinite_flag(const float* v, int64_t n, int* flag, hipStream_t s) {
+    MCVD_REQUIRE(n % 4 == 0 && flag, "nonfinite_flag: n must be a multiple of 4");
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, v, n, flag);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ---- F-PNDM pieces (models/pndm.py).  One rounding per operation, in the order of the reference's tensor expressions, so the
 // multistep combination is bit-identical to torch's elementwise evaluation: plain operators under `fp contract(off)` (the
 // __fmul_rn / __fadd_rn device functions are inlined with the translation unit's default contraction and DO get fused).

@@ -985,7 +985,19 @@ int mcvd_model::prepare_cond(const float* cond, int B) {
     return 0;
 }
 
+// f16x2 range guard, second half (the first: convs over raw tensors never take the two-piece fp16 kernels, autotune()): the forward's
+// epsilon is scanned for Inf / NaN; mcvd_ctx_check_range turns a hit into MCVD_ERANGE.
 int mcvd_model::forward(const float* x, const void* lab, const float* cond, float* out, int B) {
+    if (int rc = forward_unchecked(x, lab, cond, out, B)) return rc;
+    if (!ctx->f16x2) return 0;
+    if (!ctx->range_flag) {
+        MCVD_HIP_CHECK(hipMalloc((void**)&ctx->range_flag, sizeof(int)));
+        MCVD_HIP_CHECK(hipMemsetAsync(ctx->range_flag, 0, sizeof(int), ctx->stream));
+    }
+    return launch_nonfinite_flag(out, (int64_t)B * d.channels * d.num_frames * d.image_size * d.image_size, ctx->range_flag, ctx->stream);
+}
+
+int mcvd_model::forward_unchecked(const float* x, const void* lab, const float* cond, float* out, int B) {
     MCVD_REQUIRE(finalized, "forward before mcvd_model_finalize");
     MCVD_REQUIRE(B > 0 && x && lab && out, "forward: bad arguments");
     if (int rc = prepare_B(B)) return rc;

@@ -41,6 +41,7 @@ struct mcvd_ctx {
     const float* spade_gb = nullptr;     // mcvd_op_conv2d: SPADE prologue inputs of the next convs (mcvd_ctx_set_spade_inputs; tests)
     const float* spade_coef2 = nullptr;
     float* stats_buf = nullptr;          // mcvd_op_conv2d: where the conv's GroupNorm partials go (mcvd_ctx_set_stats_buffer; tests)
+    int* range_flag = nullptr;     // device word: set by nonfinite_flag_kernel after a forward under f16x2 (mcvd_ctx_check_range reads + clears it)
     float* scratch = nullptr;      // small device scratch for stand-alone ops (kernel taps, packed weights)
     size_t scratch_bytes = 0;
     int ensure_scratch(size_t bytes);
@@ -221,6 +222,7 @@ struct mcvd_model {
                                    //    the Dense_0 projections are evaluated for one row and read with stride 0
     int labels_f32 = 0;            // the labels of the forward in flight are float [B] instead of int64 [B] (mcvd_unet_forward_ft)
     int forward(const float* x, const void* labels, const float* cond, float* out, int B);
+    int forward_unchecked(const float* x, const void* labels, const float* cond, float* out, int B);
     int launch_op(const mcvd::Op& op, const float* x, const void* labels, const float* cond, float* out, int B);
     float* resolve(const mcvd::TRef& r, const float* x, const float* cond, float* out, int B) const;
 };

@@ -247,6 +247,7 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
         x = x - _f((1 - alphas[-1]).sqrt()) * call_net(x, last_noise)
         if not final_only:
             images.append(x.to("cpu"))
+    _lib.check(_lib.lib.mcvd_ctx_check_range(net._ctx), "sampler (f16x2 range guard)")      # no-op unless the option f16x2 is on
     if final_only:
         return x.unsqueeze(0)
     return torch.stack(images)

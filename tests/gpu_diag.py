@@ -475,6 +475,7 @@ def w2htl(f):
         cases = [(a, b_, c, d, {12: 10, 14: 15}[e], g) for a, b_, c, d, e, g in cases]
     if os.environ.get("MCVD_TL_CASES"):
         cases = [cases[int(v)] for v in os.environ["MCVD_TL_CASES"].split(",")]
+    act_tl = int(os.environ.get("MCVD_TL_ACT", "1"))        # 0: affine prologue only (what the q|k|v projections run)
     for cin, cout, H, ks, shp, cot in cases:
         x = torch.randn(B, cin, H, H, device="cuda")
         w = torch.randn(cout, cin, ks, ks, device="cuda") / (cin * ks * ks) ** 0.5
@@ -482,20 +483,20 @@ def w2htl(f):
         coef = torch.ones(B, cin, 2, device="cuda")
         ctx.opt("conv_shape", shp)
         ctx.opt("conv_cot", cot)
-        f.write(f"--- {ks}x{ks} shape {shp} cot {cot}: ")
+        f.write(f"--- {ks}x{ks} shape {shp} cot {cot} exp {os.environ.get('MCVD_Q1_EXP', '0')}: ")
         os.environ["MCVD_DBG_WAVE"] = "0"
         for _ in range(3):
-            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+            ctx.conv2d(x, w, b, coef=coef, act=act_tl, scale=0.7)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(4):
-            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+            ctx.conv2d(x, w, b, coef=coef, act=act_tl, scale=0.7)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 4
         dbg = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
         _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
-        ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+        ctx.conv2d(x, w, b, coef=coef, act=act_tl, scale=0.7)
         torch.cuda.synchronize()
         _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
         d = dbg.view(-1, 8).cpu()

@@ -750,6 +750,43 @@ def test_f16x2_option_is_authoritative():
     assert (b0 - b).abs().max().item() <= 2e-5 * b.abs().max().item()
 
 
+def test_f16x2_overflow_is_reported_and_the_default_path_has_the_range():
+    """A net whose temb projections are scaled by 3e4 drives the GroupNorm-ed activations to ~1e5: the default (three-piece bf16) path
+    reproduces the oracle at the fp32 tolerance; with the two-piece fp16 kernels forced the activations leave the fp16 range, nothing is
+    clamped (Inf -> NaN), and the library REPORTS it: mcvd_ctx_check_range / mcvd_sampler_run return MCVD_ERANGE (the clamp
+    at 4094 saturated silently)."""
+    from mcvd_pytorch_amd import _lib
+    from mcvd_pytorch_amd.samplers import ddpm_sampler
+    from mcvd_pytorch_amd.scorenet import HipScoreNet
+    config = synth.make_config("tiny")
+    config.device = "cuda:0"
+    sd = synth.make_state_dict(config, seed=123)
+    for k in sd:
+        if "Dense_0.weight" in k:
+            sd[k] = sd[k] * 3.0e4
+    net = HipScoreNet(config)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    t = torch.tensor([990, 130])
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t, cond)
+    assert torch.isfinite(ref).all()              # (epsilon itself is O(1): the final GroupNorm; it is the activations inside that reach ~1e5)
+    eps = net(x.cuda(), t.cuda(), cond=cond.cuda()).cpu()
+    assert (eps - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert _lib.lib.mcvd_ctx_check_range(net._ctx) == 0
+    net.set_option("f16x2", 1)
+    net.set_option("conv_shape", 12)
+    net.set_option("conv_shape1", 14)
+    bad = net(x.cuda(), t.cuda(), cond=cond.cuda()).cpu()
+    assert not torch.isfinite(bad).all()
+    assert _lib.lib.mcvd_ctx_check_range(net._ctx) == -5 and b"f16x2" in _lib.lib.mcvd_last_error(None)
+    assert _lib.lib.mcvd_ctx_check_range(net._ctx) == 0                     # the record is cleared by the call
+    for fo in (True, False):                                                # device loop and host loop
+        with pytest.raises(RuntimeError, match="f16x2"):
+            ddpm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=fo, subsample_steps=5, seed=1)
+
+
 def test_imported_table_yields_to_the_options():
     """A kernel table imported through mcvd_model_set_tuning (e.g. one tuned in an f16x2 run) must not override the arithmetic options,
     with or without autotune: f16x2 entries run as their three-piece bf16 counterparts when f16x2 is off, bf16x3 entries as the fp32

@@ -99,6 +99,35 @@ def sq():
                   f"  lds-active/busy {d.get('SQ_LDS_IDX_ACTIVE', 0) / max(d.get('SQ_BUSY_CYCLES', 0), 1):6.3f}")
 
 
+def l2():
+    """L2 (TCC) and L1 (TCP) request counters per kernel: hit rate, bytes requested by the CUs' L1s (64-byte requests), per launch."""
+    for d in ("pmc_l2a", "pmc_l2b"):
+        for f in glob.glob(os.path.join(OUT, d, "**", "*counter_collection.csv"), recursive=True):
+            agg = defaultdict(lambda: defaultdict(float))
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                agg[k]["_n_" + r["Counter_Name"]] += 1
+                if "Start_Timestamp" in r:
+                    agg[k]["_ns_" + r["Counter_Name"]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            print(f"== {os.path.relpath(f, ROOT)}: per kernel, per launch averages")
+            names = sorted({c for d2 in agg.values() for c in d2 if not c.startswith("_")})
+            for k, dd in sorted(agg.items(), key=lambda kv: -max([v for c, v in kv[1].items() if c.startswith("_ns_")] or [0]))[:12]:
+                parts = []
+                for c in names:
+                    n = dd.get("_n_" + c, 0)
+                    if n:
+                        parts.append(f"{c} {dd[c] / n:14.1f}")
+                n0 = max([dd.get("_n_" + c, 0) for c in names] or [1])
+                ns = max([dd.get("_ns_" + c, 0) for c in names] or [0])
+                extra = ""
+                if dd.get("TCC_HIT_sum") or dd.get("TCC_MISS_sum"):
+                    extra += f" | L2 hit rate {dd.get('TCC_HIT_sum', 0) / max(dd.get('TCC_HIT_sum', 0) + dd.get('TCC_MISS_sum', 0), 1):.3f}"
+                if dd.get("TCP_TCC_READ_REQ_sum") and ns:
+                    extra += f" | L1->L2 read requests x 64 B / time = {dd['TCP_TCC_READ_REQ_sum'] * 64 / ns:.1f} GB/s"
+                print(f"{k:52s} {int(n0):5d} launches, {ns / max(n0, 1) / 1e3:8.1f} us avg | " + "  ".join(parts) + extra)
+
+
 def traffic(out_json):
     """HBM-side bytes per conv launch of the Winograd kernel family from the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs,
     kernel-trace only), over the SAME population bench.py's `algorithmic_bytes_per_launch` averages: every Winograd-served 3x3 conv
@@ -172,6 +201,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "traffic":
         traffic(sys.argv[2])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "l2":
+        l2()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mfma":
         mfma()
