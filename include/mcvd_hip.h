@@ -88,21 +88,44 @@ typedef struct mcvd_unet_desc {
 int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out);
 void mcvd_ctx_destroy(mcvd_ctx* ctx);
 int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
-/* options: "naive_conv", "naive_attn" (0/1: route through the simple one-thread-per-output HIP kernels, used by the
- * tests to triangulate; "naive_attn" 2 / 3 force the fp32-MFMA / the two-piece fp16 flash attention kernel, 0 picks by "f16x2"), "conv_shape" (-1 auto; 0/1/2/3 force the 256/128/64-pixel / split-K conv tile, 4 the Winograd F(2x2,3x3) kernel where
- * it applies (8: with its 2-way split of the input channels), 5 / 6 the all-DMA 1x1 GEMM kernel (16 / 32 channels per chunk) where it applies,
- * 10 / 11 the Winograd kernel on the bf16 matrix pipe with three-piece operands (fp32-accurate), 12 / 13 on the fp16 matrix pipe with two-piece
- * operands (22-bit operands, fp32 accumulate)), "winograd" / "conv_dma1" (1: offer the Winograd / all-DMA 1x1
- * kernel to the autotuner), "bf16x3" / "f16x2" (1: offer the bf16-pipe / fp16-pipe forms of the Winograd kernel to the autotuner; "f16x2" = 0 keeps every
- * product of the 3x3 convs at fp32 accuracy), "conv_cot" (with conv_shape 5: cout tile, in 32-channel units, that mcvd_op_conv2d requests), "conv_wdma" (1: weight
- * chunks by LDS-DMA, 0: register staging), "autotune" (1: time the conv tile candidates per layer shape on first use of a batch
- * size and keep the fastest), "side_stream" (1: ResBlock shortcut convs run on a second HIP stream concurrently with Conv_0; default 0, it measured slower), "profile" (0/1, see
- * mcvd_model_profile_read), "spade_fuse" (1: the SPADE modulation of a norm is applied inside the Winograd conv loader -- gamma | beta by LDS-DMA -- where that
- * kernel runs the conv, 0 (default: the fused form measured 3.5 % slower end to end): materialised by spade_apply), "gn_stats" (1: GroupNorm statistics come out of the producing conv's epilogue where the kernel supports it, 0: always one pass
- * over the normalised tensor), "graph" (0/1: replay each UNet forward as ONE hipGraph launch instead of ~190 kernel launches -- a forward is
- * run eagerly the first time a (x, labels, cond, eps, B) pointer set is seen, captured on a private stream the second time and
- * replayed afterwards; mcvd_sampler_run presents the same set on every step.  Any option change, re-tune, workspace growth or
- * mcvd_model_finalize drops the captured graph.  Also MCVD_GRAPH=1 in the environment at mcvd_ctx_create). */
+/* options (int values; an unknown key is MCVD_EINVAL):
+ *   ARITHMETIC of the GEMM-shaped kernels (3x3 / 1x1 convs, attention).  Storage, accumulation and every elementwise op are fp32.
+ *     "bf16x3" (default 1): offer the three-piece bf16 kernels -- both MFMA operands split EXACTLY into three bf16 pieces (all 24 bits,
+ *         the fp32 exponent range; nothing scaled or clamped, Inf / NaN propagate), six piece products accumulated in fp32: less than one
+ *         fp32 rounding per product, i.e. fp32-equivalent.  With 0 every product runs on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *     "f16x2" (default 0): ALSO offer the two-piece fp16 kernels -- operands rounded to two fp16 pieces (22-23 significant bits where fp32
+ *         has 24; fp16 exponent range), three piece products: ~15 % faster end to end, NARROWER than the reference's fp32.  Range: the
+ *         pieces are finite for |activation| < ~1e3 (a Winograd transform value is a sum of four, times 2^4, against 65504); values below
+ *         ~1e-6 lose relative precision (fp16 denormals).  The library therefore (1) gives these kernels GroupNorm-ed inputs only -- a conv
+ *         over a raw tensor (stem, shortcuts, NIN_3) always runs the fp32-range kernels -- and (2) clamps nothing: an overflow becomes Inf
+ *         / NaN and is REPORTED (MCVD_ERANGE, mcvd_ctx_check_range) instead of saturating silently.
+ *   KERNEL SELECTION
+ *     "autotune" (1): time the candidate kernels per distinct layer shape on first use of a batch size and keep the fastest (a table
+ *         imported through mcvd_model_set_tuning is used as is, with or without autotune; the arithmetic options above always win over it).
+ *     "conv_shape" (-1 auto): force a kernel family for every conv (tests): 0/1/2/3 the 256/128/64-pixel / split-K direct tiles, 4 fp32
+ *         Winograd F(2x2,3x3) (8: with its 2-way split of the input channels), 5 / 6 / 9 the fp32 all-DMA 1x1 GEMM (16 / 32 channels per
+ *         chunk / 64 pixels per wave), 10 / 11 three-piece bf16 Winograd (11: K split), 12 / 13 two-piece fp16 Winograd (13: K split),
+ *         14 / 15 the split-operand 1x1 GEMM with two fp16 / three bf16 pieces.  A family that does not serve a launch falls back.
+ *     "conv_shape1" (-1): the same for the 1x1 convs only (they follow "conv_shape" otherwise), so that a test can put every 3x3 AND
+ *         every 1x1 conv of a model on chosen kernels at once.  "conv_cot": cout tile (32-channel units) mcvd_op_conv2d requests with
+ *         conv_shape 5 / 6 / 9 / 14 / 15.
+ *     "naive_attn": 0 auto (three-piece bf16 flash kernel for head dims 32..128, two-piece fp16 when "f16x2" is on, else the fp32 flash
+ *         kernel), 1 one-thread-per-query test kernel, 2 fp32 flash kernel, 3 / 4 force the two-piece fp16 / three-piece bf16 kernel.
+ *     "naive_conv" (0/1): one-thread-per-output conv kernel (tests triangulate with it).
+ *     "winograd" / "conv_dma1" (1): offer the Winograd / all-DMA 1x1 kernels to the autotuner.  "conv_wdma" (1: direct-conv weight chunks
+ *         by LDS-DMA, 0: register staging).
+ *   EXECUTION
+ *     "graph" (0/1): replay each UNet forward as ONE hipGraph launch instead of ~190 kernel launches -- a forward is run eagerly the first
+ *         time a (x, labels, cond, eps, B) pointer set is seen, captured on a private stream the second time and replayed afterwards;
+ *         mcvd_sampler_run presents the same set on every step.  Any option change, re-tune, workspace growth or mcvd_model_finalize
+ *         drops the captured graph.  Also MCVD_GRAPH=1 in the environment at mcvd_ctx_create.
+ *     "gn_stats" (1): GroupNorm statistics come out of the producing conv's epilogue where the kernel supports it (0: always one pass
+ *         over the normalised tensor).  "spade_fuse" (0): 1 = the SPADE modulation inside the fp32 Winograd conv loader (gamma | beta by
+ *         LDS-DMA; measured 3.5 % slower end to end than the materialising spade_apply kernel).  "side_stream" (0): ResBlock shortcut
+ *         convs on a second HIP stream (measured slower).  "profile" (0/1): see mcvd_model_profile_read.
+ * Environment variables read ONCE at mcvd_ctx_create set the same options: MCVD_AUTOTUNE, MCVD_SIDE_STREAM, MCVD_WINOGRAD, MCVD_CONV_DMA1,
+ * MCVD_BF16X3, MCVD_F16X2, MCVD_GRAPH, MCVD_GN_STATS, MCVD_SPADE_FUSE, MCVD_NAIVE.  Nothing else in the production library reads the
+ * environment (the diagnostics build, csrc/build.py --diag, adds timing-only ablation hooks). */
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value);
 /* Option "f16x2" only (the default three-piece bf16 arithmetic has the fp32 range and needs no guard): every UNet forward run while the
  * option is on is followed by a scan of its epsilon for non-finite values (nothing is clamped in the two-piece fp16 kernels: an
@@ -256,9 +279,10 @@ int mcvd_upfirdn2d(mcvd_ctx* ctx, const float* in, const float* kernel_host, int
 int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int C1, const float* w, const float* bias,
                    int Cout, int ks, const float* coef, int act, const float* res, float out_scale, float* y, int B, int H,
                    int W);
-/* Which kernel family the calling thread's last conv launch (mcvd_op_conv2d or a model forward) was dispatched to: 0..3 direct
- * implicit-GEMM tile shapes, 4 Winograd F(2x2,3x3), 8 Winograd with the 2-way K split, 5 / 6 all-DMA 1x1 GEMM; -1 none yet.  A forced
- * "conv_shape" that does not apply to a launch falls back to the direct kernel -- tests use this to assert what really ran. */
+/* Which kernel family the calling thread's last conv launch (mcvd_op_conv2d or a model forward) was dispatched to: the ids of the
+ * "conv_shape" option (0..3 direct implicit-GEMM tile shapes, 4 / 8 fp32 Winograd, 5 / 6 / 9 fp32 1x1 GEMM, 10 / 11 three-piece bf16
+ * Winograd, 12 / 13 two-piece fp16 Winograd, 14 / 15 split-operand 1x1 GEMM); -1 none yet.  A forced "conv_shape" that does not apply to a
+ * launch falls back -- tests use this to assert what really ran (per op of a model: mcvd_model_op_kernel). */
 int mcvd_last_conv_kernel(void);
 /* SPADE prologue of the Winograd conv kernel (layerspp.py:164-171, :530-535): while set (non-NULL gb), mcvd_op_conv2d computes
  * conv(silu(((A x + B)(1 + gamma) + beta) * s1 + b2)) with (A, B) = coef, gamma | beta = gb:[B, 2*Cin, H, W] and (s1, b2) =

@@ -9,9 +9,9 @@
 //       has the fp32 exponent range: no scale, no clamp, Inf / NaN propagate.
 //   Pieces<2> -- TWO FP16 PIECES (context option "f16x2", off by default).  v ~= v1 + v2, |v - v1 - v2| <= 2^-22 |v| (22-23
 //       significant bits where fp32 has 24), three products u1 v2 + u2 v1 + u1 v1.  fp16 has 5 exponent bits: operands are scaled
-//       by powers of two into its range (weights per layer at pack time, activations by 2^4) and the caller guarantees
-//       |activation| <= F16X2_ACT_MAX -- the library measures that per tensor and routes a launch whose input exceeds it to the
-//       Pieces<3> kernel (model.cpp: f16x2 range guard).
+//       by powers of two into its range (weights per layer at pack time, activations by 2^4).  Nothing is clamped: a value beyond
+//       the range becomes Inf and the accumulator NaN.  The library keeps raw (unbounded) tensors away from these kernels and scans
+//       every forward's output for non-finite values (model.cpp: f16x2 range guard; MCVD_ERANGE).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -25,9 +25,9 @@ typedef __bf16 px_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 px_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned px_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float F16X2_ACT_SCALE = 16.0f;                    // activations enter the fp16 pieces times 2^4 (exact)
-constexpr float F16X2_ACT_MAX = 65504.0f / 16.0f / 4.0f;    // largest |activation| the f16x2 kernels accept (1023.5): a Winograd
-                                                            // transform value is a sum of four of them
+constexpr float F16X2_ACT_SCALE = 16.0f;                    // activations enter the fp16 pieces times 2^4 (exact): finite up to
+                                                            // 65504 / 16 = 4094 (a Winograd transform value is a sum of four
+                                                            // activations: ~1e3 per activation in the worst case)
 
 template <int NP>
 struct Pieces;
@@ -45,8 +45,8 @@ struct Pieces<2> {
         const px_f32x2 v = {lo, hi};
         return __builtin_bit_cast(unsigned, __builtin_convertvector(v, px_f16x2));
     }
-    // (x, y) -> w[piece] = packed pair (x piece in the low half); CLAMP: saturate to the fp16 range first (NaN stays NaN: v_med3
-    // with a NaN operand returns... not relied upon: the range guard keeps out-of-range tensors away from these kernels)
+    // (x, y) -> w[piece] = packed pair (x piece in the low half); CLAMP (unused by the library: overflow is meant to be loud):
+    // saturate to the fp16 range first
     template <bool CLAMP>
     __device__ static __forceinline__ void split(float x, float y, unsigned (&w)[2]) {
         if (CLAMP) {

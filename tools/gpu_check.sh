@@ -21,7 +21,7 @@ testall)
   echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; tail -40 gpurun_out/pytest_gpu.log;;
 bench)
   timeout 900 python bench.py --steps 2 --warmup 1 > gpurun_out/bench.json 2> gpurun_out/bench.err
-  echo "bench rc=$?" >> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err;;
+  echo "bench rc=$?" >> gpurun_out/bench.err; cat gpurun_out/bench.json | cut -c1-1500; tail -5 gpurun_out/bench.err;;
 graphab)
   for g in 0 1; do
     timeout 600 python bench.py --steps 2 --warmup 1 --graph $g --no-cpu-baseline > gpurun_out/bench_graph$g.json 2> gpurun_out/bench_graph$g.err
@@ -39,7 +39,7 @@ others)
   for c in smmnist_big5 kth64_big_ngf128 bair_big_spade cityscapes_big cityscapes_big_variant; do
     for g in ${GRAPHS:-1}; do
       timeout 900 python bench.py --config $c --steps 1 --warmup 1 --graph $g --no-cpu-baseline > gpurun_out/bench_other_${c}_g$g.json 2> gpurun_out/bench_other_${c}_g$g.err
-      python -c "import json;d=json.load(open('gpurun_out/bench_other_${c}_g$g.json'));print('$c graph$g', d['value'], d['ms_per_step'], d['roofline']['frac'])"
+      python -c "import json;d=json.load(open('gpurun_out/bench_other_${c}_g$g.json'));print('$c graph$g', d['value'], d['ms_per_step'], d['roofline']['frac'], 'f16x2 leg', d.get('f16x2_leg', {}).get('value'))"
     done
   done;;
 prof)
