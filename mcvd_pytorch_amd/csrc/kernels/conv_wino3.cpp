@@ -5,7 +5,8 @@
 //     u * v  ~=  u1 v3 + u3 v1 + u2 v2 + u1 v2 + u2 v1 + u1 v1          (dropped: u2 v3 + u3 v2 + u3 v3 <= 2^-23.4 |u v|)
 // Each piece product is exact in the fp32 accumulator (8 x 8 significant bits), so the result differs from the fp32-MFMA kernel
 // (conv_wino.cpp) by less than one fp32 rounding per product.  bf16 has the exponent range of fp32: nothing is scaled, nothing is
-// clamped, Inf / NaN propagate.  tests/test_gpu_parity.py holds this kernel to the fixtures of the fp32 kernels and measures it
+// clamped, Inf / NaN propagate.  (The split is bit-exact for 2^-110 <= |v|; below, the third piece reaches the bf16 denormals, ulp
+// 2^-133, and the operand loses bits gradually -- tests/test_bf16x3_arithmetic_cpu.py.)  tests/test_gpu_parity.py holds this kernel to the fixtures of the fp32 kernels and measures it
 // against an fp64 convolution (random and structured inputs, 1e-6 ... 1e5 magnitudes).
 //
 // Round 2's form of this kernel split the WEIGHTS on the fly and was VALU-bound on exactly that (240 of ~430 VALU instructions per

@@ -6,7 +6,8 @@
 //   Pieces<3> -- THREE BF16 PIECES, FP32-EQUIVALENT (the default arithmetic of the library).  v = v1 + v2 + v3 exactly (round to
 //       nearest at every level; the remainders are exact in fp32 and the third has at most 8 significant bits), six products
 //       u1 v3 + u3 v1 + u2 v2 + u1 v2 + u2 v1 + u1 v1; dropped: <= 2^-23.4 |u v|, less than one fp32 rounding per product.  bf16
-//       has the fp32 exponent range: no scale, no clamp, Inf / NaN propagate.
+//       has the fp32 exponent range: no scale, no clamp, Inf / NaN propagate.  (Bit-exact split for |v| >= 2^-110; below that the
+//       third piece is a bf16 denormal, ulp 2^-133, and v loses bits gradually: tests/test_bf16x3_arithmetic_cpu.py.)
 //   Pieces<2> -- TWO FP16 PIECES (context option "f16x2", off by default).  v ~= v1 + v2, |v - v1 - v2| <= 2^-22 |v| (22-23
 //       significant bits where fp32 has 24), three products u1 v2 + u2 v1 + u1 v1.  fp16 has 5 exponent bits: operands are scaled
 //       by powers of two into its range (weights per layer at pack time, activations by 2^4).  Nothing is clamped: a value beyond
