@@ -89,17 +89,25 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
         w_goff[s] = (q0 + lane) * 4;
     }
 
-    // ---- coefficient table (PRO): (A, B) of every input channel for the images of this tile, loaded once
+    // ---- coefficient table (PRO): (A, B) of every input channel for the images of this tile, fetched once -- by LDS-DMA, 16 bytes (two
+    // channels) per lane, IN FRONT of the first chunk: these DMAs are the oldest VMEM operations of the wave, so the table has landed
+    // when chunk 0 has (in-order return) and the barrier of the first stage makes it visible.  (Round 3's first form loaded the table
+    // through registers and waited for it before the first chunk was requested: one exposed memory latency per workgroup.)
     const int b_first = (int)(gp0 / HW);
     const int nimg = HW >= PT ? 1 : PT / HW;
     if (PRO != 0) {
-        for (int t = tid; t < nimg * Cin; t += 256) {
-            const int img = min(b_first + t / Cin, a.B - 1), c = t % Cin;
-            *reinterpret_cast<f32x2*>(sC + t * 2) = *reinterpret_cast<const f32x2*>(a.coef + ((long)img * Cin + c) * 2);
+        const int ppi = Cin >> 1;                                  // 16-byte pieces per image (Cin % 16 == 0)
+        for (int q0 = 0; q0 < nimg * ppi; q0 += 256) {
+            const int q = q0 + tid;
+            if (q < nimg * ppi) {
+                const int im = q / ppi, w = q - im * ppi;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(a.coef + ((long)min(b_first + im, a.B - 1) * Cin) * 2 + w * 4),
+                    (__attribute__((address_space(3))) void*)(sC + (q0 + wave * 64) * 4), 16, 0, 0);
+            }
         }
     }
     const int my_img = HW >= PT ? 0 : (wave * 32) / HW;            // image (within the tile) of this wave's 32 pixels
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // from here on the only VMEM operations in flight are the DMA groups
 
 #define Q1_DMA(ch)                                                                                              \
     {                                                                                                           \
@@ -236,6 +244,25 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     // free) and leaves as global_store_dwordx4: four consecutive pixels per lane, 1 KiB contiguous per wave instruction.
     const float inv = NP == 2 ? a.wph[2] * (1.0f / PX::ACT_SCALE) : 1.0f;      // NP = 2: 1 / (weight scale * activation scale), a power of two
     float* sO = smem;                                         // [BCO][PT]
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int px4 = tid & 31, cr = tid >> 5;                  // store role: 4 pixels px4*4 .. +3 of cout rows cr + 8*k
+    const long gp = gp0 + px4 * 4;
+    const bool valid = gp < NPX;                              // NPX % 4 == 0: a group of four is valid or invalid as a whole
+    const long gpc = valid ? gp : 0;
+    const int ob = (int)(gpc / HW), op = (int)(gpc - (long)ob * HW);          // HW % 4 == 0: the four pixels are in one image
+    const long obase = (long)ob * a.Cout * HW + op;
+    // bias and residual of every row the thread stores, requested before the tile is transposed: fetched inside the store loop, each
+    // of its BCO / 8 rounds waited for a memory latency AND (vmcnt counts stores too) for the previous round's store to retire --
+    // 8.5 k cycles for a 48 KB tile (profiles/r03_timeline_wino3_conv1x1_b3.txt)
+    float e_bias[BCO / 8];
+    f32x4 e_res[BCO / 8];
+#pragma unroll
+    for (int k = 0; k < BCO / 8; ++k) {
+        const int co = co0 + cr + 8 * k;
+        e_bias[k] = a.bias[co];                               // zero-padded to CoutP
+        e_res[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (a.res) e_res[k] = *reinterpret_cast<const f32x4*>(a.res + obase + (long)min(co, a.Cout - 1) * HW);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading the chunk buffers
 #pragma unroll
     for (int ct = 0; ct < COT; ++ct)
@@ -243,23 +270,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
         for (int r = 0; r < 16; ++r)
             sO[(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PT + wave * 32 + l31] = acc[ct][r] * inv;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     {
-        const int px4 = tid & 31, cr = tid >> 5;              // 4 pixels px4*4 .. +3 of cout row cr + 8*k
-        const long gp = gp0 + px4 * 4;
-        const bool valid = gp < NPX;                          // NPX % 4 == 0: a group of four is valid or invalid as a whole
-        const long gpc = valid ? gp : 0;
-        const int ob = (int)(gpc / HW), op = (int)(gpc - (long)ob * HW);      // HW % 4 == 0: the four pixels are in one image
-        const long obase = (long)ob * a.Cout * HW + op;
 #pragma unroll
         for (int k = 0; k < BCO / 8; ++k) {
             const int cl = cr + 8 * k, co = co0 + cl;
-            const int coc = min(co, a.Cout - 1);
             f32x4 v = *reinterpret_cast<const f32x4*>(sO + cl * PT + px4 * 4);
-            f32x4 rv = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (a.res) rv = *reinterpret_cast<const f32x4*>(a.res + obase + (long)coc * HW);
-            const float bco = a.bias[co];                     // zero-padded to CoutP
-            v = (v + bco + rv) * a.out_scale;
+            v = (v + e_bias[k] + e_res[k]) * a.out_scale;
             if (valid && co < a.Cout) *reinterpret_cast<f32x4*>(a.y + obase + (long)co * HW) = v;
             if (a.stats && (HW >= PT || HW == 64)) {
                 // GroupNorm partials of the FINAL values (ConvArgs::stats): the 32 lanes of a half-wave hold the 128 pixels of this cout

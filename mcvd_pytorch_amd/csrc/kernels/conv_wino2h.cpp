@@ -104,6 +104,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         float top;
         asm volatile("" : "={v255}"(top));
     }
+    // every kernel argument the prologue needs, fetched NOW (one batch of scalar loads, one wait; conv_wino3.cpp)
+    asm volatile("" :: "s"(a.x0), "s"(a.x1), "s"(a.coef), "s"(a.wph), "s"(a.B), "s"(a.H), "s"(a.W), "s"(a.Cin), "s"(a.CinP), "s"(a.C0),
+                 "s"(a.C1), "s"(a.CoutP), "s"(a.ksplit), "s"(a.dbg), "s"(a.wdma));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int H = a.H, W = a.W, HW = H * W, Cin = a.Cin;
     const int rx_n = G8 ? 1 : W >> 4, ry_n = G8 ? 1 : H >> 3;
@@ -120,14 +123,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     const int co0 = cotile * BCO;
     const int rg = __builtin_amdgcn_readfirstlane(wave >> 2);   // rows 2rg, 2rg+1 of B^T d; phase order of the wave
 
-    // prologue coefficients of this sample: requested first, so that their latency passes under the index arithmetic below
-    f32x2 cpre[2] = {{1.0f, 0.0f}, {1.0f, 0.0f}};               // Cin <= 1024: at most two table entries per thread (and sample)
+    // prologue coefficients of this sample: (A_c, B_c) of channel tid + k * 512 (Cin <= 1024: at most two table entries per thread and
+    // sample).  Regions of a plane: asm loads into v202-v205 (the registers of the third patch) IN FRONT of the first patches, parked in
+    // the LDS table once they have landed (conv_wino3.cpp).  G8 (two samples, eight values: more than the six patch registers): ordinary
+    // loads, waited for before the first patch request.
+    f32x2 cpre[2] = {{1.0f, 0.0f}, {1.0f, 0.0f}};
     f32x2 cpre2[2] = {{1.0f, 0.0f}, {1.0f, 0.0f}};              // G8: the region's second sample (clamped to the last one)
-    if (PRO && a.coef) {                                        // unconditional (clamped) loads: the wait belongs at the use
+    const float* co_src[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) co_src[k] = a.coef + ((long)b * Cin + min(tid + k * NT, Cin - 1)) * 2;
+    if (PRO && G8) {                                            // unconditional (clamped) loads: the wait belongs at the use
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            cpre[k] = *reinterpret_cast<const f32x2*>(a.coef + ((long)b * Cin + min(tid + k * NT, Cin - 1)) * 2);
-            if (G8) cpre2[k] = *reinterpret_cast<const f32x2*>(a.coef + ((long)min(b + 1, a.B - 1) * Cin + min(tid + k * NT, Cin - 1)) * 2);
+            cpre[k] = *reinterpret_cast<const f32x2*>(co_src[k]);
+            cpre2[k] = *reinterpret_cast<const f32x2*>(a.coef + ((long)min(b + 1, a.B - 1) * Cin + min(tid + k * NT, Cin - 1)) * 2);
         }
     }
 
@@ -353,36 +362,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     const int ksp = a.ksplit == 2 ? 2 : 1, kh = ksp == 2 ? (int)blockIdx.y : 0;
     const int c_begin = kh * (nch_all / ksp), c_end = c_begin + nch_all / ksp;
 
-    // ---- prologue.  Issue order = need order: the raw patches of the first two chunks (into the registers of weight quads 0-2, which
-    // are not needed before the first MFMA phase), the patch of the third chunk, then the weight quads 3.. of the first chunk.  The
-    // first two patches are activated and parked as soon as THEY have landed (the weights, 3/4 of the bytes, are still in flight);
-    // quads 0-2 follow once their registers have been read.  (With one wait for everything the prologue took 10-12 k cycles, of
+    // ---- prologue.  Issue order = need order: the coefficients of the sample (into the registers of the third patch), the raw patches of
+    // the first two chunks (into the registers of weight quads 0-2, which are not needed before the first MFMA phase), then the weight
+    // quads 3.. of the first chunk.  Coefficients and patches are consumed as soon as THEY have landed (the weights, 3/4 of the bytes, are
+    // still in flight); the third patch and quads 0-2 follow once their registers have been read.  (With one wait for everything the prologue took 10-12 k cycles, of
     // which 5-8 k went into pulling ~130 KB through the CU's memory pipe before any work started: profiles/r02_wino2h_prologue.txt.)
     int vtok = 0;                                       // ordering token: written by every VMEM wait, an operand of the register reads
     {
         float nodep[MAXP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (PRO) {                         // (the compiler waits for the coefficient loads here: nothing else is in flight yet)
+        if (PRO && G8) {                   // (the compiler waits for the coefficient loads here: nothing else is in flight yet)
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 if (tid + k * NT < Cin) {
                     *reinterpret_cast<f32x2*>(sCo + (tid + k * NT) * 2) = cpre[k];
-                    if (G8) *reinterpret_cast<f32x2*>(sCo + (Cin + tid + k * NT) * 2) = cpre2[k];
+                    *reinterpret_cast<f32x2*>(sCo + (Cin + tid + k * NT) * 2) = cpre2[k];
                 }
         }
         if (G8)                            // the halo of both patch buffers is zero padding for the whole kernel
             for (int i = tid; i < 2 * PBUF; i += NT) sP[i] = 0.0f;
-        {
-            unsigned ofs[MAXP];
-            H2_READ_OFF(ofs)
-            H2_LOAD_PR(c_begin, nodep, ofs, "v208", "v209", "v210", "v211", "v212", "v213")
-            H2_LOAD_PR(c_begin + 1, nodep, ofs, "v214", "v215", "v216", "v217", "v218", "v219")
-            H2_LOAD_P(c_begin + 2, nodep, ofs)
-        }
+        unsigned ofs[MAXP];
+        H2_READ_OFF(ofs)
+        if (PRO && !G8)
+            asm volatile("global_load_dwordx2 v[202:203], %0, off\n\tglobal_load_dwordx2 v[204:205], %1, off"
+                         :: "v"(co_src[0]), "v"(co_src[1]) : "memory");
+        H2_LOAD_PR(c_begin, nodep, ofs, "v208", "v209", "v210", "v211", "v212", "v213")
+        H2_LOAD_PR(c_begin + 1, nodep, ofs, "v214", "v215", "v216", "v217", "v218", "v219")
         H2_LOAD_A_RANGE(c_begin, 3, NA, nodep)
-        if (PRO || G8) __syncthreads();    // coefficient table (and the zeroed halo) visible
         if (rec) sp[0] = __builtin_amdgcn_s_memtime() - tk0;      // loads issued
-        H2_WAIT(MAXP + NA - 3)             // the two patches have landed; younger: patch(c_begin + 2), quads 3..
+        H2_WAIT(NA - 3)                    // the coefficients and the two patches have landed; younger: quads 3..
         if (rec) sp[1] = __builtin_amdgcn_s_memtime() - tk0;      // first patches landed
+        float cdep[MAXP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (PRO && !G8) {
+            asm volatile("v_mov_b32 %0, v202\n\tv_mov_b32 %1, v203\n\tv_mov_b32 %2, v204\n\tv_mov_b32 %3, v205"
+                         : "=v"(cpre[0].x), "=v"(cpre[0].y), "=v"(cpre[1].x), "=v"(cpre[1].y) : "s"(vtok));
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (tid + k * NT < Cin) *reinterpret_cast<f32x2*>(sCo + (tid + k * NT) * 2) = cpre[k];
+            cdep[0] = cdep[1] = cpre[0].x + cpre[0].y;
+            cdep[2] = cdep[3] = cpre[1].x + cpre[1].y;
+        }
+        H2_LOAD_P(c_begin + 2, cdep, ofs)  // (behind the reads of v202-v205)
+        if (PRO || G8) __syncthreads();    // coefficient table (and the zeroed halo) visible
         {
             float pv0[MAXP], pv1[MAXP];
             f32x2 cf0[MAXP], cf1[MAXP];
@@ -446,6 +466,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     const bool fin = ksp == 1;                 // K split: bias, residual and scale are applied by the reduce kernel
     float* const ydst = fin ? a.y : a.part + (long)kh * a.B * a.Cout * HW;
     const float inv = a.wph[2] * (1.0f / H2_ACT_SCALE);       // 1 / (weight scale of this layer * activation scale): both powers of two
+    // bias and residual of all 2 * COT tasks of the thread are requested up front (conv_wino3.cpp: fetched where they are used, every
+    // sub-tile waited for two dependent memory latencies between its barriers)
+    float e_bias[COT][2];
+    f32x2 e_r0[COT][2], e_r1[COT][2];
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int co = co0 + ct * 32 + e_col0 + 16 * t2;
+            e_bias[ct][t2] = fin ? a.bias[co] : 0.0f;           // zero-padded to CoutP
+            e_r0[ct][t2] = e_r1[ct][t2] = f32x2{0.0f, 0.0f};
+            if (a.res && fin) {
+                const long o = ((long)e_b * a.Cout + min(co, a.Cout - 1)) * HW + pix;
+                e_r0[ct][t2] = *reinterpret_cast<const f32x2*>(a.res + o);
+                e_r1[ct][t2] = *reinterpret_cast<const f32x2*>(a.res + o + W);
+            }
+        }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the K loop is done with the LDS
     H2_STAMP(1)
 #pragma unroll
@@ -462,12 +499,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         for (int t2 = 0; t2 < 2; ++t2) {
             const int e_col = e_col0 + 16 * t2;
             const int co = co0 + ct * 32 + e_col;
-            f32x2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
-            if (a.res && fin) {
-                const long o = ((long)e_b * a.Cout + min(co, a.Cout - 1)) * HW + pix;
-                r0 = *reinterpret_cast<const f32x2*>(a.res + o);
-                r1 = *reinterpret_cast<const f32x2*>(a.res + o + W);
-            }
+            const f32x2 r0 = e_r0[ct][t2], r1 = e_r1[ct][t2];
             float mm[16];
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) mm[xi] = sM[(xi * 32 + e_col) * T + e_tile];
@@ -479,7 +511,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
             }
             const float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
             const float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
-            const float bvv = fin ? a.bias[co] : 0.0f;          // zero-padded to CoutP
+            const float bvv = e_bias[ct][t2];
             const float osc = fin ? a.out_scale : 1.0f;
             const float v00 = (y00 * inv + bvv + r0.x) * osc, v01 = (y01 * inv + bvv + r0.y) * osc;
             const float v10 = (y10 * inv + bvv + r1.x) * osc, v11 = (y11 * inv + bvv + r1.y) * osc;

@@ -109,6 +109,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
         float top;
         asm volatile("" : "={v255}"(top));
     }
+    // every kernel argument the prologue needs, fetched NOW (one batch of scalar loads, one wait): left to itself the compiler fetches
+    // each where it is first used, eight dependent scalar-cache round trips in front of the first patch request
+    asm volatile("" :: "s"(a.x0), "s"(a.x1), "s"(a.coef), "s"(a.wpb), "s"(a.B), "s"(a.H), "s"(a.W), "s"(a.Cin), "s"(a.CinP), "s"(a.C0),
+                 "s"(a.C1), "s"(a.CoutP), "s"(a.ksplit), "s"(a.dbg), "s"(a.wdma));
+    const unsigned long long t_start = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;     // diagnostics: the phase clock starts here
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int H = a.H, W = a.W, HW = H * W, Cin = a.Cin;
     const int rx_n = G8 ? 1 : W >> 4, ry_n = G8 ? 1 : H >> 3;
@@ -125,15 +130,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
     const int co0 = cotile * BCO;
     const int rg = __builtin_amdgcn_readfirstlane(wave >> 2);   // rows 2rg, 2rg+1 of B^T d; phase order of the wave
 
-    // prologue coefficients of this sample: requested first, so that their latency passes under the index arithmetic below
-    f32x2 cpre[2] = {{1.0f, 0.0f}, {1.0f, 0.0f}};               // Cin <= 1024: at most two table entries per thread (and sample)
-    f32x2 cpre2[2] = {{1.0f, 0.0f}, {1.0f, 0.0f}};              // G8: the region's second sample (clamped to the last one)
-    if (PRO && a.coef) {                                        // unconditional (clamped) loads: the wait belongs at the use
+    // prologue coefficients of this sample: (A_c, B_c) of channel tid + k * 512 (Cin <= 1024: at most two table entries per thread and
+    // sample; G8: also the region's second sample, clamped to the last one), fetched by asm loads into v172-v179 IN FRONT of the first
+    // patches (see the prologue below) and parked in the LDS table once they have landed
+    const float* co_src[G8 ? 4 : 2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            cpre[k] = *reinterpret_cast<const f32x2*>(a.coef + ((long)b * Cin + min(tid + k * NT, Cin - 1)) * 2);
-            if (G8) cpre2[k] = *reinterpret_cast<const f32x2*>(a.coef + ((long)min(b + 1, a.B - 1) * Cin + min(tid + k * NT, Cin - 1)) * 2);
-        }
+    for (int k = 0; k < 2; ++k) {
+        co_src[k] = a.coef + ((long)b * Cin + min(tid + k * NT, Cin - 1)) * 2;
+        if (G8) co_src[2 + k] = a.coef + ((long)min(b + 1, a.B - 1) * Cin + min(tid + k * NT, Cin - 1)) * 2;
+    }
+    if (PRO) {                             // unconditional (clamped) loads into the registers of the third patch (requested later); the
+                                           // oldest VMEM operations of the wave: their latency passes under the index arithmetic below
+        asm volatile("global_load_dwordx2 v[172:173], %0, off\n\tglobal_load_dwordx2 v[174:175], %1, off"
+                     :: "v"(co_src[0]), "v"(co_src[1]) : "memory");
+        if constexpr (G8)
+            asm volatile("global_load_dwordx2 v[176:177], %0, off\n\tglobal_load_dwordx2 v[178:179], %1, off"
+                         :: "v"(co_src[2]), "v"(co_src[3]) : "memory");
     }
 
     // ---- transform role: (channel pair, tile) = tid & 255.  Pair s_cp = channels (s_ca, s_ca + 2), s_ca = 4*(s_cp >> 1) + (s_cp & 1):
@@ -245,8 +257,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
             }                                                                                                   \
         }                                                                                                       \
     }
-#define W3_WRITE_P(ch, PV, cfv) W3_WRITE_PR(ch, PV, cfv, "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180")
-#define W3_WRITE_PR(ch, PV, cfv, A0, A1, A2, A3, B0, B1, B2, B3, H0)                                            \
+#define W3_NOHOOK(e, v)
+#define W3_WRITE_P(ch, PV, cfv) W3_WRITE_PR(ch, PV, cfv, "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", W3_NOHOOK)
+    /* HOOK(e, v): statements placed behind value e (the prologue issues its weight loads there, one at a time) */ \
+#define W3_WRITE_PR(ch, PV, cfv, A0, A1, A2, A3, B0, B1, B2, B3, H0, HOOK)                                      \
     {                                                                                                           \
         float* sPw = sP + (((ch) & 1) ? PBUF : 0);                                                              \
         const int nvalid = Cin - (ch) * CK;                                                                     \
@@ -267,6 +281,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
             float v = PV[e];                                                                                    \
             if (PRO >= 2) v = silu_w3(v);                                                                       \
             sPw[(p_pk[sl] & 0xfff) + 2 * (e & 3)] = ((int)((p_pk[sl] >> 12) & 0xff) < min(nvalid, CK)) ? v : 0.0f; \
+            HOOK(e, v)                                                                                          \
         }                                                                                                       \
     }
     /* rows 2rg and 2rg+1 of B^T d for the two channels of the pair (packed fp32: .x = channel s_ca, .y = s_ca + 2), (.) B,      \
@@ -373,11 +388,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
     // diagnostics (mcvd_ctx_set_debug_buffer): shader-clock time the wave a.wdma spends per phase
     const bool rec = a.dbg != nullptr && wave == (a.wdma & 7);
     const bool sub = (a.wdma & 64) != 0;           // record prologue / epilogue sub-phase stamps instead of the wall clock
-    unsigned long long sp[3] = {0, 0, 0};
+    unsigned long long sp[5] = {0, 0, 0, 0, 0};
     unsigned long long tk0 = 0, tprev = 0, dt[2] = {0, 0}, rt0 = 0;
     if (rec) {
         rt0 = __builtin_amdgcn_s_memrealtime();          // constant 100 MHz: start / end of the workgroup on the wall clock
-        tk0 = tprev = __builtin_amdgcn_s_memtime();
+        tk0 = tprev = t_start;
     }
 #define W3_STAMP(i)                                                                                             \
     if (rec) {                                                                                                  \
@@ -406,43 +421,60 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
     const int ksp = a.ksplit == 2 ? 2 : 1, kh = ksp == 2 ? (int)blockIdx.y : 0;
     const int c_begin = kh * (nch_all / ksp), c_end = c_begin + nch_all / ksp;
 
-    // ---- prologue.  Issue order = need order: the raw patches of the first two chunks (into the registers of weight quads 0 .. PQ-1,
-    // which are not needed before the first MFMA phase), the patch of the third chunk, then the weight quads PQ.. of the first chunk.
-    // The first two patches are activated and parked as soon as THEY have landed (the weights, most of the bytes, are still in flight);
-    // quads 0 .. PQ-1 follow once their registers have been read.
+    // ---- prologue.  Issue order = need order: the coefficients of the sample (into the registers of the third patch), the raw patches of
+    // the first two chunks (into the registers of weight quads 0 .. PQ-1, which are not needed before the first MFMA phase), then the
+    // weight quads PQ.. of the first chunk.  Coefficients and patches are consumed as soon as THEY have landed (the weights, most of the
+    // bytes, are still in flight); the third patch and quads 0 .. PQ-1 follow once their registers have been read.
     int vtok = 0;                                       // ordering token: written by every VMEM wait, an operand of the register reads
     {
         const float nodep = 0.0f;
-        if (PRO) {                         // (the compiler waits for the coefficient loads here: nothing else is in flight yet)
+        unsigned ofs[NPL];
+        W3_READ_OFF(ofs)
+        if (rec) sp[3] = __builtin_amdgcn_s_memtime() - tk0;      // index arithmetic done, only the coefficients requested yet
+        // VMEM issue order = need order.  Round 3's first form fetched the coefficients with ordinary loads and parked them before
+        // anything else was requested: a full memory latency (2-3 k cycles under load) in front of every workgroup's first patch.
+        // the first two patches land in the registers of weight quads 0 .. PQ-1 (v184-v203)
+        W3_LOAD_PR(c_begin, nodep, ofs, "v[184:187]", "v[188:191]", "v192")
+        W3_LOAD_PR(c_begin + 1, nodep, ofs, "v[194:197]", "v[198:201]", "v202")
+        if (G8)                            // the halo of both patch buffers is zero padding for the whole kernel
+            for (int i = tid; i < 2 * PBUF; i += NT) sP[i] = 0.0f;
+        if (rec) sp[0] = __builtin_amdgcn_s_memtime() - tk0;      // loads issued
+        W3_WAIT(0)                         // the coefficients and the two patches have landed
+        if (rec) sp[1] = __builtin_amdgcn_s_memtime() - tk0;      // first patches landed
+        float cdep = 0.0f;
+        if (PRO) {
+            f32x2 cpre[G8 ? 4 : 2];
+            asm volatile("v_mov_b32 %0, v172\n\tv_mov_b32 %1, v173\n\tv_mov_b32 %2, v174\n\tv_mov_b32 %3, v175"
+                         : "=v"(cpre[0].x), "=v"(cpre[0].y), "=v"(cpre[1].x), "=v"(cpre[1].y) : "s"(vtok));
+            if constexpr (G8)
+                asm volatile("v_mov_b32 %0, v176\n\tv_mov_b32 %1, v177\n\tv_mov_b32 %2, v178\n\tv_mov_b32 %3, v179"
+                             : "=v"(cpre[2].x), "=v"(cpre[2].y), "=v"(cpre[3].x), "=v"(cpre[3].y) : "s"(vtok));
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 if (tid + k * NT < Cin) {
                     *reinterpret_cast<f32x2*>(sCo + (tid + k * NT) * 2) = cpre[k];
-                    if (G8) *reinterpret_cast<f32x2*>(sCo + (Cin + tid + k * NT) * 2) = cpre2[k];
+                    if constexpr (G8) *reinterpret_cast<f32x2*>(sCo + (Cin + tid + k * NT) * 2) = cpre[2 + k];
                 }
+            cdep = cpre[0].x + cpre[1].x + (G8 ? cpre[2].x + cpre[3].x : 0.0f);
         }
-        if (G8)                            // the halo of both patch buffers is zero padding for the whole kernel
-            for (int i = tid; i < 2 * PBUF; i += NT) sP[i] = 0.0f;
-        {
-            unsigned ofs[NPL];
-            W3_READ_OFF(ofs)
-            // the first two patches land in the registers of weight quads 0 .. PQ-1 (v184-v203)
-            W3_LOAD_PR(c_begin, nodep, ofs, "v[184:187]", "v[188:191]", "v192")
-            W3_LOAD_PR(c_begin + 1, nodep, ofs, "v[194:197]", "v[198:201]", "v202")
-            W3_LOAD_P(c_begin + 2, nodep, ofs)
-        }
-        W3_LOAD_A_RANGE(c_begin, PQ, NA, nodep)
+        W3_LOAD_P(c_begin + 2, cdep, ofs)  // (behind the reads of v172-v179)
         if (PRO || G8) __syncthreads();    // coefficient table (and the zeroed halo) visible
-        if (rec) sp[0] = __builtin_amdgcn_s_memtime() - tk0;      // loads issued
-        W3_WAIT(NPL + NA - PQ)             // the two patches have landed; younger: patch(c_begin + 2), quads PQ..
-        if (rec) sp[1] = __builtin_amdgcn_s_memtime() - tk0;      // first patches landed
+        if (rec) sp[4] = __builtin_amdgcn_s_memtime() - tk0;      // coefficient table visible
         {
+            // The weight quads PQ.. of the first chunk (most of the prologue's bytes: 13 KB per wave at COT = 3) are requested ONE BEHIND
+            // EACH ACTIVATED VALUE: issued in one burst they fill the CU's vector-memory queue and every wave sat 2-3 k cycles in the
+            // issue (8 waves x 21 KB at 64 bytes per clock; profiles/r03_wino3_prologue.txt) before it could touch its patches.
+            constexpr int QR = (NA - PQ + 2 * NPV - 1) / (2 * NPV);       // quads per value
+#define W3_HOOK0(e, v) W3_LOAD_A_RANGE(c_begin, PQ + (e) * QR, (PQ + ((e) + 1) * QR < NA ? PQ + ((e) + 1) * QR : NA), v)
+#define W3_HOOK1(e, v) W3_LOAD_A_RANGE(c_begin, (PQ + (NPV + (e)) * QR < NA ? PQ + (NPV + (e)) * QR : NA), (PQ + (NPV + (e) + 1) * QR < NA ? PQ + (NPV + (e) + 1) * QR : NA), v)
             float pv0[NPV], pv1[NPV];
             f32x2 cf0[NPL], cf1[NPL];
             W3_READ_C(c_begin, cf0)
             W3_READ_C(c_begin + 1, cf1)
-            W3_WRITE_PR(c_begin, pv0, cf0, "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192")
-            W3_WRITE_PR(c_begin + 1, pv1, cf1, "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202")
+            W3_WRITE_PR(c_begin, pv0, cf0, "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", W3_HOOK0)
+            W3_WRITE_PR(c_begin + 1, pv1, cf1, "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", W3_HOOK1)
+#undef W3_HOOK0
+#undef W3_HOOK1
             const float dep = pv0[0] + pv1[0];
             W3_LOAD_A_RANGE(c_begin, 0, PQ, dep)
         }
@@ -499,6 +531,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
     const long pix = (long)(oy0 + 2 * e_ty) * W + ox0 + 2 * e_tx;
     const bool fin = ksp == 1;                 // K split: bias, residual and scale are applied by the reduce kernel
     float* const ydst = fin ? a.y : a.part + (long)kh * a.B * a.Cout * HW;
+    // bias and residual of all 2 * COT tasks of the thread are requested up front: fetched where they are used, each sub-tile waited
+    // for two dependent memory latencies between its barriers and the epilogue took 7 k cycles, twice what its LDS traffic needs
+    // (profiles/r03_wino3_kloop_merged_vs_two_phase.txt: "epi")
+    float e_bias[COT][2];
+    f32x2 e_r0[COT][2], e_r1[COT][2];
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int co = co0 + ct * 32 + e_col0 + 16 * t2;
+            e_bias[ct][t2] = fin ? a.bias[co] : 0.0f;           // zero-padded to CoutP
+            e_r0[ct][t2] = e_r1[ct][t2] = f32x2{0.0f, 0.0f};
+            if (a.res && fin) {
+                const long o = ((long)e_b * a.Cout + min(co, a.Cout - 1)) * HW + pix;
+                e_r0[ct][t2] = *reinterpret_cast<const f32x2*>(a.res + o);
+                e_r1[ct][t2] = *reinterpret_cast<const f32x2*>(a.res + o + W);
+            }
+        }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the K loop is done with the LDS
     W3_STAMP(1)
 #pragma unroll
@@ -515,12 +565,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
         for (int t2 = 0; t2 < 2; ++t2) {
             const int e_col = e_col0 + 16 * t2;
             const int co = co0 + ct * 32 + e_col;
-            f32x2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
-            if (a.res && fin) {
-                const long o = ((long)e_b * a.Cout + min(co, a.Cout - 1)) * HW + pix;
-                r0 = *reinterpret_cast<const f32x2*>(a.res + o);
-                r1 = *reinterpret_cast<const f32x2*>(a.res + o + W);
-            }
+            const f32x2 r0 = e_r0[ct][t2], r1 = e_r1[ct][t2];
             float mm[16];
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) mm[xi] = sM[(xi * 32 + e_col) * T + e_tile];
@@ -532,7 +577,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
             }
             const float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
             const float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
-            const float bvv = fin ? a.bias[co] : 0.0f;          // zero-padded to CoutP
+            const float bvv = e_bias[ct][t2];
             const float osc = fin ? a.out_scale : 1.0f;
             const float v00 = (y00 + bvv + r0.x) * osc, v01 = (y01 + bvv + r0.y) * osc;
             const float v10 = (y10 + bvv + r1.x) * osc, v11 = (y11 + bvv + r1.y) * osc;
@@ -590,13 +635,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             d[0] = dt[0]; d[1] = dt[1]; d[2] = rt0; d[3] = __builtin_amdgcn_s_memrealtime();
             d[4] = ((unsigned long long)xcc << 32) | hwid;          // which CU ran it (gpu_diag.py w2htl: per-CU timeline)
-            if (sub) { d[2] = sp[0]; d[3] = sp[1]; d[4] = sp[2]; }   // MCVD_DBG_WAVE >= 64: prologue sub-phases (cycles from the start)
-#ifdef MCVD_DIAG
-            if (tsub) { d[0] = ts[0]; d[1] = ts[1]; d[2] = ts[2]; d[3] = ts[3]; d[4] = ts[4]; d[5] = ts[5]; d[7] = ts[6]; }
-#endif
             d[5] = now - tprev;            // epilogue
             d[6] = (unsigned long long)(c_end - c_begin);
             d[7] = now - tk0;
+            // MCVD_DBG_WAVE >= 64: prologue sub-phases instead (cycles from the start of the kernel): index arithmetic done, loads issued,
+            // coefficients + first patches landed, coefficient table visible, first two patches parked
+            if (sub) { d[1] = sp[3]; d[2] = sp[0]; d[3] = sp[1]; d[4] = sp[4]; d[5] = sp[2]; }
+#ifdef MCVD_DIAG
+            if (tsub) { d[0] = ts[0]; d[1] = ts[1]; d[2] = ts[2]; d[3] = ts[3]; d[4] = ts[4]; d[5] = ts[5]; d[7] = ts[6]; }
+#endif
         }
     }
 #undef W3_STAMP

@@ -83,6 +83,10 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(GnArgs a) {
 
 // One wave per (sample, group).  Partials (sum_i, M2_i, n_i) -> N = sum n_i, mean = sum sum_i / N,
 // M2 = sum (M2_i + n_i (sum_i / n_i - mean)^2): exact identities, every term non-negative (no cancellation).
+// The kernel is pure latency (a few hundred bytes per wave, 65 launches per forward): every global load -- the partials (kept in
+// registers for both passes, up to GF_KEEP per lane) and the affine parameters of the lane's channel -- is requested before the first
+// reduction, one memory round trip per launch instead of three.
+constexpr int GF_KEEP = 8;
 __global__ __launch_bounds__(64) void gn_finalize_kernel(GnArgs a, const float* st0, int np0, const float* st1, int np1) {
     const int C = a.C0 + a.C1;
     const int gs = C / a.groups;
@@ -97,18 +101,38 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnArgs a, const float* 
     auto part = [&](int i, float& sum, float& m2, float& n) {
         if (i < P0) {
             const int cl = i / np0, p = i - cl * np0;
-            const float* q = st0 + (((long)b * a.C0 + c0 + cl) * np0 + p) * 2;
-            sum = q[0]; m2 = q[1]; n = n0;
+            const float2 q = *reinterpret_cast<const float2*>(st0 + (((long)b * a.C0 + c0 + cl) * np0 + p) * 2);
+            sum = q.x; m2 = q.y; n = n0;
         } else {
             const int j = i - P0;
             const int cl = j / np1, p = j - cl * np1;
             const int c1 = max(c0, a.C0) - a.C0 + cl;
-            const float* q = st1 + (((long)b * a.C1 + c1) * np1 + p) * 2;
-            sum = q[0]; m2 = q[1]; n = n1;
+            const float2 q = *reinterpret_cast<const float2*>(st1 + (((long)b * a.C1 + c1) * np1 + p) * 2);
+            sum = q.x; m2 = q.y; n = n1;
         }
     };
+    float ks[GF_KEEP], km[GF_KEEP], kn[GF_KEEP];
+#pragma unroll
+    for (int k = 0; k < GF_KEEP; ++k) {
+        ks[k] = 0.0f; km[k] = 0.0f; kn[k] = 1.0f;
+        if (lane + 64 * k < P) part(lane + 64 * k, ks[k], km[k], kn[k]);
+    }
+    // affine parameters of channel c0 + lane (clamped: the loads are unconditional, the stores are not)
+    const int cpar = c0 + min(lane, gs - 1);
+    float par0 = 1.0f, par1 = 0.0f;
+    if (a.mode == 1) {                // (1 + scale) * norm + shift        layerspp.py:523,535
+        const float* e = a.p0 + (long)b * a.emb_stride + a.emb_off;
+        par0 = 1.0f + e[cpar];
+        par1 = e[C + cpar];
+    } else if (a.mode == 2) {         // weight * norm + bias              torch GroupNorm affine
+        par0 = a.p0[cpar];
+        par1 = a.p1[cpar];
+    }
     float tot = 0.0f;
-    for (int i = lane; i < P; i += 64) {
+#pragma unroll
+    for (int k = 0; k < GF_KEEP; ++k)
+        if (lane + 64 * k < P) tot += ks[k];
+    for (int i = lane + 64 * GF_KEEP; i < P; i += 64) {
         float sm, m2, n;
         part(i, sm, m2, n);
         tot += sm;
@@ -118,7 +142,13 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnArgs a, const float* 
     const float N = (float)gs * (float)a.HW;
     const float mean = tot / N;
     float acc = 0.0f;
-    for (int i = lane; i < P; i += 64) {
+#pragma unroll
+    for (int k = 0; k < GF_KEEP; ++k)
+        if (lane + 64 * k < P) {
+            const float d = ks[k] / kn[k] - mean;
+            acc += km[k] + kn[k] * d * d;
+        }
+    for (int i = lane + 64 * GF_KEEP; i < P; i += 64) {
         float sm, m2, n;
         part(i, sm, m2, n);
         const float d = sm / n - mean;
@@ -128,7 +158,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnArgs a, const float* 
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     const float var = acc / N;
     const float rstd = 1.0f / sqrtf(var + a.eps);
-    for (int cl = lane; cl < gs; cl += 64) {
+    if (lane < gs) {
+        reinterpret_cast<float2*>(a.coef)[(long)b * C + cpar] = make_float2(rstd * par0, par1 - mean * rstd * par0);
+    }
+    for (int cl = lane + 64; cl < gs; cl += 64) {       // (groups of more than 64 channels: not a shape of the reference's configs)
         const int c = c0 + cl;
         float A, Bc;
         if (a.mode == 1) {

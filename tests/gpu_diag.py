@@ -430,6 +430,36 @@ def w3sub(f):
     ctx.opt("conv_shape", -1)
 
 
+def w3pro(f):
+    """conv_wino3.cpp: where the prologue of a workgroup goes (MCVD_DBG_WAVE = 64 + wave: cycles from the start of the kernel at which
+    the index arithmetic is done, the loads are issued, coefficients + first patches have landed, the coefficient table is visible,
+    the first two patches are parked; then the whole prologue)."""
+    from tests.hiputil import Ctx, P
+    ctx = Ctx()
+    B = 64
+    for cin, cout, H in [(96, 96, 64), (192, 192, 32), (480, 192, 32), (384, 384, 8)]:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda")
+        ctx.opt("conv_shape", 10)
+        for wv in (0, 7):
+            os.environ["MCVD_DBG_WAVE"] = str(64 + wv)
+            dbg = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+            _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
+            ctx.conv2d(x, w, b, coef=coef, act=1, scale=0.7)
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
+            d = dbg.view(-1, 8).cpu().double()
+            d = d[d[:, 6] > 0]
+            m = d.mean(0)
+            f.write(f"cin{cin} cout{cout} H{H} wave {wv}: index math done {m[1]:6.0f} | loads issued {m[2]:6.0f} | landed {m[3]:6.0f} | coefficient table visible {m[4]:6.0f}"
+                    f" | patches parked {m[5]:6.0f} | prologue {m[0]:6.0f} | total {m[7]:7.0f} ({int(m[6])} chunks)\n")
+    os.environ["MCVD_DBG_WAVE"] = "0"
+    ctx.opt("conv_shape", -1)
+
+
 def hostloop(f):
     """What `verbose=True` / `log=True` cost: those kwargs (the reference's video_gen passes them, runners/ncsn_runner.py:1516-1519) take
     the host loop of samplers.py (one forward + one fused update per step driven from Python, the ten log lines computed with torch)
@@ -598,6 +628,6 @@ if __name__ == "__main__":
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "w3sub": w3sub, "hostloop": hostloop, "convops": convops, "sweep1": sweep1, "w2htl": w2htl, "w2hsub": w2hsub}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "w3sub": w3sub, "w3pro": w3pro, "hostloop": hostloop, "convops": convops, "sweep1": sweep1, "w2htl": w2htl, "w2hsub": w2hsub}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 

@@ -124,7 +124,7 @@ def _dest_untouched_covering(name, loop, problems):
             problems.append(f"{name}: no wait covers `{l}`")
 
 
-def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_per_cot=6, nloops=2, npatch=(3, 1), wreg0=184):
+def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_per_cot=6, nloops=2, npatch=(3, 1), wreg0=184, named0=172):
     """conv_wino3_kernel<COT, PRO, G8, 0> / conv_wino2h_kernel<COT, PRO, G8, 0>: every loop that holds MFMAs is a K loop; a K loop
     holds wl_per_cot * COT weight loads (NP pieces x 2 positions; destinations from register `wreg0` up) + npatch[G8] patch loads
     (destinations below `wreg0`)."""
@@ -208,13 +208,29 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_
                     break
         if kloops != nloops:
             problems.append(f"{name}: expected {nloops} K loop(s), found {kloops}")
+        # anywhere in the kernel (prologue and epilogue included): the registers from `named0` up are touched by the kernel's own asm
+        # statements only (the text between the compiler's #ASMSTART / #ASMEND markers) -- loads into them, the patch / coefficient
+        # reads and the MFMAs' A operands.  The register cap that keeps the allocator away from them (amdgpu_num_vgpr) is silently
+        # dropped when LLVM cannot honour it.
+        in_asm = False
+        for l in (x.strip() for x in body.split("\n")):
+            if l.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif l.startswith(";;#ASMEND"):
+                in_asm = False
+            ops = l.split(None, 1)
+            if in_asm or len(ops) < 2 or l.startswith((".", ";")):
+                continue
+            if max(_regs(ops[1].split(";")[0]) or {0}) >= named0:
+                problems.append(f"{name}: `{l}` (compiler-generated) touches a named register")
+                break
     if seen != expect:
         problems.append(f"expected {expect} instantiations of {kernel}<COT, PRO, ..., 0>, found {seen}")
     return problems
 
 
 def check2h(asm_text):
-    return check3(asm_text, kernel="18conv_wino2h_kernel", asm_mfma=True, expect=18, wl_per_cot=4, nloops=2, npatch=(6, 6), wreg0=208)      # x {8x16 regions, 8x8 images}; one loop per phase order
+    return check3(asm_text, kernel="18conv_wino2h_kernel", asm_mfma=True, expect=18, wl_per_cot=4, nloops=2, npatch=(6, 6), wreg0=208, named0=202)      # x {8x16 regions, 8x8 images}; one loop per phase order
 
 
 def main():

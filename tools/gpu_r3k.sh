@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 3, step k: prologue / epilogue latency fixes (wino3, wino2h, 1x1), gn_finalize in one round trip
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1; tail -1 gpurun_out/build.log
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no:cacheprovider -x -k "conv or gn or forward or sampler or determin or table" > gpurun_out/pytest_k.log 2>&1; tail -5 gpurun_out/pytest_k.log
+MCVD_LIB_PATH=$PWD/mcvd_pytorch_amd/libmcvd_hip_diag.so MCVD_WEXP_ONLY=0 MCVD_WEXP_CASES=1,2,3 timeout 600 python tests/gpu_diag.py w3exp > gpurun_out/w3exp.log 2>&1; cat gpurun_out/diag_w3exp.txt | cut -c1-240; tail -3 gpurun_out/w3exp.log
+timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_k.json 2> gpurun_out/bench_k.err; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_k.json'))
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], {k:(v['launches'],v['ms']) for k,v in d['roofline']['breakdown'].items()}, 'f16x2', d.get('f16x2_leg',{}).get('value'))
+PY
+tail -2 gpurun_out/bench_k.err
