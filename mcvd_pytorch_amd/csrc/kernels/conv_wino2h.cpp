@@ -240,8 +240,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
             }                                                                                                   \
         }                                                                                                       \
     }
-#define H2_WRITE_P(ch, PV, cfv) H2_WRITE_PR(ch, PV, cfv, "v202", "v203", "v204", "v205", "v206", "v207")
-#define H2_WRITE_PR(ch, PV, cfv, R0, R1, R2, R3, R4, R5)                                                        \
+#define H2_NOHOOK(e, v)
+#define H2_WRITE_P(ch, PV, cfv) H2_WRITE_PR(ch, PV, cfv, "v202", "v203", "v204", "v205", "v206", "v207", H2_NOHOOK)
+    /* HOOK(sl, v): statements placed behind value sl (the prologue issues its weight loads there, one at a time: conv_wino3.cpp) */ \
+#define H2_WRITE_PR(ch, PV, cfv, R0, R1, R2, R3, R4, R5, HOOK)                                                  \
     {                                                                                                           \
         float* sPw = sP + (((ch) & 1) ? PBUF : 0);                                                              \
         const int nvalid = Cin - (ch) * CK;                                                                     \
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
             float v = PV[sl];                                                                                   \
             if (PRO >= 2) v = silu_h2(v);                                                                       \
             sPw[p_pk[sl] & 0xfff] = ((int)((p_pk[sl] >> 12) & 0xff) < min(nvalid, CK)) ? v * H2_ACT_SCALE : 0.0f; \
+            HOOK(sl, v)                                                                                         \
         }                                                                                                       \
     }
     /* rows 2rg and 2rg+1 of B^T d for the two channels of the pair (packed fp32: .x = channel s_ca, .y = s_ca + 2), (.) B,      \
@@ -387,9 +390,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
                          :: "v"(co_src[0]), "v"(co_src[1]) : "memory");
         H2_LOAD_PR(c_begin, nodep, ofs, "v208", "v209", "v210", "v211", "v212", "v213")
         H2_LOAD_PR(c_begin + 1, nodep, ofs, "v214", "v215", "v216", "v217", "v218", "v219")
-        H2_LOAD_A_RANGE(c_begin, 3, NA, nodep)
         if (rec) sp[0] = __builtin_amdgcn_s_memtime() - tk0;      // loads issued
-        H2_WAIT(NA - 3)                    // the coefficients and the two patches have landed; younger: quads 3..
+        H2_WAIT(0)                         // the coefficients and the two patches have landed
         if (rec) sp[1] = __builtin_amdgcn_s_memtime() - tk0;      // first patches landed
         float cdep[MAXP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (PRO && !G8) {
@@ -408,8 +410,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
             f32x2 cf0[MAXP], cf1[MAXP];
             H2_READ_C(c_begin, cf0)
             H2_READ_C(c_begin + 1, cf1)
-            H2_WRITE_PR(c_begin, pv0, cf0, "v208", "v209", "v210", "v211", "v212", "v213")
-            H2_WRITE_PR(c_begin + 1, pv1, cf1, "v214", "v215", "v216", "v217", "v218", "v219")
+            // the weight quads 3.. of the first chunk are requested one behind each activated value (conv_wino3.cpp: in one burst they
+            // fill the CU's vector-memory queue and the waves sit in the issue instead of working on their patches)
+            constexpr int QR = (NA - 3 + 2 * MAXP - 1) / (2 * MAXP) > 0 ? (NA - 3 + 2 * MAXP - 1) / (2 * MAXP) : 1;       // quads per value
+#define H2_HOOKQ(j, v) { const float hd[MAXP] = {v, v, v, v, v, v}; H2_LOAD_A_RANGE(c_begin, (3 + (j) * QR < NA ? 3 + (j) * QR : NA), (3 + ((j) + 1) * QR < NA ? 3 + ((j) + 1) * QR : NA), hd) }
+#define H2_HOOK0(sl, v) H2_HOOKQ(sl, v)
+#define H2_HOOK1(sl, v) H2_HOOKQ(MAXP + (sl), v)
+            H2_WRITE_PR(c_begin, pv0, cf0, "v208", "v209", "v210", "v211", "v212", "v213", H2_HOOK0)
+            H2_WRITE_PR(c_begin + 1, pv1, cf1, "v214", "v215", "v216", "v217", "v218", "v219", H2_HOOK1)
+#undef H2_HOOK0
+#undef H2_HOOK1
+#undef H2_HOOKQ
             float dep[MAXP];
             _Pragma("unroll") for (int sl = 0; sl < MAXP; ++sl) dep[sl] = pv0[sl] + pv1[sl];
             H2_LOAD_A_RANGE(c_begin, 0, NA < 3 ? NA : 3, dep)
