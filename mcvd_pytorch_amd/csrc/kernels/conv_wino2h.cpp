@@ -202,6 +202,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         const unsigned* ua = wr_base + (long)(ch) * (16 * COT * 512) + (i) * (NQ * 256);                        \
         _Pragma("unroll") for (int qq = 0; qq < NQ; ++qq) { H2_QUADS(H2_LD1, (i) * NQ + qq, ua + qq * 256, 0) } \
     }
+    /* weight piece `pc` of every cout sub-tile of position 2w + i of chunk `ch` (quads 2 * (i * COT + ct) + pc) */
+#define H2_LOAD_A_PIECE(ch, i, pc)                                                                              \
+    {                                                                                                           \
+        const unsigned* ua = wr_base + (long)(ch) * (16 * COT * 512) + (i) * (NQ * 256);                        \
+        _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) { H2_QUADS(H2_LD1, (i) * NQ + 2 * ct + (pc), ua + (2 * ct + (pc)) * 256, 0) } \
+    }
     /* prologue: quads Q0 .. Q1-1 of chunk `ch`, issued behind the instructions that produced DEP (which read the registers) */
 #define H2_LD1D(K, R, q, P, DEP) if ((q) == K) asm volatile("global_load_dwordx4 " R ", %0, %1" :: "v"(wr_voff), "s"(P), "v"(DEP[0]), "v"(DEP[1]), "v"(DEP[2]), "v"(DEP[3]), "v"(DEP[4]), "v"(DEP[5]) : "memory");
 #define H2_LOAD_A_RANGE(ch, Q0, Q1, DEP)                                                                        \
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         }                                                                                                       \
     }
     /* all MFMAs of chunk `ch` (V(ch) in LDS, weights(ch) in the named registers).  Per position 2w + i: wait for its NQ quads, 3*COT  \
-       MFMAs ordered piece-major (u1 v2, u2 v1, u1 v1: smallest first; consecutive MFMAs write different accumulators), then -- NEXT  \
+       MFMAs ordered piece-major (u2 v1, u1 v2, u1 v1: smallest class first; consecutive MFMAs write different accumulators), and -- NEXT \
        -- the same NQ quads are reloaded for chunk ch+1 (the matrix pipe has read its A operands by the time the wave gets past the   \
        MFMA: it issues in order).  In-order VMEM bookkeeping: when the quads of a position are needed, the loads issued after them    \
        are the other position's NQ quads and one patch group: vmcnt(NQ + MAXP), in both phase orders. */                              \
@@ -310,14 +316,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
             if (NEXT && !(EXP & 4)) H2_WAIT(VM_A)                                                               \
             if (!(EXP & 16)) {                                                                                  \
-                _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) { H2_QUADS(H2_MF1, 2 * (i * COT + ct), acc[i][ct], bq[i][1]) }      \
+                /* u2 v1 first: the second weight piece is re-requested for chunk ch+1 right behind its only product, the first     \
+                   piece behind the last one (conv_wino3.cpp: all quads in one burst stall the wave in the issue) */                 \
                 _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) { H2_QUADS(H2_MF1, 2 * (i * COT + ct) + 1, acc[i][ct], bq[i][0]) }  \
+                if (NEXT && !(EXP & 4)) H2_LOAD_A_PIECE((ch) + 1, i, 1)                                         \
+                _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) { H2_QUADS(H2_MF1, 2 * (i * COT + ct), acc[i][ct], bq[i][1]) }      \
                 _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) { H2_QUADS(H2_MF1, 2 * (i * COT + ct), acc[i][ct], bq[i][0]) }      \
+                if (NEXT && !(EXP & 4)) H2_LOAD_A_PIECE((ch) + 1, i, 0)                                         \
             } else {                                                                                            \
                 _Pragma("unroll") for (int ct = 0; ct < COT; ++ct)                                              \
                     acc[i][ct][0] += __builtin_bit_cast(float, bq[i][0][0] ^ bq[i][1][1] ^ bq[i][0][2] ^ bq[i][1][3]); \
+                if (NEXT && !(EXP & 4)) H2_LOAD_A((ch) + 1, i)                                                  \
             }                                                                                                   \
-            if (NEXT && !(EXP & 4)) H2_LOAD_A((ch) + 1, i)                                                      \
         }                                                                                                       \
     }
     /* patch of chunk ch+2 -> LDS, raw patch of chunk ch+3 requested, V(ch+1) -> LDS */
@@ -590,6 +600,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(202))) void con
     }
 #undef H2_STAMP
 #undef H2_LOAD_A
+#undef H2_LOAD_A_PIECE
 #undef H2_QUADS
 #undef H2_LD1
 #undef H2_MF1

@@ -216,6 +216,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
         const unsigned* ua = wr_base + (long)(ch) * (16 * NQ * 256) + (i) * (NQ * 256);                         \
         _Pragma("unroll") for (int qq = 0; qq < NQ; ++qq) { W3_QUADS(W3_LD1, (i) * NQ + qq, ua + qq * 256, 0) } \
     }
+    /* weight piece `pc` of every cout sub-tile of position 2w + i of chunk `ch` (quads (i * COT + ct) * 3 + pc) */            \
+#define W3_LOAD_A_PIECE(ch, i, pc)                                                                              \
+    {                                                                                                           \
+        const unsigned* ua = wr_base + (long)(ch) * (16 * NQ * 256) + (i) * (NQ * 256);                         \
+        _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) { W3_QUADS(W3_LD1, (i) * NQ + ct * 3 + (pc), ua + (ct * 3 + (pc)) * 256, 0) } \
+    }
     /* prologue: quads Q0 .. Q1-1 of chunk `ch`, issued behind the instructions that produced DEP (which read the registers) */
 #define W3_LD1D(K, R, q, P, DEP) if ((q) == K) asm volatile("global_load_dwordx4 " R ", %0, %1" :: "v"(wr_voff), "s"(P), "v"(DEP) : "memory");
 #define W3_LOAD_A_RANGE(ch, Q0, Q1, DEP)                                                                        \
@@ -325,8 +331,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
 #define W3_PRODUCT(i, PA, PB)                                                                                   \
     { _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) { W3_QUADS(W3_MF1, 3 * ((i) * COT + ct) + (PA), acc[i][ct], bq[i][PB]) } }
     /* all MFMAs of chunk `ch` (V(ch) in LDS, weights(ch) in the named registers).  Per position 2w + i: wait for its NQ quads, 6*COT  \
-       MFMAs ordered product-major (u1 v3, u3 v1, u2 v2, u1 v2, u2 v1, u1 v1: smallest first; consecutive MFMAs write different       \
-       accumulators), then -- NEXT -- the same NQ quads are reloaded for chunk ch+1 (the matrix pipe has read its A operands by the     \
+       MFMAs ordered product-major (u3 v1, u2 v2, u1 v3, u2 v1, u1 v2, u1 v1: smallest class first; consecutive MFMAs write different \
+       accumulators), and -- NEXT -- the same NQ quads are reloaded for chunk ch+1 piece by piece (the matrix pipe has read its A operands by the     \
        time the wave gets past the MFMA: it issues in order).  In-order VMEM bookkeeping: when the quads of a position are needed, the \
        loads issued after them are the other position's NQ quads and one patch group: vmcnt(NQ + NPL), in both phase orders. */      \
 #define W3_MFMA_PHASE(ch, NEXT)                                                                                 \
@@ -339,13 +345,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
             if (NEXT && !(EXP & 4)) W3_WAIT(VM_A)                                                               \
             if (!(EXP & 16)) {                                                                                  \
-                W3_PRODUCT(i, 0, 2) W3_PRODUCT(i, 2, 0) W3_PRODUCT(i, 1, 1)                                     \
-                W3_PRODUCT(i, 0, 1) W3_PRODUCT(i, 1, 0) W3_PRODUCT(i, 0, 0)                                     \
+                /* a weight piece is re-requested for chunk ch+1 as soon as its LAST product has been issued: u3 behind the first    \
+                   product, u2 behind the fourth, u1 behind the sixth -- three requests at a time, spread over the position's 576   \
+                   cycles of matrix work (nine in one burst stall the wave in the issue: the CU's vector-memory path is 70 % busy) */ \
+                W3_PRODUCT(i, 2, 0)                                                                             \
+                if (NEXT && !(EXP & 4)) W3_LOAD_A_PIECE((ch) + 1, i, 2)                                         \
+                W3_PRODUCT(i, 1, 1) W3_PRODUCT(i, 0, 2) W3_PRODUCT(i, 1, 0)                                     \
+                if (NEXT && !(EXP & 4)) W3_LOAD_A_PIECE((ch) + 1, i, 1)                                         \
+                W3_PRODUCT(i, 0, 1) W3_PRODUCT(i, 0, 0)                                                         \
+                if (NEXT && !(EXP & 4)) W3_LOAD_A_PIECE((ch) + 1, i, 0)                                         \
             } else {                                                                                            \
                 _Pragma("unroll") for (int ct = 0; ct < COT; ++ct)                                              \
                     acc[i][ct][0] += __builtin_bit_cast(float, bq[i][0][0] ^ bq[i][1][1] ^ bq[i][2][2] ^ bq[i][1][3]); \
+                if (NEXT && !(EXP & 4)) W3_LOAD_A((ch) + 1, i)                                                  \
             }                                                                                                   \
-            if (NEXT && !(EXP & 4)) W3_LOAD_A((ch) + 1, i)                                                      \
             W3_TS(4 + i)                                                                                        \
         }                                                                                                       \
     }
@@ -649,6 +662,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
 #undef W3_STAMP
 #undef W3_TS
 #undef W3_LOAD_A
+#undef W3_LOAD_A_PIECE
 #undef W3_QUADS
 #undef W3_LD1
 #undef W3_MF1
