@@ -120,10 +120,15 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         mcvd_sampler_run presents the same set on every step.  Any option change, re-tune, workspace growth or mcvd_model_finalize
  *         drops the captured graph.  Also MCVD_GRAPH=1 in the environment at mcvd_ctx_create.
  *     "gn_stats" (1): GroupNorm statistics come out of the producing conv's epilogue where the kernel supports it (0: always one pass
- *         over the normalised tensor).  "spade_fuse" (0): 1 = the SPADE modulation inside the fp32 Winograd conv loader (gamma | beta by
+ *         over the normalised tensor).  "gn_inline" (0): 1 = where every source of a norm has at most 8 partial statistics per channel (32x32 and
+ *         smaller layers) AND the consuming conv launch has at most "gn_inline_max_wg" workgroups (default: two per CU) the conv reduces them
+ *         in its own prologue and no finalize kernel is launched for that norm (kernels/gn_inline.h, mcvd_model_gn_inlined).  Off by
+ *         default: the finalize launches it spares (2.4 % of the GPU time by their durations) overlap with their neighbours inside the
+ *         graph, the redundant reduction in every workgroup does not -- measured 0.3-1 % slower on every config
+ *         (profiles/r03_gn_inline_ab.txt).  "spade_fuse" (0): 1 = the SPADE modulation inside the fp32 Winograd conv loader (gamma | beta by
  *         LDS-DMA; measured 3.5 % slower end to end than the materialising spade_apply kernel).  "side_stream" (0): ResBlock shortcut
  *         convs on a second HIP stream (measured slower).  "profile" (0/1): see mcvd_model_profile_read.
- * Environment variables read ONCE at mcvd_ctx_create set the same options: MCVD_AUTOTUNE, MCVD_SIDE_STREAM, MCVD_WINOGRAD, MCVD_CONV_DMA1,
+ * Environment variables read ONCE at mcvd_ctx_create set the same options: MCVD_AUTOTUNE, MCVD_SIDE_STREAM, MCVD_WINOGRAD, MCVD_CONV_DMA1, MCVD_GN_INLINE,
  * MCVD_BF16X3, MCVD_F16X2, MCVD_GRAPH, MCVD_GN_STATS, MCVD_SPADE_FUSE, MCVD_NAIVE.  Nothing else in the production library reads the
  * environment (the diagnostics build, csrc/build.py --diag, adds timing-only ablation hooks). */
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value);
@@ -225,6 +230,12 @@ int mcvd_model_op_info(mcvd_model* m, int i, int info[8]);
  * 15 three-piece bf16 1x1 GEMM; -2 the one-thread-per-output test kernel); -1 for an op that is not a conv or never ran.  Tests
  * use it to assert that a forced or imported kernel table is what executed (a graph replay re-runs what its capture recorded). */
 int mcvd_model_op_kernel(mcvd_model* m, int i);
+
+/* How many GroupNorm finalize launches this model has NOT made so far because the consuming conv reduced the producers' partial
+ * statistics in its own prologue (ctx option "gn_inline", default 0; csrc/kernels/gn_inline.h): a running total over the eager
+ * forwards and graph captures of the model (a graph replay re-runs what its capture recorded).  Tests use it to assert that the
+ * fused path really ran; -1 for a NULL model. */
+long mcvd_model_gn_inlined(mcvd_model* m);
 
 /* Debug/test aid: copy the output tensor of reference module `module` (index in all_modules, ncsnpp_more.py:249) from the
  * last forward at batch size B into dst_device ([B, C, H, H], capacity in floats).  The workspace keeps every intermediate of a

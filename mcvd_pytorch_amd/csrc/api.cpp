@@ -43,6 +43,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     mcvd_ctx* c = new mcvd_ctx();
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
+    c->gn_inline_max_wg = 2 * prop.multiProcessorCount;
     if (const char* t = getenv("MCVD_AUTOTUNE")) c->autotune = atoi(t);
     if (const char* t = getenv("MCVD_SIDE_STREAM")) c->side_stream = atoi(t);
     if (const char* t = getenv("MCVD_WINOGRAD")) c->winograd = atoi(t);
@@ -51,6 +52,7 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     if (const char* t = getenv("MCVD_F16X2")) c->f16x2 = atoi(t);
     if (const char* t = getenv("MCVD_GRAPH")) c->graph = atoi(t);
     if (const char* t = getenv("MCVD_GN_STATS")) c->gn_stats = atoi(t);
+    if (const char* t = getenv("MCVD_GN_INLINE")) c->gn_inline = atoi(t);
     if (const char* t = getenv("MCVD_SPADE_FUSE")) c->spade_fuse = atoi(t);
     const char* e = getenv("MCVD_NAIVE");
     if (e) {
@@ -132,6 +134,8 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "f16x2")) ctx->f16x2 = value;
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
     else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
+    else if (!strcmp(key, "gn_inline")) ctx->gn_inline = value;
+    else if (!strcmp(key, "gn_inline_max_wg")) ctx->gn_inline_max_wg = value;
     else if (!strcmp(key, "spade_fuse")) ctx->spade_fuse = value;
     else {
         set_error("unknown option '%s'", key);
@@ -553,6 +557,8 @@ int mcvd_model_op_kernel(mcvd_model* m, int i) {
     if (!m || i < 0 || i >= (int)m->ops.size() || m->ops[i].kind != OP_CONV || (size_t)i >= m->ran_kernel.size()) return -1;
     return m->ran_kernel[i];
 }
+
+long mcvd_model_gn_inlined(mcvd_model* m) { return m ? m->gn_inlined_total : -1; }
 
 int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst, int64_t capacity, int* C, int* H) {
     MCVD_REQUIRE(m && dst && B > 0 && B <= m->arena_B, "module_output: run a forward at batch >= B first");

@@ -5,6 +5,8 @@
 #include <atomic>
 #include <string>
 
+#include "kernels/gn_inline.h"
+
 namespace mcvd {
 
 void set_error(const char* fmt, ...);
@@ -89,7 +91,12 @@ struct ConvArgs {
     // (1 + scale, shift) [B][Cin][2] (may be null); requires coef (plain GroupNorm coefficients) and act
     const float* gb;
     const float* coef2;
+    // GroupNorm coefficients computed by this conv from the producers' partial statistics (kernels/gn_inline.h): gni.st0 != NULL
+    // replaces `coef` (which must still be non-null: it selects the affine prologue).  Only the launches conv_takes_gn_inline()
+    // accepts (the three-piece bf16 Winograd and 1x1 kernels) may carry it.
+    GnInline gni;
 };
+bool conv_takes_gn_inline(const ConvArgs& a, int max_wg);   // the kernel launch_conv_mfma(a) dispatches to reduces the partials itself (and has <= max_wg workgroups)
 void set_last_conv_stats_np(int np);          // (launchers)
 int last_conv_stats_np();                     // partials per (sample, channel) the thread's last conv launch wrote to a.stats; 0 = none
 int conv_cout_tile(int Cout);                 // 32-channel units per block along Cout

@@ -547,8 +547,16 @@ int mcvd_model::build_plan() {
             }
         }
     }
+    // consumers of GroupNorm coefficients: which norm of the plan wrote the table they read (the latest one before them)
+    for (size_t ci = 0; ci < ops.size(); ++ci) {
+        Op& c = ops[ci];
+        if ((c.kind != OP_CONV && c.kind != OP_FIR && c.kind != OP_APPLY) || c.coef.kind != REF_ARENA) continue;
+        for (size_t gi = 0; gi < ci; ++gi)
+            if (ops[gi].kind == OP_GN && ops[gi].coef.kind == REF_ARENA && ops[gi].coef.off == c.coef.off) c.gn_src = (int)gi;
+    }
     arena_per_sample = bld.arena;
     stats_np.assign(ops.size(), 0);
+    gn_deferred.assign(ops.size(), 0);
     if (c.noise_in_cond) {            // gamma/beta depend on the noised conditioning frames: nothing can be hoisted out of the step
         for (Op& op : ops) op.prep = false;
         has_prep = false;
@@ -599,6 +607,58 @@ float* mcvd_model::resolve(const TRef& r, const float* x, const float* cond, flo
     }
 }
 
+// GroupNorm -> (A, B).  Statistics already computed by the producers' epilogues (every source must have them) are finalized by a
+// small kernel -- or not launched at all (may_defer): where every source has at most GN_INLINE_MAX_NP partials per channel the
+// consumers reduce them in their own prologue (conv_takes_gn_inline); a consumer that cannot calls ensure_coef, which launches the
+// kernel late.  Without producer statistics: one pass over the tensor.
+int mcvd_model::launch_gn(const Op& op, const float* x, const void* lab, const float* cond, float* out, int B, bool may_defer) {
+    hipStream_t s = op_stream ? op_stream : ctx->stream;
+    const size_t gi = (size_t)(&op - ops.data());
+    GnArgs a{};
+    a.x0 = resolve(op.src0, x, cond, out, B);
+    a.x1 = resolve(op.src1, x, cond, out, B);
+    a.C0 = op.src0.C;
+    a.C1 = op.src1.kind == REF_NONE ? 0 : op.src1.C;
+    a.groups = op.groups;
+    a.eps = op.eps;
+    a.mode = op.gn_mode;
+    if (op.gn_mode == 1) {
+        a.p0 = resolve(ops[1].dst, x, cond, out, B);
+        a.emb_stride = (uniform_labels && !d.cond_emb) ? 0 : NE;
+        a.emb_off = op.emb_off;
+    } else if (op.gn_mode == 2) {
+        a.p0 = blob + op.p0;
+        a.p1 = blob + op.p1;
+    }
+    a.coef = resolve(op.coef, x, cond, out, B);
+    a.B = B;
+    a.HW = op.H * op.W;
+    const int np0 = op.prod0 >= 0 ? stats_np[op.prod0] : 0;
+    const int np1 = a.C1 == 0 ? 1 : (op.prod1 >= 0 ? stats_np[op.prod1] : 0);
+    if (gn_deferred.size() != ops.size()) gn_deferred.assign(ops.size(), 0);
+    gn_deferred[gi] = 0;
+    if (ctx->gn_stats && np0 > 0 && np1 > 0) {
+        if (may_defer && ctx->gn_inline && np0 <= GN_INLINE_MAX_NP && np1 <= GN_INLINE_MAX_NP) {
+            bool has_consumer = false;
+            for (size_t ci = gi + 1; ci < ops.size() && !has_consumer; ++ci) has_consumer = ops[ci].gn_src == (int)gi;
+            if (has_consumer) {
+                gn_deferred[gi] = 1;
+                ++gn_inlined_total;
+                return 0;
+            }
+        }
+        return launch_gn_finalize(a, resolve(ops[op.prod0].stats, x, cond, out, B), np0,
+                                  a.C1 ? resolve(ops[op.prod1].stats, x, cond, out, B) : nullptr, np1, s);
+    }
+    return launch_gn_coef(a, s);
+}
+
+int mcvd_model::ensure_coef(int gn_index, const float* x, const void* lab, const float* cond, float* out, int B) {
+    if (gn_index < 0 || (size_t)gn_index >= gn_deferred.size() || !gn_deferred[gn_index]) return 0;
+    --gn_inlined_total;
+    return launch_gn(ops[gn_index], x, lab, cond, out, B, false);       // (clears the flag)
+}
+
 int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const float* cond, float* out, int B) {
     hipStream_t s = op_stream ? op_stream : ctx->stream;
     switch (op.kind) {
@@ -615,34 +675,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
         case OP_DENSE:
             return launch_dense_all(resolve(op.src0, x, cond, out, B), packed + dense_wt, packed + dense_bias,
                                     resolve(op.dst, x, cond, out, B), (uniform_labels && !d.cond_emb) ? 1 : B, T, NE, s);
-        case OP_GN: {
-            GnArgs a{};
-            a.x0 = resolve(op.src0, x, cond, out, B);
-            a.x1 = resolve(op.src1, x, cond, out, B);
-            a.C0 = op.src0.C;
-            a.C1 = op.src1.kind == REF_NONE ? 0 : op.src1.C;
-            a.groups = op.groups;
-            a.eps = op.eps;
-            a.mode = op.gn_mode;
-            if (op.gn_mode == 1) {
-                a.p0 = resolve(ops[1].dst, x, cond, out, B);
-                a.emb_stride = (uniform_labels && !d.cond_emb) ? 0 : NE;
-                a.emb_off = op.emb_off;
-            } else if (op.gn_mode == 2) {
-                a.p0 = blob + op.p0;
-                a.p1 = blob + op.p1;
-            }
-            a.coef = resolve(op.coef, x, cond, out, B);
-            a.B = B;
-            a.HW = op.H * op.W;
-            // statistics already computed by the producers' epilogues (every source must have them), else one pass over the tensor
-            const int np0 = op.prod0 >= 0 ? stats_np[op.prod0] : 0;
-            const int np1 = a.C1 == 0 ? 1 : (op.prod1 >= 0 ? stats_np[op.prod1] : 0);
-            if (ctx->gn_stats && np0 > 0 && np1 > 0)
-                return launch_gn_finalize(a, resolve(ops[op.prod0].stats, x, cond, out, B), np0,
-                                          a.C1 ? resolve(ops[op.prod1].stats, x, cond, out, B) : nullptr, np1, s);
-            return launch_gn_coef(a, s);
-        }
+        case OP_GN:
+            return launch_gn(op, x, lab, cond, out, B, true);
         case OP_CONV: {
             ConvArgs a{};
             a.x0 = resolve(op.src0, x, cond, out, B);
@@ -696,6 +730,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             }
             // epilogue statistics from the 3x3 (Winograd) producers; the 1x1 GEMM's epilogue can emit them too, but its 16*COT
             // 32-lane reductions per wave cost the NIN_3 launches more than the norms they spare save (measured): "gn_stats" = 2 only
+            if (op.gb.kind != REF_NONE && op.gn_src >= 0)       // SPADE: spade_apply / the fused loader read the table
+                if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
             if (op.gb.kind != REF_NONE) {
                 // SPADE norm in front of this conv: fused into the Winograd loader where that kernel takes the launch, otherwise
                 // spade_apply materialises silu(((A x + B)(1 + gamma) + beta) s1 + b2) and the conv reads it plainly
@@ -717,6 +753,31 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             // (the split-operand 1x1 GEMM emits them cheaply from its transposed epilogue: shape ids 14 / 15)
             a.stats = (ctx->gn_stats && op.stats.kind != REF_NONE && !ctx->naive_conv && (op.ks == 3 || ctx->gn_stats >= 2 || a.shape_hint == 14 || a.shape_hint == 15))
                           ? resolve(op.stats, x, cond, out, B) : nullptr;
+            if (op.gn_src >= 0 && gn_deferred[op.gn_src]) {
+                // the norm in front of this conv was not launched: this kernel reduces the producers' partials itself -- or, if the
+                // launch goes to a kernel that cannot, the table is written now
+                const Op& g = ops[op.gn_src];
+                ConvArgs t = a;
+                if (!ctx->naive_conv && a.gb == nullptr && conv_takes_gn_inline(t, ctx->gn_inline_max_wg)) {
+                    a.gni.st0 = resolve(ops[g.prod0].stats, x, cond, out, B);
+                    a.gni.np0 = stats_np[g.prod0];
+                    a.gni.st1 = a.C1 ? resolve(ops[g.prod1].stats, x, cond, out, B) : nullptr;
+                    a.gni.np1 = a.C1 ? stats_np[g.prod1] : 1;
+                    a.gni.groups = g.groups;
+                    a.gni.eps = g.eps;
+                    a.gni.mode = g.gn_mode;
+                    if (g.gn_mode == 1) {
+                        a.gni.p0 = resolve(ops[1].dst, x, cond, out, B);
+                        a.gni.emb_stride = (uniform_labels && !d.cond_emb) ? 0 : NE;
+                        a.gni.emb_off = g.emb_off;
+                    } else if (g.gn_mode == 2) {
+                        a.gni.p0 = blob + g.p0;
+                        a.gni.p1 = blob + g.p1;
+                    }
+                } else if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) {
+                    return rc;
+                }
+            }
             if (ran_kernel.size() != ops.size()) ran_kernel.assign(ops.size(), -1);
             if (ctx->naive_conv) {
                 stats_np[oi] = 0;
@@ -729,6 +790,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             return rc;
         }
         case OP_FIR: {
+            if (op.gn_src >= 0)
+                if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
             const float* gb = op.gb.kind == REF_NONE ? nullptr : resolve(op.gb, x, cond, out, B);
             return launch_fir2(resolve(op.src0, x, cond, out, B),
                                op.coef.kind == REF_NONE ? nullptr : resolve(op.coef, x, cond, out, B), op.act, op.up,
@@ -774,6 +837,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             return launch_coef2(resolve(ops[1].dst, x, cond, out, B), (uniform_labels && !d.cond_emb) ? 0 : NE, op.emb_off,
                                 resolve(op.dst, x, cond, out, B), B, op.Cout, s);
         case OP_APPLY:
+            if (op.gn_src >= 0)
+                if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
             return launch_spade_apply(resolve(op.src0, x, cond, out, B), op.src0.C, resolve(op.src1, x, cond, out, B),
                                       op.src1.kind == REF_NONE ? 0 : op.src1.C, resolve(op.coef, x, cond, out, B),
                                       resolve(op.gb, x, cond, out, B),

@@ -35,6 +35,10 @@ struct mcvd_ctx {
     int spade_fuse = 0;            // 1: SPADE modulation inside the Winograd conv loader (gamma | beta by LDS-DMA); 0: through spade_apply.
                                    //    Off by default: measured 3.5 % SLOWER end to end (profiles/r02_spade_fusion_ab.txt)
     int gn_stats = 1;              // GroupNorm statistics from the producing conv's epilogue (0: always one pass over the tensor)
+    int gn_inline = 0;             // 1: a conv whose kernel can (conv_takes_gn_inline) reduces those partial statistics itself where a channel has
+                                   //    at most GN_INLINE_MAX_NP of them: no gn_finalize launch for that norm (kernels/gn_inline.h).  Off by default:
+                                   //    measured 0.3-1 % SLOWER end to end on every config (profiles/r03_gn_inline_ab.txt)
+    int gn_inline_max_wg = 0;      // ... and the conv launch has at most this many workgroups (mcvd_ctx_create: two rounds of the device's CUs)
     int autotune = 1;              // time the conv tile candidates per distinct layer shape on first use of a batch size
     int profile = 0;               // record HIP events around every op of the first forward of each sampler call
     unsigned long long* dbg = nullptr;   // conv phase-timing buffer for mcvd_op_conv2d (diagnostics)
@@ -105,6 +109,7 @@ struct Op {
     // GroupNorm op names the plan ops that produce its sources (-1: not a conv of this plan)
     TRef stats;
     int prod0 = -1, prod1 = -1;
+    int gn_src = -1;               // consumers of GroupNorm coefficients (conv, FIR, SPADE apply): the plan's OP_GN that computes `coef`
 };
 
 struct DenseEntry {
@@ -172,6 +177,11 @@ struct mcvd_model {
 
     // conv tile choice per op for the batch size it was tuned at: (shape, cot); filled by autotune()
     std::vector<int> stats_np;        // per op: partials per (sample, channel) its last launch wrote (0: none)
+    std::vector<signed char> gn_deferred;   // per OP_GN of the forward in flight: 1 = not launched, its consumers reduce the partials
+                                      //    themselves (or launch it late, the first that cannot): launch_op / ensure_coef
+    long gn_inlined_total = 0;        // norms that never needed a launch (diagnostics: mcvd_model_stat)
+    int launch_gn(const mcvd::Op& op, const float* x, const void* labels, const float* cond, float* out, int B, bool may_defer);
+    int ensure_coef(int gn_index, const float* x, const void* labels, const float* cond, float* out, int B);
     std::vector<int> ran_kernel;      // per conv op: the kernel family its last launch REALLY ran (last_conv_kernel(); -2 the naive kernel,
                                       //    -1 never launched): what mcvd_model_op_kernel reports
     std::vector<int> tuned_shape, tuned_cot;

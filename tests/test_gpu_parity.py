@@ -549,6 +549,34 @@ def test_gn_statistics_paths_agree_on_a_forward():
     assert not torch.equal(a, b)
 
 
+@pytest.mark.parametrize("cfg,B", [("smmnist_big5", 2), ("smmnist_big5_ngf96", 3), ("tiny", 2)])
+def test_gn_coefficients_from_the_consumer_agree_with_the_finalize_launch(cfg, B):
+    """"gn_inline" = 1 (opt-in: measured slower): the consuming conv reduces the producers' partial statistics itself wherever a channel has
+    at most eight of them; default: one gn_finalize launch per norm.  Same eps to fp32 rounding (the two merge the same partials in a
+    different association), the fused path really runs (mcvd_model_gn_inlined counts the launches it spared) and is bit-stable;
+    both against the oracle.  B = 3: the 8x8 layers' workgroups hold two samples, the last one clamps."""
+    from mcvd_pytorch_amd import _lib
+    config, sd, net = _net(cfg)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = torch.tensor([990, 130, 55][:B]).cuda()
+    net.set_option("gn_inline", 1)
+    n0 = _lib.lib.mcvd_model_gn_inlined(net._model)
+    a = net(x.cuda(), t, cond=cond.cuda()).clone()
+    n1 = _lib.lib.mcvd_model_gn_inlined(net._model)
+    a2 = net(x.cuda(), t, cond=cond.cuda()).clone()
+    net.set_option("gn_inline", 0)
+    b = net(x.cuda(), t, cond=cond.cuda()).clone()
+    n2 = _lib.lib.mcvd_model_gn_inlined(net._model)
+    assert n1 - n0 >= 8, f"only {n1 - n0} norms were computed by their consumers"
+    assert n2 - n1 == n1 - n0                      # (second fused forward counted, the unfused one adds nothing)
+    assert torch.equal(a, a2)
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t.cpu(), cond)
+    assert (a.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert (b.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,C,heads,H", [(2, 64, 2, 8), (2, 192, 2, 32), (3, 288, 3, 16), (2, 384, 4, 8), (2, 256, 2, 16),
                                          (1, 64, 1, 16),
