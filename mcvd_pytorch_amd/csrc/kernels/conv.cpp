@@ -15,10 +15,12 @@ int conv_cout_tile(int Cout) {
 
 int conv_chunk(int ks) { return ks == 3 ? 16 : 32; }   // packing granule of Cin (the largest chunk any tile shape uses)
 
-static int env_int(const char* name, int dflt) {
+#ifdef MCVD_DIAG
+static int env_int(const char* name, int dflt) {      // diagnostics build only: the product library reads no environment on a launch path
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
+#endif
 
 // which kernel family the last launch_conv_mfma of this thread dispatched to (tests assert a forced shape did not fall back
 // silently): 0..3 direct implicit GEMM tile shapes, 4 Winograd, 8 Winograd + K split, 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels),
@@ -37,8 +39,13 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     g_last_stats_np = 0;
     MCVD_REQUIRE(a.ks == 1 || a.ks == 3, "conv: kernel size %d unsupported", a.ks);
     MCVD_REQUIRE(a.W >= 8 && (a.W & (a.W - 1)) == 0 && a.W <= 256, "conv: W=%d must be a power of two in [8,256]", a.W);
-    static const int forced = env_int("MCVD_CONV_SHAPE", -1);
+#ifdef MCVD_DIAG
+    static const int forced = env_int("MCVD_CONV_SHAPE", -1);             // tile-heuristic experiments (tests/gpu_diag.py)
     static const int min_blocks = env_int("MCVD_CONV_MIN_BLOCKS", 400);
+#else
+    constexpr int forced = -1;              // (the "conv_shape" context option forces a kernel family; this is the direct kernel's tile)
+    constexpr int min_blocks = 400;
+#endif
     const long px = (long)a.B * a.H * a.W;
     const int ntc = a.CoutP / (32 * (a.cot > 0 ? a.cot : 1));
     auto blocks = [&](int bpx) { return ((px + bpx - 1) / bpx) * ntc; };

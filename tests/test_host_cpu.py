@@ -24,6 +24,27 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
 
 
+def test_product_library_has_no_diagnostics_hooks():
+    """The timing-only ablation kernels (wrong results by design) and every environment variable that selects them or truncates a
+    sampler exist in the diagnostics build only (csrc/build.py --diag, -DMCVD_DIAG): none of their names is in libmcvd_hip.so, and
+    the only getenv calls of the library are the option defaults read once in mcvd_ctx_create (api.cpp)."""
+    from mcvd_pytorch_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"MCVD_WINO_EXP", b"MCVD_WINO2H_EXP", b"MCVD_WINO3_EXP", b"MCVD_Q1_EXP", b"MCVD_DBG_WAVE", b"MCVD_FPNDM_MAXSTEPS",
+                 b"MCVD_CONV_SHAPE", b"MCVD_CONV_MIN_BLOCKS", b"MCVD_Q1_OCC"):
+        assert name not in blob, name
+    src = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc")
+    for dirpath, _, files in os.walk(src):
+        for f in files:
+            if not f.endswith((".cpp", ".h")) or "build" in dirpath:
+                continue
+            text = open(os.path.join(dirpath, f)).read()
+            # strip the diagnostics-only regions
+            text = re.sub(r"#ifdef MCVD_DIAG.*?#(?:else|endif)", "", text, flags=re.S)
+            if f != "api.cpp":
+                assert "getenv(" not in text, f"{f}: getenv outside #ifdef MCVD_DIAG"
+
+
 def test_no_gpu_fails_loudly():
     from mcvd_pytorch_amd import _lib
     if torch.cuda.is_available():
