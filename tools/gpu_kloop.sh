@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, step n: K-loop variants of conv_wino3 (cycles per chunk) + quick parity + bench
+# conv parity subset, K-loop cycles of conv_wino3 (diagnostics build), bench without the f16x2 leg -- the loop while tuning the kernel
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1; tail -1 gpurun_out/build.log
