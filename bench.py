@@ -369,8 +369,21 @@ def main():
             dt = max(per_rank)
         assert torch.isfinite(frames).all() and frames.shape[0] == total and frames.shape[1] == config.data.channels * nfp
         roofline, arith = roofline_of_leg(net, args, B, arith_name)
+        # ---- self-check, outside the timed region: row 0 of this rank's shard recomputed ALONE (B = 1) under the same kernel table with the
+        # same Philox key (seed, global row) must reproduce the row the full batch produced -- a mis-indexed tile at the benchmarked batch
+        # (arena offsets beyond 2^32 bytes, paired 8x8 regions, tiles that span images) cannot hide behind `isfinite`
+        last_seed = seed0 + steps - 1
+        kw = dict(final_only=True, denoise=True, subsample_steps=subsample, clip_before=True, verbose=False, log=False,
+                  seed=1000 + last_seed, sample_offset=b0)
+        if autoreg:        # (video_gen draws its block inits from a torch generator whose stream depends on the batch: check one block's sampler call)
+            full = ddpm_sampler(x, net, cond=cond, **kw)[0]
+        else:
+            full = frames[b0:b1]
+        net.set_tuning(1, net.get_tuning(b1 - b0))
+        one = ddpm_sampler(x[:1], net, cond=cond[:1], **kw)[0]
+        selfcheck = float((full[:1] - one).abs().max().item())
         return dict(value=steps * total * nfp / dt, ms_per_step=1e3 * dt / steps, per_rank=per_rank, roofline=roofline, dtype=arith,
-                    kernel_table=pinned or "autotuned in this run (HIP-event timing per distinct layer shape)")
+                    kernel_table=pinned or "autotuned in this run (HIP-event timing per distinct layer shape)", selfcheck_max_abs=selfcheck)
 
     main_arith = "f16x2" if args.f16x2 else "bf16x3"
     main_leg = run_leg(main_arith, args.f16x2, args.warmup, args.steps, 0, args.tune_cache or table_path(main_arith))
@@ -380,6 +393,13 @@ def main():
         second = run_leg("f16x2", 1, 1, args.steps, 500, table_path("f16x2"))
         net.set_option("f16x2", 0)
 
+    # which ranks / devices really took part (the driver's 8-GPU run is the first time RCCL ranks > 1 exist: make the line say what ran)
+    ranks_seen = dict(world_size=world, backend=backend if world > 1 else None, devices=[local])
+    if world > 1:
+        mine = torch.tensor([rank, local], device="cuda" if backend == "nccl" else "cpu", dtype=torch.int64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ranks_seen = dict(world_size=dist.get_world_size(), backend=backend, ranks=[int(v[0]) for v in allr], devices=[int(v[1]) for v in allr])
     if rank == 0:
         import ctypes as C
         from mcvd_pytorch_amd import _lib
@@ -399,10 +419,17 @@ def main():
                                parallelism=f"sample-sharded x{world} (1 weight broadcast + 1 final all_gather)",
                                kernel_table=main_leg["kernel_table"],
                                hip_graph=dict(enabled=bool(args.graph), captures=cap.value, replays=rep.value)),
-                   per_rank_s=main_leg["per_rank"], roofline=main_leg["roofline"])
+                   per_rank_s=main_leg["per_rank"], roofline=main_leg["roofline"],
+                   selfcheck_max_abs=main_leg["selfcheck_max_abs"],
+                   selfcheck_note="max |row 0 of the last timed call - the same row sampled alone (B = 1, same kernel table, same Philox key)| "
+                                  "over the final frames (data range [-1, 1]); computed after the timed region",
+                   profile=1, profile_note="context option profile = 1: the first forward of each leg's LAST timed call runs op by op with HIP "
+                                           "events around every launch (the roofline breakdown); it is inside the timed region (< 0.1 % of it)",
+                   rccl_ranks_seen=ranks_seen)
         if second:
             res["f16x2_leg"] = dict(value=round(second["value"], 3), unit="frames/s", ms_per_step=round(second["ms_per_step"], 2),
                                     dtype=second["dtype"], kernel_table=second["kernel_table"], roofline=second["roofline"],
+                                    selfcheck_max_abs=second["selfcheck_max_abs"],
                                     note="same workload, same K steps, context option f16x2 = 1 (1 warm-up call: re-tune or table load): "
                                          "reported only, narrower arithmetic than the reference's")
         if world == 1 and not args.no_cpu_baseline:

@@ -138,6 +138,10 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value);
  * mcvd_last_error) if any forward since the last call produced one, else 0, and clears the record.  mcvd_sampler_run / mcvd_fpndm_run
  * call it themselves before they return; a caller of mcvd_unet_forward* calls it when it wants the verdict. */
 int mcvd_ctx_check_range(mcvd_ctx* ctx);
+/* Forgets a pending range verdict without reporting it (no synchronisation).  mcvd_sampler_run / mcvd_fpndm_run call it on entry, the
+ * Python host loops at the start of every sampler call, and a change of the option "f16x2" implies it: a flag left behind by an earlier,
+ * unrelated forward (or by a call that returned an error before its own check) must not fail the next run. */
+int mcvd_ctx_clear_range(mcvd_ctx* ctx);
 /* Diagnostics: when set (device pointer to [n_blocks][8] uint64, or NULL to disable), mcvd_op_conv2d's MFMA kernel records per
  * block the shader cycles wave 0 spent in {prologue, MFMA phases, barrier after MFMA, staging writes, second barrier, split-K
  * reduction, epilogue, total}. */

@@ -116,6 +116,14 @@ int mcvd_ctx_check_range(mcvd_ctx* ctx) {
     API_CATCH
 }
 
+int mcvd_ctx_clear_range(mcvd_ctx* ctx) {
+    API_TRY
+    MCVD_REQUIRE(ctx, "ctx is NULL");
+    if (ctx->range_flag) MCVD_HIP_CHECK(hipMemsetAsync(ctx->range_flag, 0, sizeof(int), ctx->stream));
+    return 0;
+    API_CATCH
+}
+
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     MCVD_REQUIRE(ctx && key, "ctx/key is NULL");
     ++ctx->epoch;                  // captured graphs embed the kernels the options select
@@ -131,7 +139,10 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "winograd")) ctx->winograd = value;
     else if (!strcmp(key, "conv_dma1")) ctx->conv_dma1 = value;
     else if (!strcmp(key, "bf16x3")) ctx->bf16x3 = value;
-    else if (!strcmp(key, "f16x2")) ctx->f16x2 = value;
+    else if (!strcmp(key, "f16x2")) {
+        if (ctx->f16x2 != value) (void)mcvd_ctx_clear_range(ctx);        // a verdict of the other arithmetic's forwards is stale
+        ctx->f16x2 = value;
+    }
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
     else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
     else if (!strcmp(key, "gn_inline")) ctx->gn_inline = value;
@@ -586,6 +597,7 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
     MCVD_REQUIRE(m && x && B > 0, "sampler_run: bad arguments");
     MCVD_REQUIRE(kind == MCVD_SAMPLER_DDPM || kind == MCVD_SAMPLER_DDIM, "sampler_run: kind %d", kind);
     MCVD_REQUIRE(m->finalized, "sampler_run before mcvd_model_finalize");
+    if (int rc = mcvd_ctx_clear_range(m->ctx)) return rc;          // the verdict at the end is about THIS call's forwards
     const int T = m->d.num_classes;
     // schedule subsampling, models/__init__.py:229-237
     std::vector<int> steps;
@@ -695,6 +707,7 @@ int mcvd_fpndm_run(mcvd_model* m, float* x, const float* cond, int subsample_ste
     API_TRY
     MCVD_REQUIRE(m && x && B > 0, "fpndm_run: bad arguments");
     MCVD_REQUIRE(m->finalized, "fpndm_run before mcvd_model_finalize");
+    if (int rc = mcvd_ctx_clear_range(m->ctx)) return rc;
     const int T = m->d.num_classes;
     MCVD_REQUIRE(subsample_steps > 0 && subsample_steps <= T, "fpndm_run: subsample_steps=%d (the reference divides by it)", subsample_steps);
     const int64_t per = (int64_t)m->d.channels * m->d.num_frames * m->d.image_size * m->d.image_size;

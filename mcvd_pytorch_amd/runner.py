@@ -136,7 +136,9 @@ def video_gen(config, scorenet, cond, num_frames_pred=None, init_noise_fn=None, 
             k0, th0 = float(scorenet.k_cum[0]), float(scorenet.theta_t[0])
 
             def init_noise_fn(i, shp, dv):
-                g = torch.distributions.gamma.Gamma(torch.full(shp, k0, device=dv), torch.full(shp, 1.0 / th0, device=dv)).sample()
+                # drawn on the CPU and then moved, as the reference does (:1470-1474, :1545-1549: `Gamma(full(...), full(...)).sample().to(device)`):
+                # under torch.manual_seed a reference script and this loop consume the same CPU generator stream
+                g = torch.distributions.gamma.Gamma(torch.full(shp, k0), torch.full(shp, 1.0 / th0)).sample().to(dv)
                 return g - k0 * th0
         else:
             def init_noise_fn(i, shp, dv):
@@ -144,6 +146,7 @@ def video_gen(config, scorenet, cond, num_frames_pred=None, init_noise_fn=None, 
     t_min = getattr(s, "init_prev_t", -1)
     n_iter = nfp if one_at_a_time else ceil(nfp / nf)                                  # :1501-1504
     seed = sampler_kwargs.pop("seed", None)
+    sampler_kwargs.pop("gamma", None)                 # decided by config.model.gamma (:1518); a duplicate keyword would be a TypeError below
     real_init = None
     if data_init is not None:
         real_init = data_init.to(dev).float().reshape(len(data_init), -1, S, S)        # conditioning_fn(..., conditional=False) :109-110

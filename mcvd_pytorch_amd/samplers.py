@@ -113,6 +113,7 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
         if cond_noise.dim() != 5 or tuple(cond_noise.shape[1:]) != tuple(cond.shape) or cond_noise.shape[0] < n_fwd:
             raise RuntimeError(f"cond_noise has shape {tuple(cond_noise.shape)}; need at least [{n_fwd}, {', '.join(map(str, cond.shape))}]")
 
+    _lib.check(_lib.lib.mcvd_ctx_clear_range(net._ctx), "clear_range")      # the f16x2 range verdict below is about THIS call's forwards
     fast = final_only and not verbose and not log and not same_noise and noise_val is None and frac_steps is None
     if fast:
         flags = (_lib.FLAG_DENOISE if denoise else 0) | (_lib.FLAG_CLIP_BEFORE if clip_before else 0) \
@@ -310,6 +311,7 @@ def fpndm_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, su
                                                int(subsample_steps), _lib.FLAG_CLIP_BEFORE if clip_before else 0, B), "fpndm_run")
         net._cond_key = None
         return x.unsqueeze(0)
+    _lib.check(_lib.lib.mcvd_ctx_clear_range(net._ctx), "clear_range")
     alphas_old = net.alphas.cpu().flip(0)                                           # :57
     T = len(alphas_old)
     skip = T // subsample_steps                                                     # :60
@@ -361,6 +363,7 @@ def fpndm_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, su
         x = transfer(x, t, t_next, noise)                                           # pndm.py:51
         if not final_only:
             images.append(x.to("cpu"))
+    _lib.check(_lib.lib.mcvd_ctx_check_range(net._ctx), "FPNDM sampler (f16x2 range guard)")      # no-op unless the option f16x2 is on
     if final_only:
         return x.unsqueeze(0)
     return torch.stack(images)
