@@ -168,7 +168,8 @@ def roofline_of_leg(net, args, B, arith_name):
                          tflops=round(a["flops"] / a["ms"] / 1e9, 2), gbs=round(a["bytes"] / a["ms"] / 1e6, 1))
                  for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     # ---- dominant kernel: the 3x3 convs, by the kernel family each layer REALLY ran
-    FAM3 = {4: "wino_f32", 8: "wino_f32", 10: "wino_bf16x3", 11: "wino_bf16x3", 12: "wino_f16x2", 13: "wino_f16x2"}
+    FAM3 = {4: "wino_f32", 8: "wino_f32", 10: "wino_bf16x3", 11: "wino_bf16x3", 12: "wino_f16x2", 13: "wino_f16x2",
+            16: "wino_bf16x3", 17: "wino_bf16x3"}          # 16 / 17: the same kernel as persistent workgroups (conv_wino3p.cpp)
     fam = {k: dict(launches=0, ms=0.0, flops=0.0, bytes=0.0) for k in ("wino_f32", "wino_bf16x3", "wino_f16x2", "direct")}
     k1 = {}
     for i in range(n):
@@ -188,7 +189,7 @@ def roofline_of_leg(net, args, B, arith_name):
     #   piece products per fp32 product, the two-piece fp16 kernel THREE
     FAMILY = {
         "wino_f32": ("conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", 16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS),
-        "wino_bf16x3": ("conv_wino3_kernel (3x3 conv, Winograd F(2x2,3x3), operands split exactly into 3 bf16 pieces, weights pre-split at "
+        "wino_bf16x3": ("conv_wino3_kernel / conv_wino3p_kernel (persistent workgroups) (3x3 conv, Winograd F(2x2,3x3), operands split exactly into 3 bf16 pieces, weights pre-split at "
                         "pack time, 6 piece products on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-equivalent)", 6.0 * 16.0 / 36.0,
                         BF16_MFMA_PEAK_TFLOPS),
         "wino_f16x2": ("conv_wino2h_kernel (3x3 conv, Winograd F(2x2,3x3), operands split into 2 fp16 pieces = 22 significant bits, weights "

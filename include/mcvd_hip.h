@@ -105,7 +105,10 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *     "conv_shape" (-1 auto): force a kernel family for every conv (tests): 0/1/2/3 the 256/128/64-pixel / split-K direct tiles, 4 fp32
  *         Winograd F(2x2,3x3) (8: with its 2-way split of the input channels), 5 / 6 / 9 the fp32 all-DMA 1x1 GEMM (16 / 32 channels per
  *         chunk / 64 pixels per wave), 10 / 11 three-piece bf16 Winograd (11: K split), 12 / 13 two-piece fp16 Winograd (13: K split),
- *         14 / 15 the split-operand 1x1 GEMM with two fp16 / three bf16 pieces.  A family that does not serve a launch falls back.
+ *         14 / 15 the split-operand 1x1 GEMM with two fp16 / three bf16 pieces, 16 / 17 the three-piece bf16 Winograd kernel as PERSISTENT
+ *         workgroups (one per CU walks a range of (region, cout tile[, K half]) items, the staging pipeline runs on across items; results
+ *         bit-identical to 10 / 11; 17: K split).  A family that does not serve a launch falls back.  "persist_grid" (0 = one workgroup
+ *         per CU): number of workgroups of the persistent kernel (tests: long item ranges on small tensors).
  *     "conv_shape1" (-1): the same for the 1x1 convs only (they follow "conv_shape" otherwise), so that a test can put every 3x3 AND
  *         every 1x1 conv of a model on chosen kernels at once.  "conv_cot": cout tile (32-channel units) mcvd_op_conv2d requests with
  *         conv_shape 5 / 6 / 9 / 14 / 15.

@@ -144,6 +144,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
         ctx->f16x2 = value;
     }
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
+    else if (!strcmp(key, "persist_grid")) ctx->persist_grid = value;
     else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
     else if (!strcmp(key, "gn_inline")) ctx->gn_inline = value;
     else if (!strcmp(key, "gn_inline_max_wg")) ctx->gn_inline_max_wg = value;
@@ -483,7 +484,7 @@ int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* co
     MCVD_REQUIRE(n == (int)m->ops.size(), "set_tuning: %d entries for a plan of %d ops (tuning of another model?)", n, (int)m->ops.size());
     for (int i = 0; i < n; ++i) {
         const bool conv = m->ops[i].kind == OP_CONV;
-        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 15 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
+        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 17 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
                      "set_tuning: entry %d (shape %d, cout tile %d) does not fit op kind %d", i, shapes[i], cots[i], (int)m->ops[i].kind);
     }
     if (m->ctx) m->sync_tuning_options();         // the table belongs to the options in force now; a later option change drops it
@@ -840,16 +841,16 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.CinP = round_up(a.Cin, conv_chunk(ks));
     a.CoutP = round_up(Cout, 32 * a.cot);
     const size_t wfloats = (size_t)a.CinP * ks * ks * a.CoutP;
-    const bool wino = (ctx->conv_shape == 4 || ctx->conv_shape == 8 || (ctx->conv_shape >= 10 && ctx->conv_shape <= 13)) &&
-                      conv_wino_supported(ks, H, W);
+    const bool wino = (ctx->conv_shape == 4 || ctx->conv_shape == 8 || (ctx->conv_shape >= 10 && ctx->conv_shape <= 13) ||
+                       ctx->conv_shape == 16 || ctx->conv_shape == 17) && conv_wino_supported(ks, H, W);
     const bool wino_h = wino && (ctx->conv_shape == 12 || ctx->conv_shape == 13);     // fp16 pieces as well
-    const bool wino_b = wino && (ctx->conv_shape == 10 || ctx->conv_shape == 11);     // bf16 pieces as well
+    const bool wino_b = wino && (ctx->conv_shape == 10 || ctx->conv_shape == 11 || ctx->conv_shape == 16 || ctx->conv_shape == 17);     // bf16 pieces as well
     const int np1 = (ks == 1 && ctx->conv_shape == 14) ? 2 : (ks == 1 && ctx->conv_shape == 15) ? 3 : 0;      // 1x1 pieces
     const size_t ufloats = wino ? (size_t)a.CinP * 16 * a.CoutP : 0;
     const size_t hfloats = wino_h ? (size_t)((conv_wino2h_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4)
                            : wino_b ? (size_t)((conv_wino3_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4)
                            : np1 ? (size_t)((conv1x1_h2_weight_floats(a.CinP, a.CoutP, np1) + 3) / 4 * 4) : 0;
-    const size_t pfloats = (wino && (ctx->conv_shape == 8 || ctx->conv_shape == 11 || ctx->conv_shape == 13)) ? (size_t)2 * B * Cout * H * W : 0;     // K-split partial results
+    const size_t pfloats = (wino && (ctx->conv_shape == 8 || ctx->conv_shape == 11 || ctx->conv_shape == 13 || ctx->conv_shape == 17)) ? (size_t)2 * B * Cout * H * W : 0;     // K-split partial results
     if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats + hfloats + pfloats) * sizeof(float))) return rc;
     MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP + ufloats + hfloats) * sizeof(float), ctx->stream));
     if (wino) {
@@ -876,6 +877,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.shape_hint = ctx->conv_shape;
     if ((ctx->conv_shape == 5 || ctx->conv_shape == 6 || ctx->conv_shape == 9 || ctx->conv_shape == 14 || ctx->conv_shape == 15) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
     a.wdma = ctx->conv_wdma;
+    a.pgrid = ctx->persist_grid;
     a.dbg = ctx->dbg;
     a.stats = ctx->naive_conv ? nullptr : ctx->stats_buf;
     if (ctx->spade_gb) {

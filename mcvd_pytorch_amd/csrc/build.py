@@ -18,6 +18,7 @@ LIB = os.path.join(PKG, "libmcvd_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include")]
+WINO_OBJS = ("conv_wino.o", "conv_wino3.o", "conv_wino2h.o", "conv_wino3p.o")
 HOST_ONLY_FLAGS = {"model.cpp": ["-ffp-contract=off"], "api.cpp": ["-ffp-contract=off"],
                    "sampler.cpp": ["-ffp-contract=off"]}      # sampler update kernels: one rounding per operation
 
@@ -56,18 +57,30 @@ def build(force=False, jobs=None, verbose=True, diag=False):
             objs.append(obj)
             if log is not None:
                 rebuilt += 1
-                wino_rebuilt |= os.path.basename(obj) in ("conv_wino.o", "conv_wino3.o", "conv_wino2h.o")
+                wino_rebuilt |= os.path.basename(obj) in WINO_OBJS
                 if log and verbose:
                     print(log, file=sys.stderr)
-    if wino_rebuilt and not diag:
-        # conv_wino.cpp manages its VMEM waits by hand; the generated code must keep the invariants that makes sound
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_wino_isa.py")], capture_output=True, text=True)
+    relink = rebuilt or not os.path.exists(lib) or force
+    stamp = os.path.join(OBJ + ("_diag" if diag else ""), "wino_isa.ok")
+    newest_wino = max(os.path.getmtime(os.path.join(OBJ + ("_diag" if diag else ""), o)) for o in WINO_OBJS)
+    checked = os.path.exists(stamp) and os.path.getmtime(stamp) >= newest_wino
+    if wino_rebuilt or (relink and not checked) or not checked:
+        # The Winograd kernels manage their VMEM waits and their MFMA operand registers by hand (inline asm over registers the compiler is
+        # only kept away from by amdgpu_num_vgpr): the generated code must keep the invariants that makes sound.  Checked on EVERY build
+        # route -- product and diagnostics library, fresh or cached objects (the stamp is older than any unchecked object) -- before the link.
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_wino_isa.py")] + (["--diag"] if diag else []),
+                           capture_output=True, text=True)
         if r.returncode != 0:
-            os.remove(os.path.join(OBJ, "conv_wino.o"))
-            raise RuntimeError("conv_wino.cpp: generated code violates the asm-load invariants\n" + r.stderr)
+            for o in WINO_OBJS:
+                try:
+                    os.remove(os.path.join(OBJ + ("_diag" if diag else ""), o))
+                except OSError:
+                    pass
+            raise RuntimeError("Winograd kernels: generated code violates the asm-load invariants\n" + r.stderr)
+        open(stamp, "w").write(r.stdout)
         if verbose:
             print(r.stdout.strip())
-    if rebuilt or not os.path.exists(lib) or force:
+    if relink:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

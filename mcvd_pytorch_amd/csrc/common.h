@@ -76,11 +76,14 @@ struct ConvArgs {
     int shape_hint;       // -1 auto; 0/1/2 force the 256/128/64-pixel tile, 3 split-K+WDB, 4 Winograd (8: with a 2-way K split), 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels per chunk),
                           // 9 the 1x1 GEMM with 64 pixels per wave, 10 Winograd on the bf16 pipe with three-piece operands (11: with a 2-way K split),
                           // 12 Winograd on the fp16 pipe with two-piece operands (13: with a 2-way K split), 14 the 1x1 GEMM on the fp16 pipe
-                          // with two-piece operands, 15 the 1x1 GEMM on the bf16 pipe with three-piece operands
+                          // with two-piece operands, 15 the 1x1 GEMM on the bf16 pipe with three-piece operands, 16 / 17 the three-piece bf16 Winograd
+                          // kernel as persistent workgroups (17: with a 2-way K split)
     int ksplit;           // Winograd kernel only: 2 = two workgroups per tile contract half the input channels each into
                           // `part`, a second pass sums the halves; 0/1 = off
     float* part;          // ksplit == 2: scratch for the two partial results, 2 * B*Cout*H*W floats
     int wdma;             // 1: stage weight chunks by LDS-DMA (default), 0: through registers
+    int pgrid;            // persistent Winograd kernel (conv_wino3p.cpp) only: > 0 = number of workgroups (context option "persist_grid": tests
+                          // drive long item ranges and sample changes with a few workgroups); 0 = one per CU
     unsigned long long* dbg;   // optional: per-block phase cycle counters [n_blocks][8] (diagnostics), else null
     // GroupNorm statistics from the producer's epilogue (layerspp.py:518-549 consumes them): when non-null, the kernel writes for
     // every (sample, cout) `np` partial pairs (sum, M2 about the partial's own mean) over disjoint pixel sets of HW / np pixels
@@ -115,6 +118,10 @@ int launch_wino_ksplit_reduce(const ConvArgs& a, hipStream_t s);      // second 
 bool conv_wino3_usable(const ConvArgs& a);
 int launch_conv_wino3(const ConvArgs& a, hipStream_t s);
 long conv_wino3_weight_floats(int CinP, int CoutP);           // size of the wpb buffer, in floats
+// the same kernel as PERSISTENT workgroups (one per CU, each walks a contiguous range of (region, cout tile[, K half]) items, the K loop's
+// staging pipeline runs on across item boundaries; conv_wino3p.cpp): tile shape ids 16 / 17 (17: 2-way K split); bit-identical results
+bool conv_wino3p_usable(const ConvArgs& a);
+int launch_conv_wino3p(const ConvArgs& a, hipStream_t s);
 int launch_pack_wino3_weight(const float* w, float* wb, int Cout, int Cin, int CinP, int CoutP, hipStream_t s);    // wb zero-filled
 // the same convolution on the fp16 matrix pipe, operands split into two fp16 pieces (22-bit operands, three piece products; weights
 // pre-split at pack time; conv_wino2h.cpp): tile shape ids 12 / 13 (13: 2-way K split); needs ConvArgs::wph

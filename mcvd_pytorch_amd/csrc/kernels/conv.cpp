@@ -26,7 +26,7 @@ static int env_int(const char* name, int dflt) {      // diagnostics build only:
 // silently): 0..3 direct implicit GEMM tile shapes, 4 Winograd, 8 Winograd + K split, 5 / 6 all-DMA 1x1 GEMM (16 / 32 channels),
 // 9 the 1x1 GEMM with 64 pixels per wave, 10 / 11 Winograd on the bf16 pipe with three-piece operands (11: + K split), 12 / 13 Winograd on
 // the fp16 pipe with two-piece operands (13: + K split), 14 the 1x1 GEMM on the fp16 pipe with two-piece operands, 15 the 1x1 GEMM on
-// the bf16 pipe with three-piece operands
+// the bf16 pipe with three-piece operands, 16 / 17 the three-piece bf16 Winograd kernel as persistent workgroups (17: + K split)
 static thread_local int g_last_conv_kernel = -1;
 int last_conv_kernel() { return g_last_conv_kernel; }
 
@@ -62,12 +62,22 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
         b.ksplit = 0;
         if (conv_wino2h_usable(b)) { g_last_conv_kernel = 12; return launch_conv_wino2h(b, s); }
     }
-    if (a.shape_hint == 11) {                                       // bf16x3 Winograd with a 2-way K split
+    if (a.shape_hint == 17) {                                       // persistent bf16x3 Winograd, the two K halves are items
+        ConvArgs b = a;
+        b.ksplit = 2;
+        if (conv_wino3p_usable(b)) { g_last_conv_kernel = 17; return launch_conv_wino3p(b, s); }
+    }
+    if (a.shape_hint == 16 || a.shape_hint == 17) {                 // persistent bf16x3 Winograd (one workgroup per CU walks an item range)
+        ConvArgs b = a;
+        b.ksplit = 0;
+        if (conv_wino3p_usable(b)) { g_last_conv_kernel = 16; return launch_conv_wino3p(b, s); }
+    }
+    if (a.shape_hint == 11 || a.shape_hint == 17) {                 // bf16x3 Winograd with a 2-way K split
         ConvArgs b = a;
         b.ksplit = 2;
         if (conv_wino3_usable(b)) { g_last_conv_kernel = 11; return launch_conv_wino3(b, s); }
     }
-    if (a.shape_hint == 10 || a.shape_hint == 11) {                 // Winograd on the bf16 matrix pipe, operands split three ways
+    if (a.shape_hint == 10 || a.shape_hint == 11 || a.shape_hint == 16 || a.shape_hint == 17) {     // Winograd on the bf16 matrix pipe, operands split three ways
         ConvArgs b = a;
         b.ksplit = 0;
         if (conv_wino3_usable(b)) { g_last_conv_kernel = 10; return launch_conv_wino3(b, s); }
@@ -77,7 +87,7 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
         b.ksplit = 2;
         if (conv_wino_usable(b)) { g_last_conv_kernel = 8; return launch_conv_wino(b, s); }
     }
-    if ((a.shape_hint == 4 || a.shape_hint == 8 || (a.shape_hint >= 10 && a.shape_hint <= 13)) && conv_wino_usable(a)) { g_last_conv_kernel = 4; return launch_conv_wino(a, s); }   // Winograd F(2x2,3x3)
+    if ((a.shape_hint == 4 || a.shape_hint == 8 || (a.shape_hint >= 10 && a.shape_hint <= 13) || a.shape_hint == 16 || a.shape_hint == 17) && conv_wino_usable(a)) { g_last_conv_kernel = 4; return launch_conv_wino(a, s); }   // Winograd F(2x2,3x3)
     if (a.shape_hint == 15 && conv1x1_h2_supported(a, a.cot, 3)) { g_last_conv_kernel = 15; return launch_conv1x1_h2(a, a.cot, s, 3); }   // 1x1 GEMM, bf16 pipe, three exact pieces
     if (a.shape_hint == 14 && conv1x1_h2_supported(a, a.cot, 2)) { g_last_conv_kernel = 14; return launch_conv1x1_h2(a, a.cot, s, 2); }   // 1x1 GEMM, fp16 pipe, two-piece operands
     if (a.shape_hint == 5 && conv1x1_dma_supported(a, 16)) { g_last_conv_kernel = 5; return launch_conv1x1_dma(a, a.cot, 16, s); }   // all-DMA 1x1 GEMM

@@ -705,6 +705,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.cot = op.cot;
             a.shape_hint = (op.ks == 1 && ctx->conv_shape1 >= 0) ? ctx->conv_shape1 : ctx->conv_shape;
             a.wdma = ctx->conv_wdma;
+            a.pgrid = ctx->persist_grid;
             a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
             const size_t oi = (size_t)(&op - ops.data());
             if (a.shape_hint == 14 || a.shape_hint == 15) {      // forced split-operand 1x1 GEMM (tests): a cout tile that kernel serves
@@ -723,8 +724,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                     a.shape_hint = a.shape_hint == 12 ? 10 : a.shape_hint == 13 ? 11 : 15;
                     if (a.shape_hint == 15 && !conv1x1_h2_supported(a, a.cot, 3)) a.cot = op.cot;
                 }
-                if (!ctx->bf16x3 && (a.shape_hint == 10 || a.shape_hint == 11 || a.shape_hint == 15)) {
-                    a.shape_hint = a.shape_hint == 10 ? 4 : a.shape_hint == 11 ? 8 : 5;
+                if (!ctx->bf16x3 && (a.shape_hint == 10 || a.shape_hint == 11 || a.shape_hint == 15 || a.shape_hint == 16 || a.shape_hint == 17)) {
+                    a.shape_hint = (a.shape_hint == 10 || a.shape_hint == 16) ? 4 : (a.shape_hint == 11 || a.shape_hint == 17) ? 8 : 5;
                     a.cot = op.cot;
                 }
             }
@@ -893,6 +894,7 @@ int mcvd_model::autotune(int B) {
             a.y = resolve(op.dst, scratch_io, scratch_io, scratch_io, B);
             a.B = B; a.Cin = cin; a.CinP = op.CinP; a.Cout = op.Cout; a.CoutP = op.CoutP; a.H = op.H; a.W = op.W; a.ks = op.ks;
             a.wdma = ctx->conv_wdma;
+            a.pgrid = ctx->persist_grid;
             a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
             const bool spade_fused = op.gb.kind != REF_NONE && ctx->spade_fuse && ctx->winograd;
             if (spade_fused) {
@@ -945,6 +947,13 @@ int mcvd_model::autotune(int B) {
                 b.ksplit = 2;
                 if (conv_wino3_usable(b))
                     if (int rc = time_candidate(11, op.cot)) return rc;
+                // 16 / 17 = the same kernel as persistent workgroups (conv_wino3p.cpp): the staging pipeline runs on across the items of a CU
+                b.ksplit = 0;
+                if (conv_wino3p_usable(b))
+                    if (int rc = time_candidate(16, op.cot)) return rc;
+                b.ksplit = 2;
+                if (conv_wino3p_usable(b))
+                    if (int rc = time_candidate(17, op.cot)) return rc;
             }
             // f16x2 range guard: the two-piece fp16 kernels see GroupNorm-ed inputs only (a.coef set: normalised, O(1) by construction).
             // A conv over a RAW tensor (stem, shortcuts, NIN_3) has no bound on its input and stays on the fp32-range kernels.

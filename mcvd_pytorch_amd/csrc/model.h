@@ -21,6 +21,7 @@ struct mcvd_ctx {
     int conv_shape1 = -1;          // >= 0: the shape forced for the 1x1 convs only (they follow conv_shape otherwise): lets a test put
                                    //    every 3x3 conv AND every 1x1 conv of a model on chosen kernels at once
     int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
+    int persist_grid = 0;          // > 0: workgroups of the persistent Winograd kernel (tests); 0 = one per CU
     int conv_cot = 0;              // > 0 with conv_shape 5: cout tile (32-channel units) mcvd_op_conv2d requests (tests)
     int bf16x3 = 1;                // offer the three-piece bf16 kernels (conv_wino3.cpp, conv1x1_h2.cpp, attention_h2.cpp with NP = 3: fp32-equivalent
                                    //    arithmetic, full fp32 range) to the autotuner / the attention dispatch.  On by default.

@@ -584,6 +584,64 @@ def w2hsub(f):
     ctx.opt("conv_shape", -1)
 
 
+def w3ptl(f):
+    """conv_wino3p_kernel (persistent workgroups, shape 16 / 17) next to conv_wino3_kernel (10 / 11) on the bench's layer shapes at B = 64
+    (env B): event time of both, and for the persistent kernel the cycles a workgroup (wave MCVD_DBG_WAVE of it; product library: wave 0)
+    spends in prologues / K loops / epilogues, items per workgroup, shader clock."""
+    from tests.hiputil import Ctx, P
+    ctx = Ctx()
+    B = int(os.environ.get("B", 64))
+    cases = [(96, 96, 64), (192, 192, 64), (288, 96, 64), (192, 96, 64), (96, 192, 32), (192, 192, 32), (480, 192, 32), (288, 288, 32),
+             (192, 288, 16), (288, 288, 16), (672, 288, 16), (384, 384, 16), (192, 192, 16)]
+    if os.environ.get("MCVD_TL_CASES"):
+        cases = [cases[int(v)] for v in os.environ["MCVD_TL_CASES"].split(",")]
+    for cin, cout, H in cases:
+        x = torch.randn(B, cin, H, H, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+        b = torch.zeros(cout, device="cuda")
+        coef = torch.ones(B, cin, 2, device="cuda")
+        res = torch.randn(B, cout, H, H, device="cuda")
+        line = f"cin{cin:4d} cout{cout:4d} H{H:3d}:"
+        ref = None
+        for shp in (10, 16, 11, 17):
+            ctx.opt("conv_shape", shp)
+            for _ in range(3):
+                y = ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
+            ran = _lib.lib.mcvd_last_conv_kernel()
+            if ran != shp:
+                line += f"  [{shp}: n/a]"
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(6):
+                ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
+            e1.record()
+            torch.cuda.synchronize()
+            line += f"  [{shp}: {e0.elapsed_time(e1) * 1e3 / 6:7.1f} us]"
+            if shp in (10, 11):
+                ref = y.clone()
+            elif ref is not None:
+                line += " bit-equal" if torch.equal(y, ref) else " DIFFERENT"
+            if shp in (16, 17):
+                dbg = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+                _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, P(dbg)))
+                ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
+                torch.cuda.synchronize()
+                _lib.check(_lib.lib.mcvd_ctx_set_debug_buffer(ctx.h, None))
+                d = dbg.view(-1, 8).cpu()
+                d = d[d[:, 7] > 0]
+                rt0, rt1, cyc = d[:, 2].double(), d[:, 3].double(), d[:, 7].double()
+                items = (d[:, 6] >> 32).double()
+                chunks = (d[:, 6] & 0xffffffff).double()
+                clk = (cyc / ((rt1 - rt0) * 10e-9)).median().item() / 1e9
+                span = (rt1.max() - rt0.min()).item() * 10e-3
+                line += (f" {{{len(d)} wg, items {int(items.min())}..{int(items.max())}, {clk:.2f} GHz, span {span:.1f} us, per wg: total {cyc.mean():.0f} cyc = prologue {d[:, 0].double().mean():.0f}"
+                         f" + loops {d[:, 1].double().mean():.0f} ({(d[:, 1].double() / chunks).mean():.0f}/chunk) + epilogues {d[:, 5].double().mean():.0f} ({(d[:, 5].double() / items).mean():.0f}/item)}}")
+        f.write(line + "\n")
+        f.flush()
+    ctx.opt("conv_shape", -1)
+
+
 def convops(f):
     """Per-op times of the 3x3 convs of one instrumented forward (BASELINE config 2, B = 64): kernel the autotuner chose and ms,
     with the split-operand bf16 Winograd kernel offered (MCVD_BF16X3 unset) -- run again with MCVD_BF16X3=0 for the fp32 table."""
@@ -628,6 +686,6 @@ if __name__ == "__main__":
     for w in what:
         with open(os.path.join(OUT, f"diag_{w}.txt"), "w") as f:
             t0 = time.time()
-            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "w3sub": w3sub, "w3pro": w3pro, "hostloop": hostloop, "convops": convops, "sweep1": sweep1, "w2htl": w2htl, "w2hsub": w2hsub}[w](f)
+            {"precision": precision, "ops": ops, "sweep": sweep, "phases": phases, "wphases": wphases, "wexp": wexp, "w3exp": w3exp, "w3sub": w3sub, "w3pro": w3pro, "hostloop": hostloop, "convops": convops, "w3ptl": w3ptl, "sweep1": sweep1, "w2htl": w2htl, "w2hsub": w2hsub}[w](f)
             f.write(f"# done in {time.time() - t0:.1f}s\n")
 

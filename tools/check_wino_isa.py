@@ -26,7 +26,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc", "kernels", "conv_wino.cpp")
 SRC3 = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc", "kernels", "conv_wino3.cpp")
 SRC2H = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc", "kernels", "conv_wino2h.cpp")
+SRC3P = os.path.join(ROOT, "mcvd_pytorch_amd", "csrc", "kernels", "conv_wino3p.cpp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+DIAG = "--diag" in sys.argv[1:]          # check the diagnostics library's code (-DMCVD_DIAG)
 
 
 def _regs(text):
@@ -124,15 +126,55 @@ def _dest_untouched_covering(name, loop, problems):
             problems.append(f"{name}: no wait covers `{l}`")
 
 
-def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_per_cot=6, nloops=2, npatch=(3, 1), wreg0=184, named0=172):
+def _inner_loop_spans(raw):
+    """[(first line, end line)] of the INNERMOST loops of a function body given as raw lines (comments kept): LLVM marks a nested loop's
+    header with `Parent Loop ...` on the label line and `=>This Inner Loop Header: Depth=N` on a following comment line, its other
+    blocks with `in Loop: Header=BBx_y Depth=N`."""
+    labels = [k for k, l in enumerate(raw) if re.match(r"^\.LBB\d+_\d+:", l) or l.startswith("; %bb.")]
+    spans = []
+    for k in labels:
+        hm = re.match(r"^\.LBB(\d+)_(\d+):", raw[k])
+        if not hm:
+            continue
+        head = raw[k]
+        q = k + 1
+        while q < len(raw) and raw[q].startswith(";") and not raw[q].startswith("; %bb.") and not raw[q].startswith(";;#"):
+            head += " " + raw[q]
+            q += 1
+        if "Inner Loop Header" not in head:
+            continue
+        tag = f"Header=BB{hm.group(1)}_{hm.group(2)} "
+        members = [k] + [q for q in labels if tag in raw[q] + " "]
+        lo, hi_start = min(members), max(members)
+        nxt = [q for q in labels if q > hi_start]
+        spans.append((lo, nxt[0] if nxt else len(raw)))
+    return spans
+
+
+def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_per_cot=6, nloops=2, npatch=(3, 1), wreg0=184, named0=172,
+           targs=r"ILi(\d)ELi(\d)E(?:Lb([01])E)?Li0EEE", nested=False):
     """conv_wino3_kernel<COT, PRO, G8, 0> / conv_wino2h_kernel<COT, PRO, G8, 0>: every loop that holds MFMAs is a K loop; a K loop
     holds wl_per_cot * COT weight loads (NP pieces x 2 positions; destinations from register `wreg0` up) + npatch[G8] patch loads
     (destinations below `wreg0`)."""
     problems, seen = [], 0
-    for m in re.finditer(r"^(_ZN4mcvd" + kernel + r"ILi(\d)ELi(\d)E(?:Lb([01])E)?Li0EEEvNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN4mcvd" + kernel + targs + r"vNS_8ConvArgsE):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
         name, cot, g8, body = m.group(1), int(m.group(2)), int(m.group(4) or 0), m.group(5)
         seen += 1
         lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        if nested:        # the K loops are the innermost loops of a loop nest: the comment lines carry the loop structure
+            raw = [l.strip() for l in body.split("\n") if l.strip()]
+            raw_spans = _inner_loop_spans(raw)
+            # map raw spans onto `lines` through the labels that bound them
+            pos = {}
+            for k, l in enumerate(lines):
+                if re.match(r"^\.LBB\d+_\d+:", l):
+                    pos.setdefault(l.split(":")[0], k)
+
+            def to_line(q):          # raw index of a block boundary -> index in `lines` of the next label at or behind it
+                while q < len(raw) and not re.match(r"^\.LBB\d+_\d+:", raw[q]):
+                    q += 1
+                return pos[raw[q].split(":")[0]] if q < len(raw) else len(lines)
+            nested_spans = [(to_line(lo), to_line(hi)) for lo, hi in raw_spans]
         kloops = 0
         # loops: a header label ("Loop Header") plus every block the compiler marks "in Loop: Header=<that label>"; the compiler may lay
         # rotated blocks out BEFORE the header, so the loop is the contiguous label range that covers all of them (the in-order wait
@@ -146,6 +188,8 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_
             lo, hi_start = min(members), max(members)
             nxt = [q for q in label_idx if q > hi_start]
             spans.append((lo, nxt[0] if nxt else len(lines)))
+        if nested:
+            spans = nested_spans
         for i0, j in spans:
             loop = [l for l in lines[i0:j] if not re.match(r"^\.LBB", l) and not l.startswith("; %bb.")]
             if not any(l.startswith("v_mfma") for l in loop):
@@ -173,6 +217,10 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_
                         problems.append(f"{name}: `{l}` touches an accumulator inside a K loop")
                         break
             # leaving the loop: its loads may still be in flight; nothing may read or overwrite their destinations before vmcnt(0)
+            # (a linear walk along fall-through edges: the diagnostics build's per-phase clock stamps put conditional code between the
+            # loops and their drain, which the walk cannot see through -- `--diag` checks everything but this)
+            if DIAG:
+                continue
             dests = set()
             for l in wl + pl:
                 dests |= _regs(l.split(",")[0])
@@ -229,6 +277,13 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_
     return problems
 
 
+def check3p(asm_text):
+    """conv_wino3p_kernel<COT, PRO> (persistent workgroups): the K loops are the two innermost loops (one per phase order) of the
+    run / item loop nest; same VMEM population per chunk as conv_wino3_kernel."""
+    return check3(asm_text, kernel="18conv_wino3p_kernel", asm_mfma=True, expect=9, wl_per_cot=6, nloops=2, npatch=(3, 3), wreg0=184, named0=172,
+                  targs=r"ILi(\d)ELi(\d)E()EE", nested=True)
+
+
 def check2h(asm_text):
     return check3(asm_text, kernel="18conv_wino2h_kernel", asm_mfma=True, expect=18, wl_per_cot=4, nloops=2, npatch=(6, 6), wreg0=208, named0=202)      # x {8x16 regions, 8x8 images}; one loop per phase order
 
@@ -236,10 +291,10 @@ def check2h(asm_text):
 def main():
     problems = []
     with tempfile.TemporaryDirectory() as td:
-        for src, fn in ((SRC, check), (SRC3, check3), (SRC2H, check2h)):
+        for src, fn in ((SRC, check), (SRC3, check3), (SRC2H, check2h), (SRC3P, check3p)):
             out = os.path.join(td, os.path.basename(src)[:-4] + ".s")
             cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
-                   src, "-o", out]
+                   src, "-o", out] + (["-DMCVD_DIAG"] if DIAG else [])
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 print(r.stderr, file=sys.stderr)
