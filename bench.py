@@ -266,6 +266,8 @@ def main():
     ap.add_argument("--save-tuning", default=None, help="directory: write the table of every leg there (tune_<config>_B<batch>_<arithmetic>.json)")
     ap.add_argument("--no-tune-file", action="store_true", help="ignore committed tables: let the autotuner measure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-frames", default=None, help="file: rank 0 saves the gathered frames of the headline leg's last timed step (torch.save) "
+                    "-- tests compare an N-rank job with the N = 1 job of the same global batch bit for bit")
     ap.add_argument("--no-f16x2-leg", "--no-fp32-leg", dest="no_second_leg", action="store_true",
                     help="skip the second, reported-only timing with the two-piece fp16 kernels offered")
     ap.add_argument("--f16x2", type=int, default=0, help="1: the headline leg itself offers the two-piece fp16 kernels (narrower arithmetic "
@@ -369,6 +371,8 @@ def main():
             per_rank = [round(v.item(), 4) for v in allt]
             dt = max(per_rank)
         assert torch.isfinite(frames).all() and frames.shape[0] == total and frames.shape[1] == config.data.channels * nfp
+        if args.dump_frames and rank == 0 and arith_name == main_arith:
+            torch.save(frames.cpu(), args.dump_frames)
         roofline, arith = roofline_of_leg(net, args, B, arith_name)
         # ---- self-check, outside the timed region: row 0 of this rank's shard recomputed ALONE (B = 1) under the same kernel table with the
         # same Philox key (seed, global row) must reproduce the row the full batch produced -- a mis-indexed tile at the benchmarked batch

@@ -226,6 +226,7 @@ void mcvd_model_destroy(mcvd_model* m) {
     m->drop_graph();
     if (m->blob) (void)hipFree(m->blob);
     if (m->packed) (void)hipFree(m->packed);
+    if (m->packed_h) (void)hipFree(m->packed_h);
     if (m->arena) (void)hipFree(m->arena);
     if (m->labels) (void)hipFree(m->labels);
     if (m->eps_buf) (void)hipFree(m->eps_buf);
@@ -344,14 +345,10 @@ int mcvd_model_finalize(mcvd_model* m) {
             }
             if (p.wpw >= 0)
                 if (int rc = launch_pack_wino_weight(m->blob + w.off, m->packed + p.wpw, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
-            if (p.wph >= 0 && p.ks == 3)
-                if (int rc = launch_pack_wino2h_weight(m->blob + w.off, m->packed + p.wph, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
             if (p.wpb >= 0 && p.ks == 3)
                 if (int rc = launch_pack_wino3_weight(m->blob + w.off, m->packed + p.wpb, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
         }
-        if (p.wph >= 0 && p.ks == 1)           // from the packed fp32 matrix: every fused weight (q | k | v) and the padding are in place
-            if (int rc = launch_pack_conv1x1_h2(m->packed + p.wp, m->packed + p.wph, p.CinP, p.CoutP, s, 2)) return rc;
-        if (p.wpb >= 0 && p.ks == 1)
+        if (p.wpb >= 0 && p.ks == 1)           // from the packed fp32 matrix: every fused weight (q | k | v) and the padding are in place
             if (int rc = launch_pack_conv1x1_h2(m->packed + p.wp, m->packed + p.wpb, p.CinP, p.CoutP, s, 3)) return rc;
     }
     for (const DenseEntry& e : m->dense) {
@@ -365,7 +362,10 @@ int mcvd_model_finalize(mcvd_model* m) {
                                   hipMemcpyHostToDevice, s));
     MCVD_HIP_CHECK(hipStreamSynchronize(s));
     m->finalized = true;
+    m->packed_h_valid = false;             // the two-piece fp16 forms follow the weights: repacked on the next use under f16x2
     ++m->epoch;
+    if (m->ctx->f16x2)
+        if (int rc = m->ensure_f16x2_weights()) return rc;
     return 0;
     API_CATCH
 }

@@ -46,7 +46,7 @@ constexpr float AH_P_LOG = 8.317766166719343f;        // 12 ln 2: NP = 2 probabi
 
 template <int NP, int DT>   // head dim D = 32*DT
 __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int heads, int S,
-                                                          float scale_s) {
+                                                          float scale_s, int nbh, int nqt) {
     typedef Pieces<NP> PX;
     constexpr int D = 32 * DT, NST = D / 16;
     constexpr int NIK = (4 * D + 255) / 256;     // K staging items per thread: (row pair, 4 keys) -> 2 float4
@@ -57,12 +57,18 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
     unsigned* sV = sK + NST * NP * 256;                             // [DT][2 steps][NP pieces][64 lanes][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int bh = blockIdx.y;
+    // block id -> (sample-head, query tile): workgroups are dealt to the 8 XCDs round robin, and every query tile of a (sample, head)
+    // streams the same K and V.  With (query tile, sample-head) as a 2-D grid the 8 query tiles of a 32 x 32 head landed on 8 different
+    // XCDs -- 8 private L2s each fetched every K / V once: L2 hit rate 0.078, 4x the algorithmic read traffic
+    // (profiles/r03_pmc_l2_tcc_tcp.txt).  Here the query tiles of a (sample, head) run on ONE XCD, adjacent in time.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bh = (slot / nqt) * 8 + xcd, qt = slot - (slot / nqt) * nqt;
+    if (bh >= nbh) return;
     const int b = bh / heads, hd = bh - b * heads;
     const float* qb = qkv + ((long)b * 3 * C + hd * D) * S;
     const float* kb = qb + (long)C * S;
     const float* vb = kb + (long)C * S;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qt * 128 + wave * 32;
     const bool active = q0 < S;
 
     // Q pieces: lane (query l31, half) holds channels 16 st + 2e + half, e = 0..7 of every step; dword j = elements (2j, 2j+1)
@@ -236,13 +242,14 @@ static int attn_h2_launch(const float* qkv, float* out, int B, int C, int heads,
     const float scale = (float)pow((double)D, -0.5);   // int(C)**-0.5 as a Python double, then fp32 (layerspp.py:239)
     const float ops = NP == 2 ? Pieces<2>::ACT_SCALE : 1.0f;
     const float scale_s = scale * (1.0f / (ops * ops));      // exact: the S product carries the square of the operand scale
-    dim3 grid((HW + 127) / 128, B * heads);
+    const int nqt = (HW + 127) / 128, nbh = B * heads;
+    dim3 grid((unsigned)(((nbh + 7) / 8) * 8 * nqt));
     const size_t lds = (size_t)(D / 16 + 2 * (D / 32)) * NP * 256 * sizeof(unsigned);
     switch (D / 32) {
-        case 1: hipLaunchKernelGGL((attn_h2_kernel<NP, 1>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
-        case 2: hipLaunchKernelGGL((attn_h2_kernel<NP, 2>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
-        case 3: hipLaunchKernelGGL((attn_h2_kernel<NP, 3>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
-        default: hipLaunchKernelGGL((attn_h2_kernel<NP, 4>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s); break;
+        case 1: hipLaunchKernelGGL((attn_h2_kernel<NP, 1>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s, nbh, nqt); break;
+        case 2: hipLaunchKernelGGL((attn_h2_kernel<NP, 2>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s, nbh, nqt); break;
+        case 3: hipLaunchKernelGGL((attn_h2_kernel<NP, 3>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s, nbh, nqt); break;
+        default: hipLaunchKernelGGL((attn_h2_kernel<NP, 4>), grid, dim3(256), lds, s, qkv, out, C, heads, HW, scale_s, nbh, nqt); break;
     }
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;

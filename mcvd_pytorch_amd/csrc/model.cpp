@@ -98,6 +98,12 @@ struct Builder {
         packed += align4(floats);
         return o;
     }
+    int64_t packed_h = 0;                     // the two-piece fp16 weight forms live in a buffer of their own (mcvd_model::packed_h):
+    int64_t alloc_packed_h(int64_t floats) {  // allocated and packed only when the option f16x2 is on (ensure_f16x2_weights)
+        const int64_t o = packed_h;
+        packed_h += align4(floats);
+        return o;
+    }
 
     int dense_entry(const std::string& prefix, int ch) {
         m.add_param(prefix + ".Dense_0.weight", {2 * ch, m.T});
@@ -171,9 +177,9 @@ struct Builder {
         p.bias = alloc_packed(p.CoutP);
         if (wnames.size() == 1 && !nin && conv_wino_supported(ks, op.H, op.W))
             p.wpw = alloc_packed((int64_t)p.CinP * 16 * p.CoutP);
-        if (p.wpw >= 0) p.wph = alloc_packed(conv_wino2h_weight_floats(p.CinP, p.CoutP));      // two fp16 pieces (conv_wino2h.cpp)
+        if (p.wpw >= 0) p.wph = alloc_packed_h(conv_wino2h_weight_floats(p.CinP, p.CoutP));    // two fp16 pieces (conv_wino2h.cpp): offset into packed_h
         if (p.wpw >= 0) p.wpb = alloc_packed(conv_wino3_weight_floats(p.CinP, p.CoutP));       // three bf16 pieces (conv_wino3.cpp)
-        if (ks == 1) p.wph = alloc_packed(conv1x1_h2_weight_floats(p.CinP, p.CoutP, 2));   // two fp16 pieces of the packed matrix (conv1x1_h2.cpp)
+        if (ks == 1) p.wph = alloc_packed_h(conv1x1_h2_weight_floats(p.CinP, p.CoutP, 2)); // two fp16 pieces of the packed matrix (conv1x1_h2.cpp): offset into packed_h
         if (ks == 1) p.wpb = alloc_packed(conv1x1_h2_weight_floats(p.CinP, p.CoutP, 3));   // three bf16 pieces of it
         op.wpw = p.wpw;
         op.wph = p.wph;
@@ -532,6 +538,7 @@ int mcvd_model::build_plan() {
     freqs_off = bld.alloc_packed(nf / 2);
     arena_per_sample = bld.arena;
     packed_floats = bld.packed;
+    packed_h_floats = bld.packed_h;
     // GroupNorm statistics come out of the producing conv's epilogue: find, for every norm, the conv that wrote each source
     for (size_t gi = 0; gi < ops.size(); ++gi) {
         if (ops[gi].kind != OP_GN) continue;
@@ -688,7 +695,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.act = op.act;
             a.wp = packed + op.wp;
             a.wpw = op.wpw >= 0 ? packed + op.wpw : nullptr;
-            a.wph = op.wph >= 0 ? packed + op.wph : nullptr;
+            a.wph = (op.wph >= 0 && packed_h_valid) ? packed_h + op.wph : nullptr;      // present only while the option f16x2 is on
             a.wpb = op.wpb >= 0 ? packed + op.wpb : nullptr;
             a.bias = packed + op.bias;
             a.res = op.res.kind == REF_NONE ? nullptr : resolve(op.res, x, cond, out, B);
@@ -886,7 +893,7 @@ int mcvd_model::autotune(int B) {
             a.act = op.act;
             a.wp = packed + op.wp;
             a.wpw = op.wpw >= 0 ? packed + op.wpw : nullptr;
-            a.wph = op.wph >= 0 ? packed + op.wph : nullptr;
+            a.wph = (op.wph >= 0 && packed_h_valid) ? packed_h + op.wph : nullptr;      // present only while the option f16x2 is on
             a.wpb = op.wpb >= 0 ? packed + op.wpb : nullptr;
             a.bias = packed + op.bias;
             a.res = op.res.kind == REF_NONE ? nullptr : resolve(op.res, scratch_io, scratch_io, scratch_io, B);
@@ -1020,8 +1027,34 @@ void mcvd_model::sync_tuning_options() {
     }
 }
 
+// The two-piece fp16 forms of the weights (1.3 x the fp32 bytes for config 2) are packed when the option f16x2 first needs them, not at
+// every finalize: default-arithmetic models never allocate them.
+int mcvd_model::ensure_f16x2_weights() {
+    if (packed_h_valid || packed_h_floats == 0) return 0;
+    hipStream_t s = ctx->stream;
+    if (!packed_h) MCVD_HIP_CHECK(hipMalloc((void**)&packed_h, (size_t)packed_h_floats * sizeof(float)));
+    MCVD_HIP_CHECK(hipMemsetAsync(packed_h, 0, (size_t)packed_h_floats * sizeof(float), s));
+    for (const ConvPack& p : packs) {
+        if (p.wph < 0) continue;
+        if (p.ks == 3) {
+            const ParamInfo& w = params[find_param(p.weights[0].c_str())];             // Winograd layers have one weight tensor
+            if (int rc = launch_pack_wino2h_weight(blob + w.off, packed_h + p.wph, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
+        } else {
+            if (int rc = launch_pack_conv1x1_h2(packed + p.wp, packed_h + p.wph, p.CinP, p.CoutP, s, 2)) return rc;
+        }
+    }
+    MCVD_HIP_CHECK(hipStreamSynchronize(s));
+    packed_h_valid = true;
+    ++epoch;
+    return 0;
+}
+
 int mcvd_model::prepare_B(int B) {
     if (int rc = ensure_workspace(B)) return rc;
+    // (a forced two-piece kernel family -- the tests' conv_shape 12 / 13 / 14 -- needs the pieces as well as the option does)
+    const bool forced_h = (ctx->conv_shape >= 12 && ctx->conv_shape <= 14) || ctx->conv_shape1 == 14;
+    if (ctx->f16x2 || forced_h)
+        if (int rc = ensure_f16x2_weights()) return rc;
     sync_tuning_options();
     if (!ctx->naive_conv && tuned_B != B) {
         auto it = tuned_cache.find(B);

@@ -148,6 +148,10 @@ struct mcvd_model {
     std::vector<mcvd::ConvPack> packs;
     int64_t packed_floats = 0;
     float* packed = nullptr;          // kernel-layout weights (device)
+    float* packed_h = nullptr;        // the two-piece fp16 forms (ConvPack::wph offsets), allocated + packed on first use under the option f16x2
+    int64_t packed_h_floats = 0;
+    bool packed_h_valid = false;      // cleared by mcvd_model_finalize (new weights)
+    int ensure_f16x2_weights();
     int64_t dense_wt = -1, dense_bias = -1, freqs_off = -1;
     int NE = 0;                       // total Dense_0 outputs
     int T = 0;                        // temb width (4*ngf, + ngf/2 with cond_emb)

@@ -154,7 +154,7 @@ def gen_fpndm(name="tiny", batch=3, subsample=10):
           f"noclip range [{fin.min():.4f}, {fin.max():.4f}]")
 
 
-def gen_sampler_only(name, batch, subsample, kind="ddpm"):
+def gen_sampler_only(name, batch, subsample, kind="ddpm", measure_drift=False):
     """Full `ddpm_sampler` of the REAL reference at a full-width BASELINE config with the injected noise sequence: the final
     frames (full tensor, small) -- pins the oracle and the HIP path end-to-end at configs 3 / 4."""
     import models as ref_models
@@ -172,7 +172,23 @@ def gen_sampler_only(name, batch, subsample, kind="ddpm"):
             verbose=False, log=False)
     finally:
         torch.randn_like = orig
-    torch.save(dict(config_name=name, batch=batch, subsample=subsample, kind=kind, result=res.clone(), n_noise=inj.k),
+    extra = {}
+    if measure_drift:
+        # the same call in float64 (the oracle restatement, itself pinned to the reference at 2e-6 per forward: the reference hard-codes
+        # float32 in its timestep embedding and cannot run in double): |fp32 - fp64| is the noise floor a tolerance on this fixture has to
+        # stand on -- a deterministic sampler carries forward rounding through all of its steps
+        from oracle import sampler_ref
+        net64 = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123), dtype=torch.float64)
+        k = [0]
+
+        def fn(i, like):
+            k[0] += 1
+            return noise[k[0] - 1].to(like.dtype)
+        res64 = sampler_ref.sample(x.double().clone(), net64, cond=cond.double(), kind=kind, final_only=True, denoise=True,
+                                   subsample_steps=subsample, clip_before=True, noise_fn=fn)
+        extra["ref32_vs_ref64_max_abs"] = float((res.double() - res64.double()).abs().max())
+        print(f"  reference fp32 vs fp64 evaluation: {extra['ref32_vs_ref64_max_abs']:.3e}")
+    torch.save(dict(config_name=name, batch=batch, subsample=subsample, kind=kind, result=res.clone(), n_noise=inj.k, **extra),
                os.path.join(OUT, f"{name}_b{batch}_{kind}{subsample}.pt"))
     print(f"wrote {name}_b{batch}_{kind}{subsample}.pt  range [{res.min():.4f}, {res.max():.4f}]  draws {inj.k}")
 
@@ -419,6 +435,8 @@ def main_round2():
         gen_sampler_only("bair_big_spade", 2, 100)
     if "cfg5" in which:
         gen_autoregressive("cityscapes_big", 1, 8, 100)
+    if "cfg2ddim" in which:        # round 4: DDIM (deterministic: no per-step noise to wash rounding out) over 100 steps at the headline width
+        gen_sampler_only("smmnist_big5_ngf96", 2, 100, kind="ddim", measure_drift=True)
     if "f4" in which:
         gen_f4()
     if "cs_spade" in which:

@@ -103,3 +103,38 @@ def test_two_rank_sharded_sampling_matches_single_process(tmp_path):
     assert got.shape == want.shape
     # oneDNN picks batch-/thread-dependent blockings: fp32 noise floor between CPU runs (1.7e-6 per forward)
     assert (got - want).abs().max().item() <= 2e-5
+
+
+def test_eight_rank_launch_plan_with_uneven_shards(tmp_path):
+    """The launcher command bench.py builds for `--gpus 8` (bench.plan_launch: python -m torch.distributed.run, one rank per GPU,
+    127.0.0.1 rendezvous) started for real with 8 gloo ranks on the CPU, tests/dist_worker_cpu.py in place of bench.py: 11 rows over 8
+    ranks (shards of 2, 2, 2, 1, 1, 1, 1, 1), one weight broadcast, one gather -- the gathered frames must equal the single-process
+    result and every rank must report the shard shard_rows assigns it (VERDICT r3 task 7: the N = 8 rank / offset plumbing has to have
+    run somewhere before the driver's 8-GPU node does)."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    total, world = 11, 8
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_PORT=str(port), MCVD_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    cmd = bench.plan_launch(world, env, argv=[str(total), str(tmp_path)])
+    assert cmd is not None and cmd[-3].endswith("bench.py")
+    cmd[-3] = os.path.join(root, "tests", "dist_worker_cpu.py")                 # the CPU stand-in for the per-rank body of bench.py
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = torch.load(os.path.join(str(tmp_path), "gathered.pt"))
+    assert [tuple(v) for v in got["ranks"]] == [(r_,) + mdist.shard_rows(total, r_, world) for r_ in range(world)]
+    config = synth.make_config("tiny")
+    net = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123))
+    x, cond = synth.make_inputs(config, total, seed=0)
+    want = _sampler(x, net, cond=cond, sample_offset=0, config=config)[0]
+    assert got["frames"].shape == want.shape
+    assert (got["frames"] - want).abs().max().item() <= 2e-5

@@ -1149,6 +1149,28 @@ def test_full_width_sampler_vs_reference_golden(golden_dir, fx, path):
     assert err <= 1e-4, f"{fx} [{path}]: final frames max-abs err {err:.3e}"
 
 
+def test_ddim_100_at_the_headline_width_vs_reference_golden(golden_dir):
+    """`ddim_sampler` (models/__init__.py:102-203), 100 steps + denoise at BASELINE config 2 (ngf 96), B = 2, under the kernel table the
+    bench pins, against the REAL reference's frames.  DDIM draws no per-step noise, so forward rounding is carried -- and amplified --
+    through all 100 steps: the fixture records the reference's OWN fp32-vs-fp64 distance on this call (oracle/gen_golden.py:
+    gen_sampler_only(measure_drift=True)) and the tolerance is three times that, never below the 1e-4 contract of the noisy samplers."""
+    import json
+    from mcvd_pytorch_amd.samplers import ddim_sampler
+    g = torch.load(os.path.join(golden_dir, "smmnist_big5_ngf96_b2_ddim100.pt"), weights_only=False)
+    assert g["kind"] == "ddim" and g["subsample"] == 100 and g["n_noise"] == 0
+    config, sd, net = _net(g["config_name"])
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(golden_dir))), "profiles", "tune_smmnist_big5_ngf96_B64_bf16x3.json")
+    net.set_tuning(g["batch"], json.load(open(path))["64"])
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    tol = max(1e-4, 3.0 * g["ref32_vs_ref64_max_abs"])
+    for final_only in (True, False):                                  # device loop, host loop
+        out = ddim_sampler(x.cuda(), net, cond=cond.cuda(), denoise=True, subsample_steps=100, clip_before=True, verbose=False, log=False,
+                           final_only=final_only)[-1:].cpu()
+        assert out.shape == g["result"].shape
+        err = (out - g["result"]).abs().max().item()
+        assert err <= tol, f"DDIM-100 at ngf 96 (final_only={final_only}): {err:.3e} > {tol:.3e} (reference fp32 vs fp64: {g['ref32_vs_ref64_max_abs']:.3e})"
+
+
 @pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
 def test_bench_kernel_table_vs_reference_golden(golden_dir, arith):
     """The kernel table bench.py pins for the headline workload (profiles/tune_smmnist_big5_ngf96_B64_<arith>.json: tuned at B = 64 on
@@ -1614,20 +1636,60 @@ def test_direct_rccl_weight_broadcast_two_ranks(tmp_path):
     assert torch.equal(a, b)
 
 
-def test_bench_two_gpus(tmp_path):
-    """`bench.py --gpus 2` (self-launch, one rank per GPU over RCCL): the JSON line must report n_gpus 2, twice the frames of N = 1 per
-    step, both ranks' times, and the two ranks must not differ by more than 10 %.  Needs two GPUs: skipped on a one-GPU box."""
+def _bench_job(tmp_path, tag, gpus, batch, backend=None, tune_cache=None, save_tuning=None):
+    """One bench.py job (self-launching for gpus > 1): returns (JSON line, frames of the last timed step)."""
     import json
     import subprocess
     import sys
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--subsample", "5",
-                        "--batch", "8", "--no-cpu-baseline", "--no-f16x2-leg"], env=env, capture_output=True, text=True, timeout=900)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    if backend:
+        env["MCVD_DIST_BACKEND"] = backend
+    dump = os.path.join(str(tmp_path), f"frames_{tag}.pt")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--subsample", "5",
+           "--batch", str(batch), "--no-cpu-baseline", "--no-f16x2-leg", "--dump-frames", dump]
+    if tune_cache:
+        cmd += ["--tune-cache", tune_cache]
+    if save_tuning:
+        cmd += ["--save-tuning", save_tuning]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16 and d["config"]["frames_per_step"] == 80
+    return json.loads(r.stdout.strip().splitlines()[-1]), torch.load(dump)
+
+
+def _two_rank_job_matches_single_rank(tmp_path, backend):
+    """N = 2 ranks x batch 3 against N = 1 x batch 6 of the same global rows, same seeds (the Philox stream is keyed by the GLOBAL row)
+    and the SAME kernel table (the one the N = 1 job tuned at B = 6, installed for B = 3 as well): the gathered frames must be
+    bit-identical, the line must say two ranks took part."""
+    import json
+    d1, f1 = _bench_job(tmp_path, "n1", 1, 6, save_tuning=str(tmp_path))
+    table = json.load(open(os.path.join(str(tmp_path), "tune_smmnist_big5_ngf96_B6_bf16x3.json")))["6"]
+    cache = os.path.join(str(tmp_path), "table_both.json")
+    json.dump({"6": table, "3": table}, open(cache, "w"))
+    d1, f1 = _bench_job(tmp_path, "n1", 1, 6, tune_cache=cache)
+    d2, f2 = _bench_job(tmp_path, "n2", 2, 3, backend=backend, tune_cache=cache)
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["config"]["global_batch"] == 6 and d2["config"]["frames_per_step"] == 30
+    assert d2["rccl_ranks_seen"]["world_size"] == 2 and d2["rccl_ranks_seen"]["ranks"] == [0, 1]
+    assert d1["selfcheck_max_abs"] == 0.0 and d2["selfcheck_max_abs"] == 0.0
+    assert f1.shape == f2.shape == (6, 5, 64, 64)
+    assert torch.equal(f1, f2), f"N=2 frames differ from N=1: max {float((f1 - f2).abs().max()):.3e}"
+    return d2
+
+
+def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path):
+    """The N > 1 path of bench.py with real kernels on a ONE-GPU box: two ranks (gloo rendezvous and gather, both on device 0) -- row
+    shards, sample offsets, the weight broadcast, the final gather and rank 0's line -- against the single-rank job, bit for bit."""
+    _two_rank_job_matches_single_rank(tmp_path, "gloo")
+
+
+def test_bench_two_gpus(tmp_path):
+    """`bench.py --gpus 2` (self-launch, one rank per GPU over RCCL): bit-equal frames vs the N = 1 job of the same global batch under the
+    same kernel table (DESIGN.md section 1, row e), both ranks' devices in the line, and the two ranks' times within 10 % of each other.
+    Needs two GPUs: skipped on a one-GPU box (test_bench_two_ranks_on_one_gpu_match_single_rank covers the plumbing there)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    d = _two_rank_job_matches_single_rank(tmp_path, None)
+    assert d["rccl_ranks_seen"]["backend"] == "nccl" and sorted(d["rccl_ranks_seen"]["devices"]) == [0, 1]
     assert len(d["per_rank_s"]) == 2 and max(d["per_rank_s"]) <= 1.1 * min(d["per_rank_s"]), d["per_rank_s"]
