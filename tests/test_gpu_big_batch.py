@@ -73,6 +73,24 @@ def test_forward_at_the_benchmarked_batch(golden_dir, name, B, fx, nb, taps_too)
     torch.cuda.synchronize()
     assert torch.isfinite(eps).all()
     table = pinned or net.get_tuning(B)
+    if pinned:
+        # what the bench runs is what is tested: under the committed table every conv op must have run the kernel family the table names
+        # (mcvd_model_op_kernel reports what really executed; a hint that does not serve a launch falls back silently otherwise)
+        import ctypes as C
+        from mcvd_pytorch_amd import _lib
+        n = _lib.lib.mcvd_model_profile_read(net._model, None, None, None, None, None, 0)
+        assert n == len(table)
+        info, fams = (C.c_int * 8)(), set()
+        for i in range(n):
+            _lib.check(_lib.lib.mcvd_model_op_info(net._model, i, info), "op_info")
+            if info[0] != 3 or table[i][0] < 0:
+                continue
+            ran = _lib.lib.mcvd_model_op_kernel(net._model, i)
+            if ran == -1:
+                continue                 # cond-only (SPADE prep) convs run once per cond, not in this forward's record
+            assert ran == table[i][0], f"{name} B={B} op {i} ({info[2]}x{info[2]} {info[4]}->{info[5]} @{info[3]}): ran kernel {ran}, the committed table names {table[i][0]}"
+            fams.add(ran)
+        assert fams & {10, 11, 16, 17} and 15 in fams, f"{name}: kernel families that ran: {sorted(fams)}"
     eps_c = eps.cpu()
     # ---- rows 0..nb-1 against the real reference's output
     if "fwd_eps" in g:
