@@ -201,18 +201,21 @@ def roofline_of_leg(net, args, B, arith_name):
     executed = algorithmic * mult_ratio
     # HBM-side bytes per launch: NOT measured in this run -- read from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     # tools/gpu_check.sh prof) over the same launch population of the same kernel family, when such a file exists
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_sha = None, None, None
     try:
         if args.config == "smmnist_big5_ngf96" and B == 64:
             for fn in sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")):
                 tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if tj.get("family", "wino_f32") == dom_key and "traffic_bytes_per_launch" in tj:
+                    import hashlib
                     traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/" + fn      # the latest file of the family wins
+                    traffic_sha = hashlib.sha256(open(os.path.join(ROOT, "profiles", fn), "rb").read()).hexdigest()[:16]
     except Exception:
         traffic = None
     roofline = dict(bound="mfma", kernel=dom_name,
                     achieved=round(executed, 2), peak=pipe_peak, unit="TFLOP/s",
                     frac=round(executed / pipe_peak, 4), traffic=traffic, traffic_from_file=bool(traffic), traffic_source=traffic_src,
+                    traffic_file_sha16=traffic_sha,
                     note=("achieved / frac = flops the kernel EXECUTES on its matrix pipe (Winograd F(2x2,3x3): 16/36 of the "
                           "direct-form multiplies; x6 piece products for the three-piece bf16 kernel, x3 for the two-piece fp16 kernel) / "
                           "HIP-event time of its launches in one forward of the timed region / that pipe's dense peak, i.e. the matrix-pipe "
@@ -266,6 +269,8 @@ def main():
     ap.add_argument("--save-tuning", default=None, help="directory: write the table of every leg there (tune_<config>_B<batch>_<arithmetic>.json)")
     ap.add_argument("--no-tune-file", action="store_true", help="ignore committed tables: let the autotuner measure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the B = 1 recomputation of row 0 after the timed region (profiling runs: its "
+                    "101 single-sample forwards would enter the per-kernel averages of rocprofv3 --stats)")
     ap.add_argument("--dump-frames", default=None, help="file: rank 0 saves the gathered frames of the headline leg's last timed step (torch.save) "
                     "-- tests compare an N-rank job with the N = 1 job of the same global batch bit for bit")
     ap.add_argument("--no-f16x2-leg", "--no-fp32-leg", dest="no_second_leg", action="store_true",
@@ -317,20 +322,38 @@ def main():
     broadcast_weights(net, src=0)                    # ONE RCCL broadcast of the packed blob (no-op at N=1)
     net.set_option("profile", 1)
     net.set_option("graph", args.graph)
+    for kv in os.environ.get("MCVD_BENCH_OPTS", "").split(","):      # diagnostics: context options, e.g. MCVD_BENCH_OPTS=conv_shape=10,naive_attn=2
+        if kv:
+            net.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
     total = B * world
     b0, b1 = shard_rows(total, rank, world)
     x, cond = synthetic.random_inputs(config, b0, b1 - b0)
     x, cond = x.cuda(), cond.cuda()
 
-    def one_step(i):
+    # MCVD_BENCH_SERIALIZE=1 (tests that put several ranks on ONE GPU): the ranks take turns on the device instead of overlapping.  Two
+    # processes whose kernels share the CUs of one MI355X are not a supported configuration (one process per GPU is the design) -- and
+    # not a safe one: co-resident kernels of the two processes corrupted each other's results (profiles/r04_two_process_corruption.txt).
+    serialize = world > 1 and os.environ.get("MCVD_BENCH_SERIALIZE", "0") == "1"
+
+    def local_step(i):
         if autoreg:            # the whole autoregressive job: n_blocks sampler calls, cond shifted on the device, crop to nfp frames
             g = torch.Generator(device="cuda").manual_seed(1000 + i)
-            out = video_gen(config, net, cond, num_frames_pred=nfp, seed=1000 + i, sample_offset=b0,
-                            init_noise_fn=lambda k, shp, dev: torch.randn(shp, device=dev, generator=g))
+            return video_gen(config, net, cond, num_frames_pred=nfp, seed=1000 + i, sample_offset=b0,
+                             init_noise_fn=lambda k, shp, dev: torch.randn(shp, device=dev, generator=g))
+        return ddpm_sampler(x, net, cond=cond, final_only=True, denoise=True, subsample_steps=subsample,
+                            clip_before=True, verbose=False, log=False, seed=1000 + i, sample_offset=b0)[0]
+
+    def one_step(i):
+        if serialize:
+            out = None
+            for r in range(world):
+                if r == rank:
+                    out = local_step(i)
+                    torch.cuda.synchronize()
+                dist.barrier()
         else:
-            out = ddpm_sampler(x, net, cond=cond, final_only=True, denoise=True, subsample_steps=subsample,
-                               clip_before=True, verbose=False, log=False, seed=1000 + i, sample_offset=b0)[0]
+            out = local_step(i)
         return gather_rows(out, total)               # final gather of the generated frames
 
     def fence():
@@ -380,13 +403,20 @@ def main():
         last_seed = seed0 + steps - 1
         kw = dict(final_only=True, denoise=True, subsample_steps=subsample, clip_before=True, verbose=False, log=False,
                   seed=1000 + last_seed, sample_offset=b0)
-        if autoreg:        # (video_gen draws its block inits from a torch generator whose stream depends on the batch: check one block's sampler call)
-            full = ddpm_sampler(x, net, cond=cond, **kw)[0]
-        else:
-            full = frames[b0:b1]
-        net.set_tuning(1, net.get_tuning(b1 - b0))
-        one = ddpm_sampler(x[:1], net, cond=cond[:1], **kw)[0]
-        selfcheck = float((full[:1] - one).abs().max().item())
+        selfcheck = None
+        if not args.no_selfcheck:
+            if autoreg:    # (video_gen draws its block inits from a torch generator whose stream depends on the batch: check one block's sampler call)
+                full = ddpm_sampler(x, net, cond=cond, **kw)[0]
+            else:
+                full = frames[b0:b1]
+            net.set_tuning(1, net.get_tuning(b1 - b0))
+            for r in range(world if serialize else 1):
+                if not serialize or r == rank:
+                    one = ddpm_sampler(x[:1], net, cond=cond[:1], **kw)[0]
+                    torch.cuda.synchronize()
+                if serialize:
+                    dist.barrier()
+            selfcheck = float((full[:1] - one).abs().max().item())
         return dict(value=steps * total * nfp / dt, ms_per_step=1e3 * dt / steps, per_rank=per_rank, roofline=roofline, dtype=arith,
                     kernel_table=pinned or "autotuned in this run (HIP-event timing per distinct layer shape)", selfcheck_max_abs=selfcheck)
 

@@ -141,6 +141,16 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value);
  * mcvd_last_error) if any forward since the last call produced one, else 0, and clears the record.  mcvd_sampler_run / mcvd_fpndm_run
  * call it themselves before they return; a caller of mcvd_unet_forward* calls it when it wants the verdict. */
 int mcvd_ctx_check_range(mcvd_ctx* ctx);
+/* Runtime self-test of the hand-scheduled Winograd kernels: conv_wino3_kernel and conv_wino3p_kernel read and write
+ * registers the compiler is only kept away from by a function attribute and wait for their loads with hand-counted `s_waitcnt`; the
+ * build checks the generated code (tools/check_wino_isa.py), this call checks the running binary on the running device: one small
+ * 3x3 conv (64 -> 96 channels, 16 x 16, GroupNorm + SiLU prologue, residual) through shape ids 10 and 16 against the fp32-MFMA
+ * Winograd kernel (shape id 4: compiler-scheduled MFMAs).  10 vs 4 within 1e-4 of the output scale and 16 bit-equal to 10 -> returns 0
+ * (and 1 on later calls without re-running).  On a mismatch the context option "bf16x3" is switched OFF (every product then runs on the
+ * fp32 MFMA), the reason is left in mcvd_last_error and MCVD_ESELFTEST is returned.  mcvd_model_finalize runs it once per context;
+ * a result is bit-reproducible either way. */
+#define MCVD_ESELFTEST (-6)
+int mcvd_ctx_selftest(mcvd_ctx* ctx);
 /* Forgets a pending range verdict without reporting it (no synchronisation).  mcvd_sampler_run / mcvd_fpndm_run call it on entry, the
  * Python host loops at the start of every sampler call, and a change of the option "f16x2" implies it: a flag left behind by an earlier,
  * unrelated forward (or by a call that returned an error before its own check) must not fail the next run. */

@@ -39,6 +39,7 @@ _PROTOS = {
     "mcvd_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
     "mcvd_ctx_check_range": (_i, [_vp]),
     "mcvd_ctx_clear_range": (_i, [_vp]),
+    "mcvd_ctx_selftest": (_i, [_vp]),
     "mcvd_ctx_set_debug_buffer": (_i, [_vp, _vp]),
     "mcvd_model_create": (_i, [_vp, C.POINTER(UNetDesc), C.POINTER(_vp)]),
     "mcvd_model_destroy": (None, [_vp]),

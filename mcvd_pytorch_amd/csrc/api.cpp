@@ -5,7 +5,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <cmath>
 #include <new>
+#include <vector>
 
 #include "model.h"
 
@@ -113,6 +116,61 @@ int mcvd_ctx_check_range(mcvd_ctx* ctx) {
     set_error("f16x2: a UNet forward produced non-finite values -- an activation left the fp16 range of the two-piece kernels, or the model "
               "diverged; rerun with the option f16x2 = 0 (the default three-piece bf16 arithmetic has the fp32 range)");
     return MCVD_ERANGE;
+    API_CATCH
+}
+
+int mcvd_ctx_selftest(mcvd_ctx* ctx) {
+    API_TRY
+    MCVD_REQUIRE(ctx, "ctx is NULL");
+    if (ctx->wino_selftest == 1) return 1;
+    if (ctx->wino_selftest < 0) return MCVD_ESELFTEST;
+    constexpr int B = 1, Cin = 64, Cout = 96, H = 16;
+    const size_t nx = (size_t)B * Cin * H * H, nw = (size_t)Cout * Cin * 9, ny = (size_t)B * Cout * H * H;
+    std::vector<float> host(nx + nw + Cout + 2 * Cin + ny);
+    unsigned st = 0x9e3779b9u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)((st >> 8) & 0xffff) / 32768.0f - 1.0f; };     // [-1, 1)
+    for (size_t i = 0; i < nx; ++i) host[i] = 1.7f * rnd();
+    for (size_t i = 0; i < nw; ++i) host[nx + i] = rnd() * 0.0417f;                       // ~ 1 / sqrt(Cin * 9)
+    for (int i = 0; i < Cout; ++i) host[nx + nw + i] = 0.1f * rnd();
+    for (int i = 0; i < Cin; ++i) { host[nx + nw + Cout + 2 * i] = 1.0f + 0.3f * rnd(); host[nx + nw + Cout + 2 * i + 1] = 0.3f * rnd(); }
+    for (size_t i = 0; i < ny; ++i) host[nx + nw + Cout + 2 * Cin + i] = rnd();
+    float* dev = nullptr;
+    MCVD_HIP_CHECK(hipMalloc((void**)&dev, (host.size() + 3 * ny) * sizeof(float)));
+    struct Free { float* p; ~Free() { (void)hipFree(p); } } guard{dev};
+    MCVD_HIP_CHECK(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    const float *x = dev, *w = dev + nx, *bias = w + nw, *coef = bias + Cout, *res = coef + 2 * Cin;
+    float* y = dev + host.size();
+    const int saved_shape = ctx->conv_shape, saved_naive = ctx->naive_conv;
+    const int shapes[3] = {4, 10, 16};
+    int rc = 0, ran[3] = {-1, -1, -1};
+    ctx->naive_conv = 0;
+    for (int k = 0; k < 3 && rc == 0; ++k) {
+        ctx->conv_shape = shapes[k];
+        rc = mcvd_op_conv2d(ctx, x, Cin, nullptr, 0, w, bias, Cout, 3, coef, 1, res, 0.70710678f, y + k * ny, B, H, H);
+        ran[k] = last_conv_kernel();
+    }
+    ctx->conv_shape = saved_shape;
+    ctx->naive_conv = saved_naive;
+    if (rc) return rc;
+    std::vector<float> out(3 * ny);
+    MCVD_HIP_CHECK(hipMemcpyAsync(out.data(), y, 3 * ny * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    MCVD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    float scale = 0.0f, d10 = 0.0f;
+    size_t diff16 = 0;
+    for (size_t i = 0; i < ny; ++i) {
+        scale = std::max(scale, std::fabs(out[i]));
+        d10 = std::max(d10, std::fabs(out[ny + i] - out[i]));
+        diff16 += memcmp(&out[2 * ny + i], &out[ny + i], sizeof(float)) != 0;
+    }
+    const bool ok = ran[0] == 4 && ran[1] == 10 && ran[2] == 16 && scale > 0.1f && d10 <= 1e-4f * scale && diff16 == 0 && std::isfinite(d10);
+    if (ok) { ctx->wino_selftest = 1; return 0; }
+    ctx->wino_selftest = -1;
+    ctx->bf16x3 = 0;
+    ++ctx->epoch;
+    set_error("self-test of the hand-scheduled Winograd kernels FAILED on this device (kernels that ran: %d %d %d; |bf16x3 - fp32 MFMA| = %.3e at "
+              "scale %.3e; %zu values of the persistent form differ from the per-item form): the option bf16x3 was switched off for this context",
+              ran[0], ran[1], ran[2], (double)d10, (double)scale, diff16);
+    return MCVD_ESELFTEST;
     API_CATCH
 }
 
@@ -227,6 +285,7 @@ void mcvd_model_destroy(mcvd_model* m) {
     if (m->blob) (void)hipFree(m->blob);
     if (m->packed) (void)hipFree(m->packed);
     if (m->packed_h) (void)hipFree(m->packed_h);
+    if (m->coef2_desc_dev) (void)hipFree(m->coef2_desc_dev);
     if (m->arena) (void)hipFree(m->arena);
     if (m->labels) (void)hipFree(m->labels);
     if (m->eps_buf) (void)hipFree(m->eps_buf);
@@ -360,12 +419,38 @@ int mcvd_model_finalize(mcvd_model* m) {
     }
     MCVD_HIP_CHECK(hipMemcpyAsync(m->packed + m->freqs_off, m->freqs.data(), m->freqs.size() * sizeof(float),
                                   hipMemcpyHostToDevice, s));
+    {   // SPADE nets: the descriptors of every (1 + scale, shift) table (model.cpp: OP_COEF2)
+        std::vector<long long> desc;
+        m->coef2_first = -1; m->coef2_count = 0; m->coef2_cmax = 0;
+        bool all_arena = true;
+        for (size_t i = 0; i < m->ops.size(); ++i) {
+            const Op& op = m->ops[i];
+            if (op.kind != OP_COEF2 || op.prep) continue;
+            if (m->coef2_first < 0) m->coef2_first = (int)i;
+            all_arena = all_arena && op.dst.kind == REF_ARENA;
+            desc.push_back((long long)op.dst.off); desc.push_back(op.emb_off); desc.push_back(op.Cout);
+            m->coef2_cmax = std::max(m->coef2_cmax, op.Cout);
+            ++m->coef2_count;
+        }
+        if (m->coef2_count > 1 && all_arena) {
+            if (m->coef2_desc_dev) (void)hipFree(m->coef2_desc_dev);
+            m->coef2_desc_dev = nullptr;
+            MCVD_HIP_CHECK(hipMalloc((void**)&m->coef2_desc_dev, desc.size() * sizeof(long long)));
+            MCVD_HIP_CHECK(hipMemcpyAsync(m->coef2_desc_dev, desc.data(), desc.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+            MCVD_HIP_CHECK(hipStreamSynchronize(s));          // `desc` is a local
+        } else {
+            m->coef2_count = 0;
+        }
+    }
     MCVD_HIP_CHECK(hipStreamSynchronize(s));
     m->finalized = true;
     m->packed_h_valid = false;             // the two-piece fp16 forms follow the weights: repacked on the next use under f16x2
     ++m->epoch;
     if (m->ctx->f16x2)
         if (int rc = m->ensure_f16x2_weights()) return rc;
+    // once per context: the hand-scheduled Winograd kernels against the compiler-scheduled one, on this device (a failure switches the
+    // option bf16x3 off and is reported by mcvd_ctx_selftest / mcvd_last_error; the model stays usable on the fp32-MFMA kernels)
+    if (m->ctx->wino_selftest == 0 && m->ctx->bf16x3 && m->ctx->winograd) (void)mcvd_ctx_selftest(m->ctx);
     return 0;
     API_CATCH
 }
@@ -520,7 +605,9 @@ int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, doub
     for (int i = 0; i < n; ++i) {
         const Op& op = m->ops[i];
         float t = 0.f;
-        if (!op.prep) MCVD_HIP_CHECK(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
+        // (the (1 + scale, shift) table ops behind the first one launch nothing: the first fills every table -- model.cpp OP_COEF2)
+        const bool noop = op.kind == OP_COEF2 && m->coef2_count > 1 && (int)i != m->coef2_first;
+        if (!op.prep && !noop) MCVD_HIP_CHECK(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
         kinds[i] = (int)op.kind;
         ks[i] = op.kind == OP_CONV ? op.ks : 0;
         ms[i] = t;

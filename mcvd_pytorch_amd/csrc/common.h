@@ -186,6 +186,8 @@ int launch_upfirdn2d(const float* in, const float* kernel_dev, int kh, int kw, i
 int launch_spade_apply(const float* x0, int C0, const float* x1, int C1, const float* coef, const float* gb,
                        const float* coef2, float* y, int B, int HW, hipStream_t s);
 int launch_coef2(const float* emb, int emb_stride, int emb_off, float* coef2, int B, int C, hipStream_t s);
+// all tables of a forward at once: desc_dev[3 t] = {arena offset per sample, emb_off, C} (device, int64); coef2 table t = arena + off * B
+int launch_coef2_all(const float* emb, int emb_stride, const long long* desc_dev, int ntab, int cmax, float* arena, int B, hipStream_t s);
 int launch_nearest_resize(const float* in, float* out, int BC, int H, int W, int oh, int ow, hipStream_t s);
 
 // ------------------------------------------------------------------ time embedding

@@ -319,6 +319,27 @@ int launch_coef2(const float* emb, int emb_stride, int emb_off, float* coef2, in
     return 0;
 }
 
+// every (1 + scale, shift) table of a forward in ONE launch (a SPADE net has one per normalisation: 56 launches of coef2_kernel per
+// forward at BASELINE config 4, each a few hundred bytes of work behind a full launch): table t = blockIdx.y, desc[t] = {arena offset per
+// sample of the table, column of its Dense_0 block in the fused embedding row, channels}
+__global__ void coef2_all_kernel(const float* emb, int emb_stride, const long long* desc, float* arena, int B) {
+    const long long* d = desc + 3 * blockIdx.y;
+    const int C = (int)d[2], emb_off = (int)d[1];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const float* e = emb + (long)b * emb_stride + emb_off;
+    float* coef2 = arena + d[0] * (long long)B;
+    coef2[2 * i] = 1.0f + e[c];
+    coef2[2 * i + 1] = e[C + c];
+}
+
+int launch_coef2_all(const float* emb, int emb_stride, const long long* desc_dev, int ntab, int cmax, float* arena, int B, hipStream_t s) {
+    hipLaunchKernelGGL(coef2_all_kernel, dim3((B * cmax + 255) / 256, ntab), dim3(256), 0, s, emb, emb_stride, desc_dev, arena, B);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // F.interpolate(mode='nearest'): src = floor(dst * in/out)
 __global__ void nearest_kernel(const float* in, float* out, int BC, int H, int W, int oh, int ow) {
     const long n = (long)BC * oh * ow;

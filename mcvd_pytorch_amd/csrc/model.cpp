@@ -841,9 +841,18 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             return launch_cond_noise(cond, z, alphas_dev, static_cast<const int64_t*>(lab), d.num_classes,
                                      resolve(op.dst, x, cond, out, B), B, per, s);
         }
-        case OP_COEF2:
+        case OP_COEF2: {
+            // the FIRST table op of the plan fills every table of the forward in one launch (they all read the fused Dense_0 row, which
+            // is complete before any of them); the others are no-ops.  All tables are arena tensors.
+            const int self = (int)(&op - ops.data());
+            if (coef2_desc_dev && coef2_count > 1) {
+                if (self != coef2_first) return 0;
+                return launch_coef2_all(resolve(ops[1].dst, x, cond, out, B), (uniform_labels && !d.cond_emb) ? 0 : NE, coef2_desc_dev,
+                                        coef2_count, coef2_cmax, arena, B, s);
+            }
             return launch_coef2(resolve(ops[1].dst, x, cond, out, B), (uniform_labels && !d.cond_emb) ? 0 : NE, op.emb_off,
                                 resolve(op.dst, x, cond, out, B), B, op.Cout, s);
+        }
         case OP_APPLY:
             if (op.gn_src >= 0)
                 if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;

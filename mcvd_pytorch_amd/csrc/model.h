@@ -22,6 +22,8 @@ struct mcvd_ctx {
                                    //    every 3x3 conv AND every 1x1 conv of a model on chosen kernels at once
     int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
     int persist_grid = 0;          // > 0: workgroups of the persistent Winograd kernel (tests); 0 = one per CU
+    int wino_selftest = 0;         // 0 not run yet, 1 passed, -1 FAILED: the hand-scheduled bf16 Winograd kernels disagree with the fp32-MFMA Winograd
+                                   //    kernel on this device / driver (mcvd_ctx_selftest); bf16x3 was switched off for this context
     int conv_cot = 0;              // > 0 with conv_shape 5: cout tile (32-channel units) mcvd_op_conv2d requests (tests)
     int bf16x3 = 1;                // offer the three-piece bf16 kernels (conv_wino3.cpp, conv1x1_h2.cpp, attention_h2.cpp with NP = 3: fp32-equivalent
                                    //    arithmetic, full fp32 range) to the autotuner / the attention dispatch.  On by default.
@@ -148,6 +150,8 @@ struct mcvd_model {
     std::vector<mcvd::ConvPack> packs;
     int64_t packed_floats = 0;
     float* packed = nullptr;          // kernel-layout weights (device)
+    long long* coef2_desc_dev = nullptr;   // SPADE nets: {arena offset, emb_off, C} of every (1 + scale, shift) table (launch_coef2_all), uploaded at finalize
+    int coef2_first = -1, coef2_count = 0, coef2_cmax = 0;      // plan index of the first OP_COEF2 (it fills every table), number of tables, widest
     float* packed_h = nullptr;        // the two-piece fp16 forms (ConvPack::wph offsets), allocated + packed on first use under the option f16x2
     int64_t packed_h_floats = 0;
     bool packed_h_valid = false;      // cleared by mcvd_model_finalize (new weights)

@@ -194,9 +194,18 @@ class HipScoreNet:
                 _lib.check(_lib.lib.mcvd_model_set_param(self._model, k.encode(), _fptr(p.data), shape, p.dim(), 1),
                            f"set_param({k})")
             _lib.check(_lib.lib.mcvd_model_finalize(self._model), "finalize")
+            self._report_selftest()
             _lib.check(_lib.lib.mcvd_model_invalidate_cond(self._model))
         self._cond_key = None
         self._dirty = False
+
+    def _report_selftest(self):
+        """mcvd_model_finalize runs the library's self-test of its hand-scheduled Winograd kernels once per context (include/mcvd_hip.h:
+        mcvd_ctx_selftest).  A failure is not fatal -- the library falls back to its fp32-MFMA kernels -- but it must not be silent."""
+        rc = _lib.lib.mcvd_ctx_selftest(self._ctx)
+        if rc < 0:
+            import warnings
+            warnings.warn("mcvd_hip: " + _lib.last_error() + " (results stay within the fp32 contract; throughput is lower)", RuntimeWarning)
 
     def eval(self):
         self.training = False
@@ -262,6 +271,7 @@ class HipScoreNet:
             self._bind_stream()
             _lib.check(_lib.lib.mcvd_model_import_blob(self._model, _fptr(blob.contiguous())), "import_blob")
             _lib.check(_lib.lib.mcvd_model_finalize(self._model), "finalize")
+            self._report_selftest()
             # keep the python-visible copies coherent
             name, shape, ndim, off = C.c_char_p(), (C.c_int64 * 4)(), C.c_int(), C.c_int64()
             for i, (k, p) in enumerate(self._params.items()):

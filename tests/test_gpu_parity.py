@@ -1647,6 +1647,8 @@ def _bench_job(tmp_path, tag, gpus, batch, backend=None, tune_cache=None, save_t
         env.pop(k, None)
     if backend:
         env["MCVD_DIST_BACKEND"] = backend
+        if backend == "gloo":            # several ranks on ONE GPU: they take turns on the device (bench.py: MCVD_BENCH_SERIALIZE)
+            env["MCVD_BENCH_SERIALIZE"] = "1"
     dump = os.path.join(str(tmp_path), f"frames_{tag}.pt")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--subsample", "5",
            "--batch", str(batch), "--no-cpu-baseline", "--no-f16x2-leg", "--dump-frames", dump]
@@ -1680,7 +1682,10 @@ def _two_rank_job_matches_single_rank(tmp_path, backend):
 
 def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path):
     """The N > 1 path of bench.py with real kernels on a ONE-GPU box: two ranks (gloo rendezvous and gather, both on device 0) -- row
-    shards, sample offsets, the weight broadcast, the final gather and rank 0's line -- against the single-rank job, bit for bit."""
+    shards, sample offsets, the weight broadcast, the final gather and rank 0's line -- against the single-rank job, bit for bit.
+    The ranks take turns on the device: two processes that overlap on one GPU are outside the design (one process per GPU), and this
+    test's first form found out why they must be -- kernels of the two processes that share a SIMD corrupt each other
+    (profiles/r04_two_process_corruption.txt; not a property of the multi-rank plumbing under test here)."""
     _two_rank_job_matches_single_rank(tmp_path, "gloo")
 
 

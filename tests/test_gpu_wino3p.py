@@ -116,3 +116,32 @@ def test_persistent_kernel_leaves_no_stale_pipeline_state(ctx):
         ctx.opt("persist_grid", 0)
     for a, b in zip(outs[:4], outs[4:]):
         assert torch.equal(a, b)
+
+
+def test_runtime_selftest_of_the_hand_scheduled_kernels(ctx):
+    """mcvd_ctx_selftest: shape 10 vs the compiler-scheduled fp32 Winograd kernel within 1e-4, shape 16 bit-equal to shape 10,
+    on the running device; 0 the first time, 1 (cached verdict) afterwards; the forced kernel options of the context are restored."""
+    from mcvd_pytorch_amd import _lib
+    ctx.opt("conv_shape", 12)
+    try:
+        assert _lib.lib.mcvd_ctx_selftest(ctx.h) in (0, 1), _lib.last_error()
+        assert _lib.lib.mcvd_ctx_selftest(ctx.h) == 1
+        # the option was put back: a conv under it still takes the forced family's fallback chain, not shape 16
+        x = torch.randn(1, 64, 16, 16, device="cuda")
+        w = torch.randn(32, 64, 3, 3, device="cuda") / 24.0
+        ctx.conv2d(x, w, torch.zeros(32, device="cuda"))
+        assert _lib.lib.mcvd_last_conv_kernel() in (4, 12)          # (raw input: the f16x2 family applies only with a GroupNorm prologue)
+    finally:
+        ctx.opt("conv_shape", -1)
+
+
+def test_models_run_the_selftest_at_finalize():
+    from oracle import synth
+    from mcvd_pytorch_amd import _lib
+    from mcvd_pytorch_amd.scorenet import HipScoreNet
+    config = synth.make_config("tiny")
+    config.device = "cuda:0"
+    net = HipScoreNet(config)
+    net.load_state_dict(synth.make_state_dict(config, seed=123), strict=True)
+    net.sync_parameters(force=True)
+    assert _lib.lib.mcvd_ctx_selftest(net._ctx) == 1          # already run (and passed) by mcvd_model_finalize

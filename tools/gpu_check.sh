@@ -44,29 +44,29 @@ others)
   done;;
 prof)
   cd /tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f16x2-leg > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_bench.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f16x2-leg --no-selfcheck > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_bench.err
   # HBM-side PMC counters, each in its own run (kernel-trace only); the kernel table comes from the cache: no autotune launches
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --graph 0 > $R/gpurun_out/pmc_fetch.json 2> $R/gpurun_out/pmc_fetch.err
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --graph 0 > $R/gpurun_out/pmc_write.json 2> $R/gpurun_out/pmc_write.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --no-selfcheck --graph 0 > $R/gpurun_out/pmc_fetch.json 2> $R/gpurun_out/pmc_fetch.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --no-selfcheck --graph 0 > $R/gpurun_out/pmc_write.json 2> $R/gpurun_out/pmc_write.err
   cd $R; python tools/summarize_prof.py > gpurun_out/prof_summary.txt 2>&1; head -40 gpurun_out/prof_summary.txt
   python tools/summarize_prof.py traffic gpurun_out/conv3x3_traffic.json > gpurun_out/traffic.log 2>&1; tail -3 gpurun_out/traffic.log
   find gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -size +20M -delete;;
 pmc_mfma)
   cd /tmp
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_mfma -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --graph 0 > $R/gpurun_out/pmc_mfma.json 2> $R/gpurun_out/pmc_mfma.err
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_mfma -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --no-selfcheck --graph 0 > $R/gpurun_out/pmc_mfma.json 2> $R/gpurun_out/pmc_mfma.err
   cd $R; python tools/summarize_prof.py mfma > gpurun_out/pmc_mfma_summary.txt 2>&1; head -30 gpurun_out/pmc_mfma_summary.txt
   find gpurun_out/pmc_mfma -name "*.csv" -size +20M -delete;;
 pmc_l2)
   # L2 side of the dominant kernel: hit rate and request counts (one pass per TCC / TCP group)
   cd /tmp
-  rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $R/gpurun_out/pmc_l2a -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --graph 0 > $R/gpurun_out/pmc_l2a.json 2> $R/gpurun_out/pmc_l2a.err
-  rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum --output-format csv -d $R/gpurun_out/pmc_l2b -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --graph 0 > $R/gpurun_out/pmc_l2b.json 2> $R/gpurun_out/pmc_l2b.err
+  rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $R/gpurun_out/pmc_l2a -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --no-selfcheck --graph 0 > $R/gpurun_out/pmc_l2a.json 2> $R/gpurun_out/pmc_l2a.err
+  rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum --output-format csv -d $R/gpurun_out/pmc_l2b -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --no-selfcheck --graph 0 > $R/gpurun_out/pmc_l2b.json 2> $R/gpurun_out/pmc_l2b.err
   cd $R; python tools/summarize_prof.py l2 > gpurun_out/pmc_l2_summary.txt 2>&1; head -40 gpurun_out/pmc_l2_summary.txt; tail -3 gpurun_out/pmc_l2a.err gpurun_out/pmc_l2b.err
   find gpurun_out/pmc_l2a gpurun_out/pmc_l2b -name "*.csv" -size +20M -delete;;
 pmc_sq)
   # wave-state split of the kernels: parked (s_waitcnt / barrier) vs issue-stalled (pipe busy) vs issuing; LDS conflicts
   cd /tmp
-  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/pmc_sq -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --graph 0 > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/pmc_sq -o bench -- python $R/bench.py --steps 1 --warmup 0 --subsample 5 --no-cpu-baseline --no-f16x2-leg --no-selfcheck --graph 0 > $R/gpurun_out/pmc_sq.json 2> $R/gpurun_out/pmc_sq.err
   cd $R; python tools/summarize_prof.py sq > gpurun_out/pmc_sq_summary.txt 2>&1; head -30 gpurun_out/pmc_sq_summary.txt
   find gpurun_out/pmc_sq -name "*.csv" -size +20M -delete;;
 *) echo "unknown mode $MODE";;

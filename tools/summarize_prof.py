@@ -145,8 +145,8 @@ def traffic(out_json):
                "with the fp32 Winograd K-split ops and are left out: 3 x 8 us of 41 ops)", "per_instantiation": {}}
         fam = lambda k: k.startswith("conv_wino2h_kernel")
     elif dom.startswith("conv_wino3_kernel"):
-        res = {"family": "wino_bf16x3", "kernel_family": "conv_wino3_kernel<*>", "per_instantiation": {}}
-        fam = lambda k: k.startswith("conv_wino3_kernel")
+        res = {"family": "wino_bf16x3", "kernel_family": "conv_wino3_kernel<*> + conv_wino3p_kernel<*> (the same kernel as persistent workgroups)", "per_instantiation": {}}
+        fam = lambda k: k.startswith("conv_wino3_kernel") or k.startswith("conv_wino3p_kernel")
     else:
         res = {"family": "wino_f32", "kernel_family": "conv_wino_kernel<*> + wino_ksplit_reduce_kernel", "per_instantiation": {}}
         fam = lambda k: k.startswith("conv_wino_kernel") or k.startswith("wino_ksplit_reduce")
