@@ -99,6 +99,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
     if (it0 >= it1) return;
     const int rg = __builtin_amdgcn_readfirstlane(wave >> 2);   // rows 2rg, 2rg+1 of B^T d; phase order of the wave
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // diagnostics build only (env MCVD_W3P_EXP, WRONG RESULTS, timing only): bit 0 the transform stores one bf16 piece three times instead of
+    // splitting (what the split costs the staging phase), bit 1 and one store instead of three (what an fp32 V with 8-byte stores would save)
+#ifdef MCVD_DIAG
+    const bool WP_EXP_NOSPLIT = (a.pgrid & (1 << 20)) != 0, WP_EXP_ONESTORE = (a.pgrid & (1 << 21)) != 0;
+#else
+    constexpr bool WP_EXP_NOSPLIT = false, WP_EXP_ONESTORE = false;
+#endif
 #ifdef MCVD_DIAG
     // diagnostics build only (env MCVD_W3P_STAGGER = cycles / 256): the odd workgroups start late.  All workgroups of this kernel run in
     // lock step (same work, same start); the experiment measures what the simultaneous epilogues / weight requests of 256 CUs cost.
@@ -242,10 +249,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
             const f32x2 v0 = m0 - m2, v1 = m1 + m2, v2 = m2 - m1, v3 = m1 - m3;                                 \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
                 unsigned w1, w2, w3;                                                                            \
-                wp_split3(q == 0 ? v0 : q == 1 ? v1 : q == 2 ? v2 : v3, w1, w2, w3);                            \
+                const f32x2 vq = q == 0 ? v0 : q == 1 ? v1 : q == 2 ? v2 : v3;                                  \
+                if (WP_EXP_NOSPLIT) { w1 = wp_cvt_pk(vq.x, vq.y); w2 = w3 = w1; }      /* diagnostics, timing only */ \
+                else wp_split3(vq, w1, w2, w3);                                                                 \
                 vdst[(row * 4 + q) * 256] = w1;                                                                 \
-                vdst[(row * 4 + q) * 256 + PW] = w2;                                                            \
-                vdst[(row * 4 + q) * 256 + 2 * PW] = w3;                                                        \
+                if (!WP_EXP_ONESTORE) {                                                                         \
+                    vdst[(row * 4 + q) * 256 + PW] = w2;                                                        \
+                    vdst[(row * 4 + q) * 256 + 2 * PW] = w3;                                                    \
+                }                                                                                               \
             }                                                                                                   \
         }                                                                                                       \
     }
@@ -625,7 +636,7 @@ static int wino3p_launch2(const ConvArgs& a, hipStream_t s) {
     }
     const int ksp = a.ksplit == 2 ? 2 : 1;
     const long n_items = (long)a.B * (a.H / 8) * (a.W / 16) * (a.CoutP / BCO) * ksp;
-    const int cus = a.pgrid > 0 ? a.pgrid : wino3p_num_cus();
+    const int cus = (a.pgrid & 0xfffff) > 0 ? (a.pgrid & 0xfffff) : wino3p_num_cus();
     dim3 grid((unsigned)(n_items < cus ? n_items : cus));
     ConvArgs k = a;
     if (k.dbg) k.wdma = 0;                 // wave 0 records its phase times
@@ -636,6 +647,7 @@ static int wino3p_launch2(const ConvArgs& a, hipStream_t s) {
     }
     k.wdma &= 0xff;
     if (const char* st = getenv("MCVD_W3P_STAGGER")) k.wdma |= atoi(st) << 8;
+    if (const char* ex = getenv("MCVD_W3P_EXP")) k.pgrid |= atoi(ex) << 20;
 #else
     k.wdma &= 0xff;
 #endif
