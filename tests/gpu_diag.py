@@ -192,6 +192,7 @@ def phases(f):
                 " ".join(f"{n} {100 * m[i] / m[7]:.1f}%" for i, n in enumerate(names[:7])) + "\n")
         f.flush()
     ctx.opt("conv_shape", -1)
+    ctx.opt("wino_cs", 0)
 
 
 def wphases(f):
@@ -603,13 +604,16 @@ def w3ptl(f):
         res = torch.randn(B, cout, H, H, device="cuda")
         line = f"cin{cin:4d} cout{cout:4d} H{H:3d}:"
         ref = None
-        for shp in (10, 16, 11, 17):
+        for shp in (10, 16, 16 + 100, 11, 17, 17 + 100):          # + 100: the consumer-side split form of the persistent kernel (option wino_cs)
+            ctx.opt("wino_cs", 1 if shp >= 100 else 0)
+            tag = shp
+            shp = shp % 100
             ctx.opt("conv_shape", shp)
             for _ in range(3):
                 y = ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
             ran = _lib.lib.mcvd_last_conv_kernel()
             if ran != shp:
-                line += f"  [{shp}: n/a]"
+                line += f"  [{tag}: n/a]"
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -617,7 +621,7 @@ def w3ptl(f):
                 ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)
             e1.record()
             torch.cuda.synchronize()
-            line += f"  [{shp}: {e0.elapsed_time(e1) * 1e3 / 6:7.1f} us]"
+            line += f"  [{tag}: {e0.elapsed_time(e1) * 1e3 / 6:7.1f} us]"
             if shp in (10, 11):
                 ref = y.clone()
             elif ref is not None:

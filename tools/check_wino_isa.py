@@ -226,34 +226,41 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_
                 dests |= _regs(l.split(",")[0])
             # the exit edge: the last conditional branch of the loop that leaves it (else the code laid out behind the loop)
             inside = {re.match(r"^(\.LBB\d+_\d+):", l).group(1) for l in lines[i0:j] if re.match(r"^\.LBB\d+_\d+:", l)}
-            start = j
-            for l in reversed(lines[i0:j]):
+            # every conditional branch of the loop to a label outside its span is a candidate exit; a candidate whose path runs straight back
+            # into the loop (a latch block the compiler laid out in front of the header) is a back edge, not an exit
+            starts = []
+            for l in lines[i0:j]:
                 bm = re.match(r"^s_cbranch_\w+ (\.LBB\d+_\d+)", l)
                 if bm and bm.group(1) not in inside:
                     tgt = [k for k, t in enumerate(lines) if t.startswith(bm.group(1) + ":")]
-                    if tgt:
-                        start = tgt[0]
-                    break
-            pos, steps = start, 0
-            while pos < len(lines) and steps < 4000:          # follow the fall-through path and unconditional branches
-                t = lines[pos]
-                pos += 1
-                steps += 1
-                if re.match(r"^\.LBB", t):
-                    continue
-                bm = re.match(r"^s_(?:branch|cbranch_execnz) (\.LBB\d+_\d+)", t)      # (EXEC is never zero in this kernel)
-                if bm:
-                    tgt = [k for k, u in enumerate(lines) if u.startswith(bm.group(1) + ":")]
-                    if not tgt:
+                    if tgt and tgt[0] not in starts:
+                        starts.append(tgt[0])
+            if not starts:
+                starts = [j]
+            for start in starts:
+                pos, steps = start, 0
+                while pos < len(lines) and steps < 4000:          # follow the fall-through path and unconditional branches
+                    t = lines[pos]
+                    pos += 1
+                    steps += 1
+                    lm = re.match(r"^(\.LBB\d+_\d+):", t)
+                    if lm and lm.group(1) in inside:
+                        break                                      # back inside the loop: this candidate was a back edge
+                    if re.match(r"^\.LBB", t):
+                        continue
+                    bm = re.match(r"^s_(?:branch|cbranch_execnz) (\.LBB\d+_\d+)", t)      # (EXEC is never zero in this kernel)
+                    if bm:
+                        tgt = [k for k, u in enumerate(lines) if u.startswith(bm.group(1) + ":")]
+                        if not tgt:
+                            break
+                        pos = tgt[0]
+                        continue
+                    if re.match(r"^s_waitcnt.*vmcnt\(0\)", t):
                         break
-                    pos = tgt[0]
-                    continue
-                if re.match(r"^s_waitcnt.*vmcnt\(0\)", t):
-                    break
-                ops = t.split(None, 1)
-                if len(ops) > 1 and not t.startswith("s_waitcnt") and _regs(ops[1]) & dests:
-                    problems.append(f"{name}: `{t}` touches a K-loop load destination after the loop, before vmcnt(0)")
-                    break
+                    ops = t.split(None, 1)
+                    if len(ops) > 1 and not t.startswith("s_waitcnt") and _regs(ops[1]) & dests:
+                        problems.append(f"{name}: `{t}` touches a K-loop load destination after the loop, before vmcnt(0)")
+                        break
         if kloops != nloops:
             problems.append(f"{name}: expected {nloops} K loop(s), found {kloops}")
         # anywhere in the kernel (prologue and epilogue included): the registers from `named0` up are touched by the kernel's own asm
@@ -280,8 +287,8 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_
 def check3p(asm_text):
     """conv_wino3p_kernel<COT, PRO> (persistent workgroups): the K loops are the two innermost loops (one per phase order) of the
     run / item loop nest; same VMEM population per chunk as conv_wino3_kernel."""
-    return check3(asm_text, kernel="18conv_wino3p_kernel", asm_mfma=True, expect=9, wl_per_cot=6, nloops=2, npatch=(3, 3), wreg0=184, named0=172,
-                  targs=r"ILi(\d)ELi(\d)E()EE", nested=True)
+    return check3(asm_text, kernel="18conv_wino3p_kernel", asm_mfma=True, expect=18, wl_per_cot=6, nloops=2, npatch=(3, 3), wreg0=184, named0=172,
+                  targs=r"ILi(\d)ELi(\d)ELb([01])EEE", nested=True)          # x {split by the transform, split by the consumer}
 
 
 def check2h(asm_text):
