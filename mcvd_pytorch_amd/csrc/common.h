@@ -82,7 +82,6 @@ struct ConvArgs {
                           // `part`, a second pass sums the halves; 0/1 = off
     float* part;          // ksplit == 2: scratch for the two partial results, 2 * B*Cout*H*W floats
     int wdma;             // 1: stage weight chunks by LDS-DMA (default), 0: through registers
-    int wcs;              // persistent Winograd kernel only: 1 = the consumer-side split form (fp32 V in LDS, the multiplying wave splits; bit-identical)
     int pgrid;            // persistent Winograd kernel (conv_wino3p.cpp) only: > 0 = number of workgroups (context option "persist_grid": tests
                           // drive long item ranges and sample changes with a few workgroups); 0 = one per CU
     unsigned long long* dbg;   // optional: per-block phase cycle counters [n_blocks][8] (diagnostics), else null

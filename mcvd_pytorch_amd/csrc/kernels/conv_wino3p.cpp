@@ -58,12 +58,7 @@ __device__ __forceinline__ void wp_split3(f32x2 v, unsigned& w1, unsigned& w2, u
 }
 
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU
-// CS ("consumer-side split"): the transform parks V as fp32 pairs (one ds_write_b64 per position and channel pair) and the wave that
-//     multiplies a position splits its B operand into the three bf16 pieces itself, behind the MFMAs of the position before (one or two
-//     VALU instructions behind an MFMA of the same wave are free: profiles/r03_ubench_mfma_valu.txt); the same pieces, the same
-//     products in the same order -> bit-identical results.  The staging phase loses 48 of its VALU instructions per thread and chunk
-//     (5-9 % of the chunk when they are simply dropped: profiles/r04_wino3p_vs_wino3_layers.txt).
-template <int COT, int PRO, bool CS>
+template <int COT, int PRO>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv_wino3p_kernel(ConvArgs a) {
     // amdgpu_num_vgpr(86): the compiler may allocate v0-v171 (LLVM doubles the number on gfx90a+; conv_wino3.cpp); v172-v255 hold the
     // in-flight loads and the MFMA A operands and are named in the asm text only.
@@ -104,13 +99,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
     if (it0 >= it1) return;
     const int rg = __builtin_amdgcn_readfirstlane(wave >> 2);   // rows 2rg, 2rg+1 of B^T d; phase order of the wave
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // diagnostics build only (env MCVD_W3P_EXP, WRONG RESULTS, timing only): bit 0 the transform stores one bf16 piece three times instead of
-    // splitting (what the split costs the staging phase), bit 1 and one store instead of three (what an fp32 V with 8-byte stores would save)
-#ifdef MCVD_DIAG
-    const bool WP_EXP_NOSPLIT = (a.pgrid & (1 << 20)) != 0, WP_EXP_ONESTORE = (a.pgrid & (1 << 21)) != 0;
-#else
-    constexpr bool WP_EXP_NOSPLIT = false, WP_EXP_ONESTORE = false;
-#endif
 #ifdef MCVD_DIAG
     // diagnostics build only (env MCVD_W3P_STAGGER = cycles / 256): the odd workgroups start late.  All workgroups of this kernel run in
     // lock step (same work, same start); the experiment measures what the simultaneous epilogues / weight requests of 256 CUs cost.
@@ -254,18 +242,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
             const f32x2 v0 = m0 - m2, v1 = m1 + m2, v2 = m2 - m1, v3 = m1 - m3;                                 \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
                 unsigned w1, w2, w3;                                                                            \
-                const f32x2 vq = q == 0 ? v0 : q == 1 ? v1 : q == 2 ? v2 : v3;                                  \
-                if constexpr (CS) {       /* fp32 pair (channels s_ca, s_ca + 2 = K slots 2j, 2j + 1 of half h): [position][half][j][tile] */ \
-                    reinterpret_cast<f32x2*>(vdst - v_wr)[v_wr + (row * 4 + q) * 256] = vq;                     \
-                } else {                                                                                        \
-                    if (WP_EXP_NOSPLIT) { w1 = wp_cvt_pk(vq.x, vq.y); w2 = w3 = w1; }      /* diagnostics, timing only */ \
-                    else wp_split3(vq, w1, w2, w3);                                                             \
-                    vdst[(row * 4 + q) * 256] = w1;                                                             \
-                    if (!WP_EXP_ONESTORE) {                                                                     \
-                        vdst[(row * 4 + q) * 256 + PW] = w2;                                                    \
-                        vdst[(row * 4 + q) * 256 + 2 * PW] = w3;                                                \
-                    }                                                                                           \
-                }                                                                                               \
+                wp_split3(q == 0 ? v0 : q == 1 ? v1 : q == 2 ? v2 : v3, w1, w2, w3);                            \
+                vdst[(row * 4 + q) * 256] = w1;                                                                 \
+                vdst[(row * 4 + q) * 256 + PW] = w2;                                                            \
+                vdst[(row * 4 + q) * 256 + 2 * PW] = w3;                                                        \
             }                                                                                                   \
         }                                                                                                       \
     }
@@ -280,51 +260,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
     { _Pragma("unroll") for (int ct = 0; ct < COT; ++ct) { WP_QUADS(WP_MF1, 3 * ((i) * COT + ct) + (PA), acc[i][ct], bq[i][PB]) } }
     /* all MFMAs of the chunk whose V sits in buffer `par` (weights in the named registers); behind each piece's last product the
        same registers are re-requested from WNX, the (wave's) weights of the NEXT chunk of the stream (conv_wino3.cpp: W3_MFMA_PHASE) */
-    /* CS: the fp32 pairs of position 2w + i -> VB[j]: f32x2 index ((pos*2 + half)*4 + j)*T + l31 */               \
-#define WP_LOAD_BF(i, VB)                                                                                       \
-    {                                                                                                           \
-        const f32x2* q = reinterpret_cast<const f32x2*>(sVc) + (((2 * wave + (i)) * 2 + half) * 4) * T + l31;   \
-        _Pragma("unroll") for (int jp = 0; jp < 4; ++jp) VB[jp] = q[jp * T];                                    \
-    }
-#define WP_SPLIT_B(VB, BQ, jp)                                                                                  \
-    {                                                                                                           \
-        unsigned w1, w2, w3;                                                                                    \
-        wp_split3(VB[jp], w1, w2, w3);                                                                          \
-        BQ[0][jp] = w1; BQ[1][jp] = w2; BQ[2][jp] = w3;                                                         \
-    }
-    /* the consumer-side form: position 0's operand is split in front of its MFMAs, position 1's behind the first four products of
-       position 0, one channel pair (9 VALU) per product (3 MFMAs); sched_barrier keeps the groups where they are written */ \
-#define WP_MFMA_PHASE_CS(par, WNX)                                                                              \
-    {                                                                                                           \
-        const unsigned* sVc = sV + ((par) ? VW : 0);                                                            \
-        f32x2 vb0[4], vb1[4];                                                                                   \
-        u32x4 bq[2][3];                                                                                         \
-        WP_LOAD_BF(0, vb0) WP_LOAD_BF(1, vb1)                                                                   \
-        WP_SPLIT_B(vb0, bq[0], 0) WP_SPLIT_B(vb0, bq[0], 1) WP_SPLIT_B(vb0, bq[0], 2) WP_SPLIT_B(vb0, bq[0], 3) \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        WP_WAIT(VM_A)                                                                                           \
-        WP_PRODUCT(0, 2, 0)                                                                                     \
-        WP_LOAD_A_PIECE(WNX, 0, 2)                                                                              \
-        __builtin_amdgcn_sched_barrier(0); WP_SPLIT_B(vb1, bq[1], 0) __builtin_amdgcn_sched_barrier(0);         \
-        WP_PRODUCT(0, 1, 1)                                                                                     \
-        __builtin_amdgcn_sched_barrier(0); WP_SPLIT_B(vb1, bq[1], 1) __builtin_amdgcn_sched_barrier(0);         \
-        WP_PRODUCT(0, 0, 2)                                                                                     \
-        __builtin_amdgcn_sched_barrier(0); WP_SPLIT_B(vb1, bq[1], 2) __builtin_amdgcn_sched_barrier(0);         \
-        WP_PRODUCT(0, 1, 0)                                                                                     \
-        WP_LOAD_A_PIECE(WNX, 0, 1)                                                                              \
-        __builtin_amdgcn_sched_barrier(0); WP_SPLIT_B(vb1, bq[1], 3) __builtin_amdgcn_sched_barrier(0);         \
-        WP_PRODUCT(0, 0, 1) WP_PRODUCT(0, 0, 0)                                                                 \
-        WP_LOAD_A_PIECE(WNX, 0, 0)                                                                              \
-        WP_WAIT(VM_A)                                                                                           \
-        WP_PRODUCT(1, 2, 0)                                                                                     \
-        WP_LOAD_A_PIECE(WNX, 1, 2)                                                                              \
-        WP_PRODUCT(1, 1, 1) WP_PRODUCT(1, 0, 2) WP_PRODUCT(1, 1, 0)                                             \
-        WP_LOAD_A_PIECE(WNX, 1, 1)                                                                              \
-        WP_PRODUCT(1, 0, 1) WP_PRODUCT(1, 0, 0)                                                                 \
-        WP_LOAD_A_PIECE(WNX, 1, 0)                                                                              \
-    }
 #define WP_MFMA_PHASE(par, WNX)                                                                                 \
-    if constexpr (CS) WP_MFMA_PHASE_CS(par, WNX) else                                                           \
     {                                                                                                           \
         const unsigned* sVc = sV + ((par) ? VW : 0);                                                            \
         u32x4 bq[2][3];                                                                                         \
@@ -659,9 +595,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
 #undef WP_LOAD_B
 #undef WP_PRODUCT
 #undef WP_MFMA_PHASE
-#undef WP_MFMA_PHASE_CS
-#undef WP_LOAD_BF
-#undef WP_SPLIT_B
 #undef WP_VALU_PHASE
 }
 
@@ -681,18 +614,18 @@ static int wino3p_num_cus() {
     return n;
 }
 
-template <int COT, int PRO, bool CS>
-static int wino3p_launch3(const ConvArgs& a, hipStream_t s) {
+template <int COT, int PRO>
+static int wino3p_launch2(const ConvArgs& a, hipStream_t s) {
     constexpr int BCO = 32 * COT;
     static PerDeviceOnce raised;
     if (raised.first_use()) {
-        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3p_kernel<COT, PRO, CS>),
+        MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3p_kernel<COT, PRO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised.done();
     }
     const int ksp = a.ksplit == 2 ? 2 : 1;
     const long n_items = (long)a.B * (a.H / 8) * (a.W / 16) * (a.CoutP / BCO) * ksp;
-    const int cus = (a.pgrid & 0xfffff) > 0 ? (a.pgrid & 0xfffff) : wino3p_num_cus();
+    const int cus = a.pgrid > 0 ? a.pgrid : wino3p_num_cus();
     dim3 grid((unsigned)(n_items < cus ? n_items : cus));
     ConvArgs k = a;
     if (k.dbg) k.wdma = 0;                 // wave 0 records its phase times
@@ -703,20 +636,14 @@ static int wino3p_launch3(const ConvArgs& a, hipStream_t s) {
     }
     k.wdma &= 0xff;
     if (const char* st = getenv("MCVD_W3P_STAGGER")) k.wdma |= atoi(st) << 8;
-    if (const char* ex = getenv("MCVD_W3P_EXP")) k.pgrid |= atoi(ex) << 20;
 #else
     k.wdma &= 0xff;
 #endif
-    hipLaunchKernelGGL((conv_wino3p_kernel<COT, PRO, CS>), grid, dim3(WP_NT), wino3p_lds_bytes(a.Cin), s, k);
+    hipLaunchKernelGGL((conv_wino3p_kernel<COT, PRO>), grid, dim3(WP_NT), wino3p_lds_bytes(a.Cin), s, k);
     MCVD_HIP_CHECK(hipGetLastError());
     if (ksp == 2) return launch_wino_ksplit_reduce(a, s);
     if (a.stats) set_last_conv_stats_np((a.H / 8) * (a.W / 16));
     return 0;
-}
-
-template <int COT, int PRO>
-static int wino3p_launch2(const ConvArgs& a, hipStream_t s) {
-    return a.wcs ? wino3p_launch3<COT, PRO, true>(a, s) : wino3p_launch3<COT, PRO, false>(a, s);
 }
 
 template <int COT>

@@ -713,7 +713,6 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.shape_hint = (op.ks == 1 && ctx->conv_shape1 >= 0) ? ctx->conv_shape1 : ctx->conv_shape;
             a.wdma = ctx->conv_wdma;
             a.pgrid = ctx->persist_grid;
-            a.wcs = ctx->wino_cs;
             a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
             const size_t oi = (size_t)(&op - ops.data());
             if (a.shape_hint == 14 || a.shape_hint == 15) {      // forced split-operand 1x1 GEMM (tests): a cout tile that kernel serves
@@ -912,7 +911,6 @@ int mcvd_model::autotune(int B) {
             a.B = B; a.Cin = cin; a.CinP = op.CinP; a.Cout = op.Cout; a.CoutP = op.CoutP; a.H = op.H; a.W = op.W; a.ks = op.ks;
             a.wdma = ctx->conv_wdma;
             a.pgrid = ctx->persist_grid;
-            a.wcs = ctx->wino_cs;
             a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
             const bool spade_fused = op.gb.kind != REF_NONE && ctx->spade_fuse && ctx->winograd;
             if (spade_fused) {

@@ -21,7 +21,6 @@ struct mcvd_ctx {
     int conv_shape1 = -1;          // >= 0: the shape forced for the 1x1 convs only (they follow conv_shape otherwise): lets a test put
                                    //    every 3x3 conv AND every 1x1 conv of a model on chosen kernels at once
     int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
-    int wino_cs = 0;               // persistent Winograd kernel: the consumer-side split form (ConvArgs::wcs)
     int persist_grid = 0;          // > 0: workgroups of the persistent Winograd kernel (tests); 0 = one per CU
     int wino_selftest = 0;         // 0 not run yet, 1 passed, -1 FAILED: the hand-scheduled bf16 Winograd kernels disagree with the fp32-MFMA Winograd
                                    //    kernel on this device / driver (mcvd_ctx_selftest); bf16x3 was switched off for this context

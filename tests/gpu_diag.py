@@ -192,7 +192,6 @@ def phases(f):
                 " ".join(f"{n} {100 * m[i] / m[7]:.1f}%" for i, n in enumerate(names[:7])) + "\n")
         f.flush()
     ctx.opt("conv_shape", -1)
-    ctx.opt("wino_cs", 0)
 
 
 def wphases(f):
@@ -604,10 +603,8 @@ def w3ptl(f):
         res = torch.randn(B, cout, H, H, device="cuda")
         line = f"cin{cin:4d} cout{cout:4d} H{H:3d}:"
         ref = None
-        for shp in (10, 16, 16 + 100, 11, 17, 17 + 100):          # + 100: the consumer-side split form of the persistent kernel (option wino_cs)
-            ctx.opt("wino_cs", 1 if shp >= 100 else 0)
+        for shp in (10, 16, 11, 17):
             tag = shp
-            shp = shp % 100
             ctx.opt("conv_shape", shp)
             for _ in range(3):
                 y = ctx.conv2d(x, w, b, coef=coef, act=1, res=res, scale=0.7)

@@ -58,8 +58,7 @@ def _inputs(case, seed=11):
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "B{}_c{}+{}_o{}_H{}_pro{}_ks{}".format(c[0], c[1], c[2], c[3], c[4], int(c[5]) + c[6], c[8]))
 @pytest.mark.parametrize("grid", [0, 1, 7, 40], ids=["per_cu", "g1", "g7", "g40"])
-@pytest.mark.parametrize("cs", [0, 1], ids=["split_in_transform", "split_by_consumer"])
-def test_persistent_kernel_is_bit_identical(ctx, case, grid, cs):
+def test_persistent_kernel_is_bit_identical(ctx, case, grid):
     from mcvd_pytorch_amd import _lib
     B, C0, C1, Cout, H, use_coef, act, use_res, ks2, expect = case
     x0, x1, w, bias, coef, res = _inputs(case)
@@ -72,13 +71,11 @@ def test_persistent_kernel_is_bit_identical(ctx, case, grid, cs):
         base_ran = _lib.lib.mcvd_last_conv_kernel()
         ctx.opt("conv_shape", 17 if ks2 else 16)
         ctx.opt("persist_grid", grid)
-        ctx.opt("wino_cs", cs)          # 1: fp32 V in LDS, the multiplying wave splits its B operand (same pieces, same products: bit-identical)
         got, got_st, got_np = ctx.conv2d_stats(dev(x0), dev(w), dev(bias), **kw)
         ran = _lib.lib.mcvd_last_conv_kernel()
     finally:
         ctx.opt("conv_shape", -1)
         ctx.opt("persist_grid", 0)
-        ctx.opt("wino_cs", 0)
     assert ran == expect, f"{case}: kernel family {ran} ran, expected {expect}"
     assert base_ran == (11 if expect == 17 else 10)
     assert torch.equal(got, want), f"{case} grid {grid}: {int((got != want).sum())} of {got.numel()} values differ from conv_wino3_kernel, max {float((got - want).abs().max()):.3e}"

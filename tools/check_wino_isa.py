@@ -287,8 +287,8 @@ def check3(asm_text, kernel="17conv_wino3_kernel", asm_mfma=True, expect=18, wl_
 def check3p(asm_text):
     """conv_wino3p_kernel<COT, PRO> (persistent workgroups): the K loops are the two innermost loops (one per phase order) of the
     run / item loop nest; same VMEM population per chunk as conv_wino3_kernel."""
-    return check3(asm_text, kernel="18conv_wino3p_kernel", asm_mfma=True, expect=18, wl_per_cot=6, nloops=2, npatch=(3, 3), wreg0=184, named0=172,
-                  targs=r"ILi(\d)ELi(\d)ELb([01])EEE", nested=True)          # x {split by the transform, split by the consumer}
+    return check3(asm_text, kernel="18conv_wino3p_kernel", asm_mfma=True, expect=9, wl_per_cot=6, nloops=2, npatch=(3, 3), wreg0=184, named0=172,
+                  targs=r"ILi(\d)ELi(\d)E()EE", nested=True)
 
 
 def check2h(asm_text):
