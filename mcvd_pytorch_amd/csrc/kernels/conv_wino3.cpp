@@ -539,7 +539,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
     }
     // The MFMAs are inline asm: the compiler does not know that the accumulators were written by the matrix pipe and inserts none of
     // the wait states a read of an MFMA result needs (8-pass MFMA -> VALU / LDS read: 11).  Nothing in the K loop reads them.
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    // The nops are tied to the accumulators ("+v"): a free-standing asm could be scheduled away from the values it protects.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (COT == 3)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]) :: "memory");
+    else if constexpr (COT == 2)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
+    else
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[1][0]) :: "memory");
 
     // ---------------- inverse transform + epilogue, one 32-cout sub-tile at a time ----------------
     float* sM = smem;                      // [16 positions][32 couts][32 tiles] = 64 KiB
