@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 closing run: full GPU suite, smoke, the default bench line, every other BASELINE config under its committed table
+# closing run of a round: full GPU suite, smoke, the default bench line, every other BASELINE config under its committed table
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1; tail -1 gpurun_out/build.log
