@@ -169,7 +169,7 @@ def roofline_of_leg(net, args, B, arith_name):
                  for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     # ---- dominant kernel: the 3x3 convs, by the kernel family each layer REALLY ran
     FAM3 = {4: "wino_f32", 8: "wino_f32", 10: "wino_bf16x3", 11: "wino_bf16x3", 12: "wino_f16x2", 13: "wino_f16x2",
-            16: "wino_bf16x3", 17: "wino_bf16x3"}          # 16 / 17: the same kernel as persistent workgroups (conv_wino3p.cpp)
+            16: "wino_bf16x3", 17: "wino_bf16x3", 18: "wino_bf16x3", 19: "wino_bf16x3", 20: "wino_bf16x3"}          # 16 / 17: the same kernel as persistent workgroups (conv_wino3p.cpp)
     fam = {k: dict(launches=0, ms=0.0, flops=0.0, bytes=0.0) for k in ("wino_f32", "wino_bf16x3", "wino_f16x2", "direct")}
     k1 = {}
     for i in range(n):

@@ -107,7 +107,10 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         chunk / 64 pixels per wave), 10 / 11 three-piece bf16 Winograd (11: K split), 12 / 13 two-piece fp16 Winograd (13: K split),
  *         14 / 15 the split-operand 1x1 GEMM with two fp16 / three bf16 pieces, 16 / 17 the three-piece bf16 Winograd kernel as PERSISTENT
  *         workgroups (one per CU walks a range of (region, cout tile[, K half]) items, the staging pipeline runs on across items; results
- *         bit-identical to 10 / 11; 17: K split).  A family that does not serve a launch falls back.  "persist_grid" (0 = one workgroup
+ *         bit-identical to 10 / 11; 17: K split), 18 / 19 the three-piece bf16 Winograd kernel with the input channels in 4 / 8 parts and
+ *         20 the persistent kernel with 4 parts (small batches: 8x8 / 16x16 layers with fewer (region, cout tile) pairs than CUs; the
+ *         parts are summed in index order by the reduce pass -- deterministic; a layer without the chunks for the depth takes the next
+ *         shallower split).  A family that does not serve a launch falls back.  "persist_grid" (0 = one workgroup
  *         per CU): number of workgroups of the persistent kernel (tests: long item ranges on small tensors).
  *     "conv_shape1" (-1): the same for the 1x1 convs only (they follow "conv_shape" otherwise), so that a test can put every 3x3 AND
  *         every 1x1 conv of a model on chosen kernels at once.  "conv_cot": cout tile (32-channel units) mcvd_op_conv2d requests with

@@ -569,7 +569,7 @@ int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* co
     MCVD_REQUIRE(n == (int)m->ops.size(), "set_tuning: %d entries for a plan of %d ops (tuning of another model?)", n, (int)m->ops.size());
     for (int i = 0; i < n; ++i) {
         const bool conv = m->ops[i].kind == OP_CONV;
-        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 17 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
+        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 20 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
                      "set_tuning: entry %d (shape %d, cout tile %d) does not fit op kind %d", i, shapes[i], cots[i], (int)m->ops[i].kind);
     }
     if (m->ctx) m->sync_tuning_options();         // the table belongs to the options in force now; a later option change drops it
@@ -929,15 +929,17 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     a.CoutP = round_up(Cout, 32 * a.cot);
     const size_t wfloats = (size_t)a.CinP * ks * ks * a.CoutP;
     const bool wino = (ctx->conv_shape == 4 || ctx->conv_shape == 8 || (ctx->conv_shape >= 10 && ctx->conv_shape <= 13) ||
-                       ctx->conv_shape == 16 || ctx->conv_shape == 17) && conv_wino_supported(ks, H, W);
+                       (ctx->conv_shape >= 16 && ctx->conv_shape <= 20)) && conv_wino_supported(ks, H, W);
     const bool wino_h = wino && (ctx->conv_shape == 12 || ctx->conv_shape == 13);     // fp16 pieces as well
-    const bool wino_b = wino && (ctx->conv_shape == 10 || ctx->conv_shape == 11 || ctx->conv_shape == 16 || ctx->conv_shape == 17);     // bf16 pieces as well
+    const bool wino_b = wino && (ctx->conv_shape == 10 || ctx->conv_shape == 11 || (ctx->conv_shape >= 16 && ctx->conv_shape <= 20));     // bf16 pieces as well
     const int np1 = (ks == 1 && ctx->conv_shape == 14) ? 2 : (ks == 1 && ctx->conv_shape == 15) ? 3 : 0;      // 1x1 pieces
     const size_t ufloats = wino ? (size_t)a.CinP * 16 * a.CoutP : 0;
     const size_t hfloats = wino_h ? (size_t)((conv_wino2h_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4)
                            : wino_b ? (size_t)((conv_wino3_weight_floats(a.CinP, a.CoutP) + 3) / 4 * 4)
                            : np1 ? (size_t)((conv1x1_h2_weight_floats(a.CinP, a.CoutP, np1) + 3) / 4 * 4) : 0;
-    const size_t pfloats = (wino && (ctx->conv_shape == 8 || ctx->conv_shape == 11 || ctx->conv_shape == 13 || ctx->conv_shape == 17)) ? (size_t)2 * B * Cout * H * W : 0;     // K-split partial results
+    const int kparts = (ctx->conv_shape == 8 || ctx->conv_shape == 11 || ctx->conv_shape == 13 || ctx->conv_shape == 17) ? 2
+                       : (ctx->conv_shape == 18 || ctx->conv_shape == 20) ? 4 : ctx->conv_shape == 19 ? 8 : 0;
+    const size_t pfloats = wino ? (size_t)kparts * B * Cout * H * W : 0;     // K-split partial results
     if (int rc = ctx->ensure_scratch((wfloats + a.CoutP + ufloats + hfloats + pfloats) * sizeof(float))) return rc;
     MCVD_HIP_CHECK(hipMemsetAsync(ctx->scratch, 0, (wfloats + a.CoutP + ufloats + hfloats) * sizeof(float), ctx->stream));
     if (wino) {

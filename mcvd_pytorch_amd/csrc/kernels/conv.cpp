@@ -62,22 +62,44 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
         b.ksplit = 0;
         if (conv_wino2h_usable(b)) { g_last_conv_kernel = 12; return launch_conv_wino2h(b, s); }
     }
-    if (a.shape_hint == 17) {                                       // persistent bf16x3 Winograd, the two K halves are items
+    // bf16x3 Winograd ids: 10 plain, 11 / 18 / 19 = K split in 2 / 4 / 8 parts (small-batch 8x8 / 16x16 layers: more workgroups than
+    // (region, cout tile) pairs), 16 / 17 / 20 = persistent workgroups with 1 / 2 / 4 K parts.  A deeper split that a layer cannot take
+    // (too few channel chunks) degrades to the next shallower one.
+    int h = a.shape_hint;
+    if (h == 20) {
+        ConvArgs b = a;
+        b.ksplit = 4;
+        if (conv_wino3p_usable(b)) { g_last_conv_kernel = 20; return launch_conv_wino3p(b, s); }
+        h = 17;
+    }
+    if (h == 19) {
+        ConvArgs b = a;
+        b.ksplit = 8;
+        if (conv_wino3_usable(b)) { g_last_conv_kernel = 19; return launch_conv_wino3(b, s); }
+        h = 18;
+    }
+    if (h == 18) {
+        ConvArgs b = a;
+        b.ksplit = 4;
+        if (conv_wino3_usable(b)) { g_last_conv_kernel = 18; return launch_conv_wino3(b, s); }
+        h = 11;
+    }
+    if (h == 17) {                                                  // persistent bf16x3 Winograd, the two K halves are items
         ConvArgs b = a;
         b.ksplit = 2;
         if (conv_wino3p_usable(b)) { g_last_conv_kernel = 17; return launch_conv_wino3p(b, s); }
     }
-    if (a.shape_hint == 16 || a.shape_hint == 17) {                 // persistent bf16x3 Winograd (one workgroup per CU walks an item range)
+    if (h == 16 || h == 17) {                                       // persistent bf16x3 Winograd (one workgroup per CU walks an item range)
         ConvArgs b = a;
         b.ksplit = 0;
         if (conv_wino3p_usable(b)) { g_last_conv_kernel = 16; return launch_conv_wino3p(b, s); }
     }
-    if (a.shape_hint == 11 || a.shape_hint == 17) {                 // bf16x3 Winograd with a 2-way K split
+    if (h == 11 || h == 17) {                                       // bf16x3 Winograd with a 2-way K split
         ConvArgs b = a;
         b.ksplit = 2;
         if (conv_wino3_usable(b)) { g_last_conv_kernel = 11; return launch_conv_wino3(b, s); }
     }
-    if (a.shape_hint == 10 || a.shape_hint == 11 || a.shape_hint == 16 || a.shape_hint == 17) {     // Winograd on the bf16 matrix pipe, operands split three ways
+    if (h == 10 || h == 11 || h == 16 || h == 17) {                 // Winograd on the bf16 matrix pipe, operands split three ways
         ConvArgs b = a;
         b.ksplit = 0;
         if (conv_wino3_usable(b)) { g_last_conv_kernel = 10; return launch_conv_wino3(b, s); }
@@ -87,7 +109,7 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
         b.ksplit = 2;
         if (conv_wino_usable(b)) { g_last_conv_kernel = 8; return launch_conv_wino(b, s); }
     }
-    if ((a.shape_hint == 4 || a.shape_hint == 8 || (a.shape_hint >= 10 && a.shape_hint <= 13) || a.shape_hint == 16 || a.shape_hint == 17) && conv_wino_usable(a)) { g_last_conv_kernel = 4; return launch_conv_wino(a, s); }   // Winograd F(2x2,3x3)
+    if ((a.shape_hint == 4 || a.shape_hint == 8 || (a.shape_hint >= 10 && a.shape_hint <= 13) || (a.shape_hint >= 16 && a.shape_hint <= 20)) && conv_wino_usable(a)) { g_last_conv_kernel = 4; return launch_conv_wino(a, s); }   // Winograd F(2x2,3x3)
     if (a.shape_hint == 15 && conv1x1_h2_supported(a, a.cot, 3)) { g_last_conv_kernel = 15; return launch_conv1x1_h2(a, a.cot, s, 3); }   // 1x1 GEMM, bf16 pipe, three exact pieces
     if (a.shape_hint == 14 && conv1x1_h2_supported(a, a.cot, 2)) { g_last_conv_kernel = 14; return launch_conv1x1_h2(a, a.cot, s, 2); }   // 1x1 GEMM, fp16 pipe, two-piece operands
     if (a.shape_hint == 5 && conv1x1_dma_supported(a, 16)) { g_last_conv_kernel = 5; return launch_conv1x1_dma(a, a.cot, 16, s); }   // all-DMA 1x1 GEMM

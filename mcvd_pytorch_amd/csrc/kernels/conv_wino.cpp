@@ -565,12 +565,12 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(ConvArgs a) {
 
 // y = s * (p0 + p1 + bias[c] + res): the second pass of the 2-way K split, 4 pixels per thread
 __global__ __launch_bounds__(256) void wino_ksplit_reduce_kernel(const float* part, const float* bias, const float* res, float scale,
-                                                                 float* y, long n4, long half_stride, int Cout, int HW4) {
+                                                                 float* y, long n4, long half_stride, int Cout, int HW4, int ksp) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const f32x4 p0 = reinterpret_cast<const f32x4*>(part)[i];
-        const f32x4 p1 = reinterpret_cast<const f32x4*>(part + half_stride)[i];
+        f32x4 acc = reinterpret_cast<const f32x4*>(part)[i];
+        for (int k = 1; k < ksp; ++k) acc = acc + reinterpret_cast<const f32x4*>(part + k * half_stride)[i];      // p0 + p1 + ... in this fixed order
         const float bv = bias[(i / HW4) % Cout];
-        f32x4 v = p0 + p1 + bv;
+        f32x4 v = acc + bv;
         if (res) v = v + reinterpret_cast<const f32x4*>(res)[i];
         reinterpret_cast<f32x4*>(y)[i] = v * scale;
     }
@@ -580,15 +580,15 @@ __global__ __launch_bounds__(256) void wino_ksplit_reduce_kernel(const float* pa
 // float4 of the flat index = PL lanes of one wave (HW4 = 16 or 64), one partial per plane over its HW pixels.
 template <int PL>
 __global__ __launch_bounds__(256) void wino_ksplit_reduce_stats_kernel(const float* part, const float* bias, const float* res, float scale,
-                                                                       float* y, long n4, long half_stride, int Cout, float* stats) {
+                                                                       float* y, long n4, long half_stride, int Cout, float* stats, int ksp) {
     const long i = blockIdx.x * 256L + threadIdx.x;
     const bool in = i < n4;
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
     if (in) {
-        const f32x4 p0 = reinterpret_cast<const f32x4*>(part)[i];
-        const f32x4 p1 = reinterpret_cast<const f32x4*>(part + half_stride)[i];
+        f32x4 acc = reinterpret_cast<const f32x4*>(part)[i];
+        for (int k = 1; k < ksp; ++k) acc = acc + reinterpret_cast<const f32x4*>(part + k * half_stride)[i];      // p0 + p1 + ... in this fixed order
         const float bv = bias[(i / PL) % Cout];
-        v = p0 + p1 + bv;
+        v = acc + bv;
         if (res) v = v + reinterpret_cast<const f32x4*>(res)[i];
         v = v * scale;
         reinterpret_cast<f32x4*>(y)[i] = v;
@@ -653,24 +653,27 @@ static int wino_launch_exp(int e, const ConvArgs& k, dim3 grid, size_t lds, hipS
 }
 #endif
 
-// Second pass of the 2-way K split (conv_wino.cpp and conv_wino3.cpp): y = s * (p0 + p1 + bias + res), with the GroupNorm partials of
-// the final values where the plane size allows (one partial per (sample, channel) plane).
+// Second pass of the K split (a.ksplit = 2 parts in conv_wino.cpp / conv_wino2h.cpp; 2, 4 or 8 in conv_wino3.cpp / conv_wino3p.cpp):
+// y = s * (p0 + p1 + ... + bias + res) in that fixed order, with the GroupNorm partials of the final values where the plane size
+// allows (one partial per (sample, channel) plane).
 int launch_wino_ksplit_reduce(const ConvArgs& a, hipStream_t s) {
+    const int ksp = a.ksplit >= 2 ? a.ksplit : 2;
     const long n = (long)a.B * a.Cout * a.H * a.W, n4 = n / 4;
     const int hw4 = a.H * a.W / 4;
     if (a.stats && (hw4 == 16 || hw4 == 64)) {     // ... with the GroupNorm partials of the final values (one per plane)
         const int blocks = (int)((n4 + 255) / 256);
         if (hw4 == 16)
             hipLaunchKernelGGL(wino_ksplit_reduce_stats_kernel<16>, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale,
-                               a.y, n4, n, a.Cout, a.stats);
+                               a.y, n4, n, a.Cout, a.stats, ksp);
         else
             hipLaunchKernelGGL(wino_ksplit_reduce_stats_kernel<64>, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale,
-                               a.y, n4, n, a.Cout, a.stats);
+                               a.y, n4, n, a.Cout, a.stats, ksp);
         set_last_conv_stats_np(1);
     } else {
         const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
         hipLaunchKernelGGL(wino_ksplit_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale, a.y, n4, n,
-                           a.Cout, hw4);
+                           a.Cout, hw4, ksp);
+        if (a.stats) set_last_conv_stats_np(0);     // no partials for planes above 16x16: the consumer reduces the tensor itself
     }
     MCVD_HIP_CHECK(hipGetLastError());
     return 0;

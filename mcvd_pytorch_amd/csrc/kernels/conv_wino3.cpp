@@ -71,7 +71,8 @@ __device__ __forceinline__ void w3_split3(f32x2 v, unsigned& w1, unsigned& w2, u
 }
 
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU (the GroupNorm / temb prologue of conv_wino.cpp)
-// a.ksplit == 2 (grid.y = 2): half of the input channels per workgroup, raw partial result to a.part[half] (conv_wino.cpp).
+// a.ksplit == 2 / 4 / 8 (grid.y = that many): one part of the input channels per workgroup, raw partial result to a.part[part]; the reduce
+//     pass (conv_wino.cpp) sums the parts in index order.
 // EXP != 0 (built with -DMCVD_DIAG only): timing-only ablations of the K loop (wrong results; env MCVD_WINO3_EXP, tests/gpu_diag.py
 //     w3exp): bit 0 no tile transform, bit 1 no patch activation/park, bit 2 no VMEM in the loop, bit 3 no B-operand reads, bit 4 no MFMA.
 // G8: 8x8 images -- the 32 tiles of a workgroup are TWO whole images (16 tiles each, image i at patch columns 10 i .. 10 i + 9); every
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
 
     // ---- chunk range of this workgroup (a.ksplit == 2: blockIdx.y picks one half of the input channels)
     const int nch_all = a.CinP / CK;
-    const int ksp = a.ksplit == 2 ? 2 : 1, kh = ksp == 2 ? (int)blockIdx.y : 0;
+    const int ksp = a.ksplit >= 2 ? a.ksplit : 1, kh = ksp >= 2 ? (int)blockIdx.y : 0;          // 2, 4 or 8 parts of the input channels
     const int c_begin = kh * (nch_all / ksp), c_end = c_begin + nch_all / ksp;
 
     // ---- prologue.  Issue order = need order: the coefficients of the sample (into the registers of the third patch), the raw patches of
@@ -720,7 +721,7 @@ static int wino3_launch2(const ConvArgs& a, hipStream_t s) {
     constexpr int BCO = 32 * COT;
     const size_t lds = wino3_lds_bytes(a.Cin, G8);
     const int nreg = G8 ? (a.B + 1) / 2 : a.B * (a.H / 8) * (a.W / 16);
-    const int ksp = a.ksplit == 2 ? 2 : 1;
+    const int ksp = a.ksplit >= 2 ? a.ksplit : 1;
     dim3 grid(((nreg + 7) / 8) * 8 * (a.CoutP / BCO), ksp);
     ConvArgs k = a;
     int rc = 0;
@@ -753,7 +754,7 @@ static int wino3_launch2(const ConvArgs& a, hipStream_t s) {
     }
     if (rc) return rc;
     MCVD_HIP_CHECK(hipGetLastError());
-    if (ksp == 2) return launch_wino_ksplit_reduce(a, s);
+    if (ksp >= 2) return launch_wino_ksplit_reduce(a, s);
     if (a.stats) set_last_conv_stats_np(G8 ? 1 : (a.H / 8) * (a.W / 16));
     return 0;
 }
@@ -777,7 +778,8 @@ bool conv_wino3_usable(const ConvArgs& a) {
     return a.ks == 3 && ((a.H % 8 == 0 && a.W % 16 == 0 && a.H >= 8 && a.W >= 16) || g8) && a.wpb && !a.gb && a.Cin <= 1024 &&
            a.CinP % W3_CK == 0 && (a.C1 == 0 || a.C0 % W3_CK == 0) && a.H * a.W <= 16384 &&
            (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) && wino3_lds_bytes(a.Cin, g8) <= 160 * 1024 &&
-           (a.ksplit != 2 || ((a.CinP / W3_CK) % 2 == 0 && a.CinP / W3_CK >= 4 && a.part != nullptr));
+           (a.ksplit < 2 || ((a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && (a.CinP / W3_CK) % a.ksplit == 0 &&
+                             a.CinP / W3_CK >= 2 * a.ksplit && a.part != nullptr));        // every part at least two chunks
 }
 
 // a.wpb: the layout of launch_pack_wino3_weight, packed for conv_wino_cout_tile(Cout).

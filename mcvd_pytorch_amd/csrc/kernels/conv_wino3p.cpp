@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
     const int H = a.H, W = a.W, HW = H * W, Cin = a.Cin;
     const int rx_n = W >> 4, rpi = rx_n * (H >> 3);              // regions per image
     const int nct = a.CoutP / BCO;
-    const int ksp = a.ksplit == 2 ? 2 : 1;
+    const int ksp = a.ksplit >= 2 ? a.ksplit : 1;                // K parts per (region, cout tile): 1, 2, 4 or 8
     const int nch = (a.CinP / CK) / ksp;                         // chunks per item
     const int ips = rpi * nct * ksp;                             // items per sample
     const int n_items = a.B * ips;
@@ -623,7 +623,7 @@ static int wino3p_launch2(const ConvArgs& a, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised.done();
     }
-    const int ksp = a.ksplit == 2 ? 2 : 1;
+    const int ksp = a.ksplit >= 2 ? a.ksplit : 1;
     const long n_items = (long)a.B * (a.H / 8) * (a.W / 16) * (a.CoutP / BCO) * ksp;
     const int cus = a.pgrid > 0 ? a.pgrid : wino3p_num_cus();
     dim3 grid((unsigned)(n_items < cus ? n_items : cus));
@@ -641,7 +641,7 @@ static int wino3p_launch2(const ConvArgs& a, hipStream_t s) {
 #endif
     hipLaunchKernelGGL((conv_wino3p_kernel<COT, PRO>), grid, dim3(WP_NT), wino3p_lds_bytes(a.Cin), s, k);
     MCVD_HIP_CHECK(hipGetLastError());
-    if (ksp == 2) return launch_wino_ksplit_reduce(a, s);
+    if (ksp >= 2) return launch_wino_ksplit_reduce(a, s);
     if (a.stats) set_last_conv_stats_np((a.H / 8) * (a.W / 16));
     return 0;
 }
@@ -660,8 +660,10 @@ bool conv_wino3p_usable(const ConvArgs& a) {
     return a.ks == 3 && a.H % 8 == 0 && a.W % 16 == 0 && a.H >= 8 && a.W >= 16 && a.wpb && !a.gb && !a.gni.st0 && a.Cin <= 1024 &&
            a.CinP % WP_CK == 0 && (a.C1 == 0 || a.C0 % WP_CK == 0) && a.H * a.W <= 16384 &&
            (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) && wino3p_lds_bytes(a.Cin) <= 160 * 1024 &&
-           (long)a.B * (a.H / 8) * (a.W / 16) * (a.CoutP / 32) * 2 < (1L << 31) &&
-           (a.ksplit == 2 ? (nchunks % 2 == 0 && nchunks / 2 >= WP_MINCH && a.part != nullptr) : nchunks >= WP_MINCH);
+           (long)a.B * (a.H / 8) * (a.W / 16) * (a.CoutP / 32) * 8 < (1L << 31) &&
+           (a.ksplit >= 2 ? ((a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && nchunks % a.ksplit == 0 && nchunks / a.ksplit >= WP_MINCH &&
+                             a.part != nullptr)
+                          : nchunks >= WP_MINCH);
 }
 
 int launch_conv_wino3p(const ConvArgs& a, hipStream_t s) {

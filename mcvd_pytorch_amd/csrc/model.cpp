@@ -592,7 +592,7 @@ int mcvd_model::ensure_workspace(int B) {
     size_t kfl = 0;                               // K-split Winograd candidates: 3x3 layers at 8x8 / 16x16
     for (const Op& op : ops)
         if (op.kind == OP_CONV && op.ks == 3 && op.wpw >= 0 && op.H * op.W <= 256)
-            kfl = std::max(kfl, (size_t)2 * B * op.Cout * op.H * op.W);
+            kfl = std::max(kfl, (size_t)8 * B * op.Cout * op.H * op.W);         // up to 8 parts (shape id 19)
     if (kfl) MCVD_HIP_CHECK(hipMalloc((void**)&ksplit_buf, kfl * sizeof(float)));
     if (d.noise_in_cond && d.num_frames_cond > 0)
         MCVD_HIP_CHECK(hipMalloc((void**)&cond_z, (size_t)d.channels * d.num_frames_cond * d.image_size * d.image_size * B * sizeof(float)));
@@ -731,8 +731,8 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                     a.shape_hint = a.shape_hint == 12 ? 10 : a.shape_hint == 13 ? 11 : 15;
                     if (a.shape_hint == 15 && !conv1x1_h2_supported(a, a.cot, 3)) a.cot = op.cot;
                 }
-                if (!ctx->bf16x3 && (a.shape_hint == 10 || a.shape_hint == 11 || a.shape_hint == 15 || a.shape_hint == 16 || a.shape_hint == 17)) {
-                    a.shape_hint = (a.shape_hint == 10 || a.shape_hint == 16) ? 4 : (a.shape_hint == 11 || a.shape_hint == 17) ? 8 : 5;
+                if (!ctx->bf16x3 && (a.shape_hint == 10 || a.shape_hint == 11 || (a.shape_hint >= 15 && a.shape_hint <= 20))) {
+                    a.shape_hint = (a.shape_hint == 10 || a.shape_hint == 16) ? 4 : a.shape_hint == 15 ? 5 : 8;
                     a.cot = op.cot;
                 }
             }
@@ -970,6 +970,20 @@ int mcvd_model::autotune(int B) {
                 b.ksplit = 2;
                 if (conv_wino3p_usable(b))
                     if (int rc = time_candidate(17, op.cot)) return rc;
+                // 18 / 19 / 20 = 4 / 8 K parts (20: persistent, 4 parts), offered where the 2-way split leaves the chip with less than
+                // a few workgroups per CU (the measurement decides; above that the reduce pass only costs)
+                const bool g8 = op.H == 8 && op.W == 8;
+                const long pairs = (g8 ? (B + 1) / 2 : (long)B * (op.H / 8) * (op.W / 16)) * (op.CoutP / (32 * conv_wino_cout_tile(op.Cout)));
+                if (2 * pairs < 1024) {
+                    b.ksplit = 4;
+                    if (conv_wino3_usable(b))
+                        if (int rc = time_candidate(18, op.cot)) return rc;
+                    if (conv_wino3p_usable(b))
+                        if (int rc = time_candidate(20, op.cot)) return rc;
+                    b.ksplit = 8;
+                    if (4 * pairs < 1024 && conv_wino3_usable(b))
+                        if (int rc = time_candidate(19, op.cot)) return rc;
+                }
             }
             // f16x2 range guard: the two-piece fp16 kernels see GroupNorm-ed inputs only (a.coef set: normalised, O(1) by construction).
             // A conv over a RAW tensor (stem, shortcuts, NIN_3) has no bound on its input and stays on the fp32-range kernels.

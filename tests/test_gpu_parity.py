@@ -661,6 +661,8 @@ FORWARD_MODES = {
     "bf16x3ks": {"conv_shape": 11, "conv_shape1": 15, "naive_attn": 4},          # ... K-split Winograd where it applies
     "bf16x3p": {"conv_shape": 16, "conv_shape1": 15, "naive_attn": 4},           # ... persistent Winograd workgroups (conv_wino3p.cpp)
     "bf16x3pks": {"conv_shape": 17, "conv_shape1": 15, "naive_attn": 4},         # ... with the K halves as items where the split applies
+    "bf16x3ks8": {"conv_shape": 19, "conv_shape1": 15, "naive_attn": 4},         # ... 8 K parts where the layer has the chunks, else 4 / 2 / none
+    "bf16x3pks4": {"conv_shape": 20, "conv_shape1": 15, "naive_attn": 4},        # ... persistent with 4 K parts as items, else 2 / none
     "f16x2": {"conv_shape": 12, "conv_shape1": 14, "naive_attn": 3},             # two-piece fp16 everywhere (incl. raw-input convs: values are O(1) here)
     "f16x2ks": {"conv_shape": 13, "conv_shape1": 14, "naive_attn": 3},
 }
@@ -692,17 +694,20 @@ def _assert_mode_ran(net, mode):
         return
     ran = _conv_kernels(net)
     want3, want1 = opts["conv_shape"], opts["conv_shape1"]
-    base3 = want3 - (want3 & 1)                  # 10 / 12 / 16: the unsplit form
+    base3 = {18: 10, 19: 10, 20: 16}.get(want3, want3 - (want3 & 1))            # 10 / 12 / 16: the unsplit form
+    fam3 = {10: (10, 11, 18, 19), 16: (16, 17, 20)}.get(base3, (base3, base3 + 1)) if want3 >= 18 else (base3, base3 + 1)
     for ks, H, cin, cout, k in ran:
         if ks == 1 and cin % 32 == 0:
             assert k == want1, f"1x1 conv {cin}->{cout} @{H} ran kernel {k}, expected {want1}"
         if ks == 3 and cin % 16 == 0 and H % 8 == 0 and (H >= 16 or H == 8):
             if base3 == 16:                      # persistent workgroups: every layer with >= 4 chunks of 16 channels that is not 8x8; the rest on 10 / 11
-                ok = (16, 17) if (H >= 16 and cin >= 64) else (10, 11)
+                ok = fam3 if (H >= 16 and cin >= 64) else (10, 11)
             else:
-                ok = (base3, base3 + 1)
+                ok = fam3
             assert k in ok, f"3x3 conv {cin}->{cout} @{H} ran kernel {k}, expected one of {ok}"
-    assert any(ks == 1 and k == want1 for ks, _, _, _, k in ran) and any(ks == 3 and k in (base3, base3 + 1) for ks, _, _, _, k in ran)
+    if want3 >= 18:                              # the deep split itself ran somewhere (the configs of these tests have >= 256-channel 8x8 / 16x16 layers)
+        assert any(k == want3 for ks, _, _, _, k in ran if ks == 3) or not any(ks == 3 and cin >= 256 and H <= 16 for ks, H, cin, _, _ in ran), (mode, ran)
+    assert any(ks == 1 and k == want1 for ks, _, _, _, k in ran) and any(ks == 3 and k in fam3 for ks, _, _, _, k in ran)
 
 
 @pytest.mark.parametrize("fx", ["tiny_b3.pt", "tiny_spade_b2.pt", "smmnist_big5_b2.pt", "tiny_cosine_b2.pt",
@@ -854,7 +859,7 @@ def test_imported_table_yields_to_the_options():
     net.set_option("autotune", 1)
 
 
-@pytest.mark.parametrize("shape", [4, 10, 11, 12, 13, 10 + 256, 16, 17, 16 + 256])
+@pytest.mark.parametrize("shape", [4, 10, 11, 12, 13, 10 + 256, 16, 17, 16 + 256, 19, 20])
 def test_forward_is_bit_deterministic(shape):
     """300 forwards of BASELINE config 1 (B = 2) with every 3x3 conv forced onto one Winograd kernel must be bit-identical.  The
     kernels count their own VMEM waits; a register the compiler copies (or reuses) while a load into it is still in flight shows
