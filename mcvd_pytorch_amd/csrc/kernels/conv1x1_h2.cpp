@@ -40,7 +40,7 @@ constexpr int Q1_MAXIMG = 4;     // images a pixel tile may span (HW >= 32)
 
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU
 // EXP != 0 (built with -DMCVD_DIAG only; env MCVD_Q1_EXP): timing-only ablations of the K loop, wrong results: bit 0 no DMA behind the
-// first three chunks, bit 1 no MFMA, bit 2 no affine / SiLU / split, bit 3 no barrier
+// first three chunks, bit 1 no MFMA, bit 2 no affine / SiLU / split, bit 3 no barrier; bit 4 (right results): the split is not pinned in front of the next barrier
 template <int NP, int COT, int PRO, int EXP = 0>
 __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptiles, int nct) {
     typedef Pieces<NP> PX;
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
         }
     }
     const int my_img = HW >= PT ? 0 : (wave * 32) / HW;            // image (within the tile) of this wave's 32 pixels
+    const int x_lane = wave * 32 + l31 + half * PT;                // the lane's pixel, row `half` of the chunk
 
 #define Q1_DMA(ch)                                                                                              \
     {                                                                                                           \
@@ -148,6 +149,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     // staged -- its pixel / coefficient reads are issued first, its affine / SiLU / split (the other B register set) is independent of
     // the MFMAs and the compiler interleaves the two.  Round 2's loop did LDS reads -> VALU -> MFMAs of ONE chunk in sequence between
     // two barriers: 2.3 k cycles per chunk with 0.58 k of matrix work per wave (profiles/r03_timeline_wino3_conv1x1_b3.txt).
+    // What a chunk costs (profiles/r04_conv1x1_h2_ablation.txt, cycles per chunk at two workgroups per CU, 1152 of them MFMA time of the
+    // two waves of a SIMD): the times of the parts ADD rather than overlap -- no MFMAs -51 %, no split -30 %, no DMA -17 % -- and a wave
+    // issues one VALU instruction per ~7.6 cycles (profiles/r03_ubench_mfma_valu.txt), so every VALU instruction of the staging counts:
+    // the eight pixel reads differ by immediates (two per ds_read2st64_b32), the affine is eight v_fma_f32 in asm (the vectoriser's
+    // v_pk_fma_f32 cost three v_mov per pair), the barrier is the builtin (behind an asm wait the compiler's lgkmcnt bookkeeping held
+    // the first MFMA of every chunk for the pixel reads): 90 -> 52 VALU per chunk, 1.88 k -> 1.68 k cycles.  Tried and dropped: two A
+    // register sets with the reads behind the barrier (+5 %: the scheduler chains the MFMAs per accumulator), s_setprio around the MFMAs
+    // (+3 %), three instead of two workgroups per CU (round 3: no gain).
     const int nchunks = Cin / CK;          // Cin % CK == 0 (launch check): the zero rows that pad the weights are never staged
     Q1_DMA(0);
     if (nchunks > 1) Q1_DMA(1);
@@ -166,13 +175,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
         if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * G) : "memory");                           \
         else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G) : "memory");                          \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
-        if (!(EXP & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                        \
+        if (!(EXP & 8)) {      /* builtins, not asm: the compiler's own lgkmcnt bookkeeping must see that the LDS reads have drained */ \
+            asm volatile("" ::: "memory");                                                                      \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 /* lgkmcnt(0) */                                 \
+            __builtin_amdgcn_s_barrier();                                                                       \
+            asm volatile("" ::: "memory");                                                                      \
+        }                                                                                                       \
         if ((k) + 3 < nchunks && !(EXP & 1)) Q1_DMA((k) + 3);                                                   \
-        const float* sXc = sX + ((k) & (NB - 1)) * XSZ + wave * 32 + l31;                                       \
-        const float* sCb = sC + ((long)my_img * Cin + (k) * CK) * 2;                                            \
+        const float* sXc = sX + ((k) & (NB - 1)) * XSZ + x_lane;       /* (the lane's half is in the base: the eight reads differ by immediates) */ \
+        const float* sCb = sC + ((long)my_img * Cin + (k) * CK) * 2 + half * 2;                                 \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {         /* element e of lane (n, h) = channel 2e + h of the chunk */ \
-            BV[e] = sXc[(2 * e + half) * PT];                                                                   \
-            if (PRO != 0) CF[e] = *reinterpret_cast<const f32x2*>(sCb + (2 * e + half) * 2);                    \
+            BV[e] = sXc[2 * e * PT];                                                                            \
+            if (PRO != 0) CF[e] = *reinterpret_cast<const f32x2*>(sCb + 4 * e);                                 \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     }
@@ -189,8 +203,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     if (EXP & 4) { _Pragma("unroll") for (int p = 0; p < NP; ++p) _Pragma("unroll") for (int j = 0; j < 4; ++j) BP[p][j] = __builtin_bit_cast(unsigned, BV[2 * j]); } else \
     {                                                                                                           \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                         \
-            if (PRO != 0) {                                                                                     \
-                BV[e] = BV[e] * CF[e].x + CF[e].y;                                                              \
+            if (PRO != 0) {     /* (asm: the vectoriser pairs these into v_pk_fma_f32 and pays three v_mov per pair to line the operands up) */ \
+                asm("v_fma_f32 %0, %1, %2, %3" : "=v"(BV[e]) : "v"(BV[e]), "v"(CF[e].x), "v"(CF[e].y));         \
                 if (PRO == 2) BV[e] = silu_q(BV[e]);                                                            \
             }                                                                                                   \
             if (NP == 2) BV[e] *= PX::ACT_SCALE;                                                                \
@@ -215,8 +229,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
         Q1_STAGE((k) + 1, bv, cf)                                                                               \
         Q1_MMA(aw, BPC)                                                                                         \
         Q1_PREP(bv, cf, BPN)                                                                                    \
+        /* the split ends HERE (left alone the scheduler sinks every other chunk's split below the next barrier, where nothing overlaps it) */ \
+        if (!(EXP & 16)) {                                                                                      \
+            /* three MFMAs lead (the wait for the pixel reads comes behind them), the others follow a share of the split each */ \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                  \
+            _Pragma("unroll") for (int i_ = 3; i_ < PX::NPROD * COT; ++i_) {                                    \
+                __builtin_amdgcn_sched_group_barrier(0x002, NVS, 0);                                            \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+            }                                                                                                   \
+            _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) asm volatile("" : "+v"(BPN[p_]));                 \
+        }                                                                                                       \
         Q1_READ_AW((k) + 1, aw)                                                                                 \
     }
+    constexpr int NVS = (PRO == 2 ? 120 : PRO == 1 ? 76 : 64) / (PX::NPROD * COT > 3 ? PX::NPROD * COT - 3 : 1) + 1;      // VALU instructions per MFMA
     {
         float bv[8];
         f32x2 cf[8];
@@ -383,6 +408,7 @@ static int q1_launch(const ConvArgs& a, hipStream_t s) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, 3, 1, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, 3, 1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, 3, 1, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, 3, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 raised2.done();
             }
             switch (e) {      // (all with the affine prologue instantiation: the caller passes coef)
@@ -391,8 +417,26 @@ static int q1_launch(const ConvArgs& a, hipStream_t s) {
                 case 4: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 4>), grid, dim3(256), lds, s, a, ptiles, nct); break;
                 case 6: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 6>), grid, dim3(256), lds, s, a, ptiles, nct); break;
                 case 7: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 7>), grid, dim3(256), lds, s, a, ptiles, nct); break;
+                case 16: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 16>), grid, dim3(256), lds, s, a, ptiles, nct); break;
                 default: hipLaunchKernelGGL((conv1x1_h2_kernel<3, 3, 1, 15>), grid, dim3(256), lds, s, a, ptiles, nct); break;
             }
+            MCVD_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
+    if constexpr (NP == 3) {     // diagnostics build only: MCVD_Q1_NOPRIO=1 runs the loop of EXP bit 4 (right results) for the A/B
+        static const bool noprio = getenv("MCVD_Q1_NOPRIO") && atoi(getenv("MCVD_Q1_NOPRIO")) != 0;
+        if (noprio) {
+            static PerDeviceOnce raised3;
+            if (raised3.first_use()) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                raised3.done();
+            }
+            if (!a.coef) hipLaunchKernelGGL((conv1x1_h2_kernel<NP, COT, 0, 16>), grid, dim3(256), lds, s, a, ptiles, nct);
+            else if (!a.act) hipLaunchKernelGGL((conv1x1_h2_kernel<NP, COT, 1, 16>), grid, dim3(256), lds, s, a, ptiles, nct);
+            else hipLaunchKernelGGL((conv1x1_h2_kernel<NP, COT, 2, 16>), grid, dim3(256), lds, s, a, ptiles, nct);
             MCVD_HIP_CHECK(hipGetLastError());
             return 0;
         }
