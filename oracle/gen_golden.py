@@ -154,6 +154,30 @@ def gen_fpndm(name="tiny", batch=3, subsample=10):
           f"noclip range [{fin.min():.4f}, {fin.max():.4f}]")
 
 
+def gen_fpndm_wide(name, batch, subsample):
+    """FPNDM_sampler of the REAL reference (models/__init__.py:38-99, models/pndm.py) at a full-width BASELINE config: final frames of the
+    clipped run, plus the fp32-vs-fp64 distance of the same call on the oracle restatement (the sampler is deterministic and its
+    linear multistep combination amplifies forward rounding: the tolerance of a test on this fixture stands on that number)."""
+    import models as ref_models
+    from oracle import sampler_ref
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    net.load_state_dict(synth.make_state_dict(config, seed=123), strict=False)
+    x, cond = synth.make_inputs(config, batch, seed=0)
+    res = ref_models.FPNDM_sampler(x.clone(), net, cond=cond, final_only=True, subsample_steps=subsample, clip_before=True,
+                                   verbose=False, log=False)
+    sd = synth.make_state_dict(config, seed=123)
+    o32 = sampler_ref.fpndm_sample(x.clone(), unet_ref.OracleScoreNet(config, sd), cond=cond, final_only=True,
+                                   subsample_steps=subsample, clip_before=True)
+    o64 = sampler_ref.fpndm_sample(x.double().clone(), unet_ref.OracleScoreNet(config, sd, dtype=torch.float64), cond=cond.double(),
+                                   final_only=True, subsample_steps=subsample, clip_before=True)
+    drift = float((res.double() - o64.double()).abs().max())
+    print(f"  reference fp32 vs oracle fp64: {drift:.3e}; oracle fp32 vs reference fp32: {float((o32 - res).abs().max()):.3e}")
+    torch.save(dict(config_name=name, batch=batch, subsample=subsample, result=res.clone(), ref32_vs_ref64_max_abs=drift),
+               os.path.join(OUT, f"{name}_b{batch}_fpndm{subsample}.pt"))
+    print(f"wrote {name}_b{batch}_fpndm{subsample}.pt  shape {tuple(res.shape)}  range [{res.min():.4f}, {res.max():.4f}]")
+
+
 def gen_sampler_only(name, batch, subsample, kind="ddpm", measure_drift=False):
     """Full `ddpm_sampler` of the REAL reference at a full-width BASELINE config with the injected noise sequence: the final
     frames (full tensor, small) -- pins the oracle and the HIP path end-to-end at configs 3 / 4."""
@@ -437,6 +461,8 @@ def main_round2():
         gen_autoregressive("cityscapes_big", 1, 8, 100)
     if "cfg2ddim" in which:        # round 4: DDIM (deterministic: no per-step noise to wash rounding out) over 100 steps at the headline width
         gen_sampler_only("smmnist_big5_ngf96", 2, 100, kind="ddim", measure_drift=True)
+    if "cfg2fpndm" in which:       # round 4: the F-PNDM sampler at the headline width (25 sampler steps = 34 forwards)
+        gen_fpndm_wide("smmnist_big5_ngf96", 2, 25)
     if "f4" in which:
         gen_f4()
     if "cs_spade" in which:

@@ -1176,6 +1176,26 @@ def test_ddim_100_at_the_headline_width_vs_reference_golden(golden_dir):
         assert err <= tol, f"DDIM-100 at ngf 96 (final_only={final_only}): {err:.3e} > {tol:.3e} (reference fp32 vs fp64: {g['ref32_vs_ref64_max_abs']:.3e})"
 
 
+def test_fpndm_25_at_the_headline_width_vs_reference_golden(golden_dir):
+    """`FPNDM_sampler` (models/__init__.py:38-99, models/pndm.py), 25 sampler steps (34 forwards: three Runge-Kutta starts, then the
+    four-step Adams-Bashforth form) at BASELINE config 2 (ngf 96), B = 2, under the kernel table the bench pins, against the REAL
+    reference's frames -- device loop (mcvd_fpndm_run) and host loop.  Deterministic and a linear multistep combination of epsilons:
+    the tolerance is three times the reference's fp32-vs-fp64 distance on this call (in the fixture), at least the 1e-4 contract."""
+    import json
+    from mcvd_pytorch_amd.samplers import fpndm_sampler
+    g = torch.load(os.path.join(golden_dir, "smmnist_big5_ngf96_b2_fpndm25.pt"), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(golden_dir))), "profiles", "tune_smmnist_big5_ngf96_B64_bf16x3.json")
+    net.set_tuning(g["batch"], json.load(open(path))["64"])
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    tol = max(1e-4, 3.0 * g["ref32_vs_ref64_max_abs"])
+    for final_only in (True, False):
+        out = fpndm_sampler(x.cuda(), net, cond=cond.cuda(), final_only=final_only, subsample_steps=g["subsample"], clip_before=True)[-1:].cpu()
+        assert out.shape == g["result"].shape
+        err = (out - g["result"]).abs().max().item()
+        assert err <= tol, f"F-PNDM-25 at ngf 96 (final_only={final_only}): {err:.3e} > {tol:.3e} (reference fp32 vs fp64: {g['ref32_vs_ref64_max_abs']:.3e})"
+
+
 @pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
 def test_bench_kernel_table_vs_reference_golden(golden_dir, arith):
     """The kernel table bench.py pins for the headline workload (profiles/tune_smmnist_big5_ngf96_B64_<arith>.json: tuned at B = 64 on

@@ -132,6 +132,20 @@ def test_ddim_100_at_the_headline_width_matches_reference(golden_dir):
     assert (out - g["result"]).abs().max().item() <= max(1e-4, 3.0 * g["ref32_vs_ref64_max_abs"])
 
 
+def test_fpndm_25_at_the_headline_width_matches_reference(golden_dir):
+    """The oracle's F-PNDM sampler against the REAL reference's FPNDM_sampler (models/__init__.py:38-99, models/pndm.py) at BASELINE
+    config 2 (ngf 96), 25 sampler steps = 34 forwards: deterministic linear multistep -- the tolerance is three times the reference's
+    fp32-vs-fp64 distance on this call (recorded in the fixture), at least 1e-4."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    g = load(golden_dir, "smmnist_big5_ngf96_b2_fpndm25.pt")
+    config = synth.make_config(g["config_name"])
+    net = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123))
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    out = sampler_ref.fpndm_sample(x.clone(), net, cond=cond, final_only=True, subsample_steps=g["subsample"], clip_before=True)
+    assert out.shape == g["result"].shape
+    assert (out - g["result"]).abs().max().item() <= max(1e-4, 3.0 * g["ref32_vs_ref64_max_abs"])
+
+
 def ar_oracle(config, sd, batch, nfp, subsample):
     """The autoregressive block loop (runners/ncsn_runner.py:1504-1569) over the oracle sampler, with the inputs of
     oracle/gen_golden.py:gen_autoregressive (init seed 50 + block, step noise seed 60 + block)."""
