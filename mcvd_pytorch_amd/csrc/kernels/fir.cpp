@@ -74,26 +74,51 @@ __global__ __launch_bounds__(256) void fir2_kernel(FirArgs a) {
         } else {
             // per axis: y[m] = (x[2m-1] + 3x[2m] + 3x[2m+1] + x[2m+2]) / 8
             float col[10], colr[10];
-            if (!a.gamma) {
-                // non-SPADE: the 4 x 10 input window as two aligned float4 + the two edge columns per row, unconditional with
-                // clamped coordinates (16 loads instead of 40 predicated ones), zeroed AFTER the activation where outside
+            {
+                // the 4 x 10 input window as two aligned float4 + the two edge columns per row, unconditional with clamped coordinates
+                // (16 loads instead of 40 predicated ones), zeroed AFTER the activation where outside.  SPADE: the gamma and beta maps
+                // of the same window the same way -- until round 4 that case took the element-wise path of fir_src: 120 predicated
+                // scalar loads per thread, 95 us for a launch that takes 24 this way (profiles/r04_rocprofv3_cfg4_bair_big_spade.txt)
                 const int x0 = 2 * ox0;                                   // multiple of 8
                 const bool in_l = x0 > 0, in_r = x0 + 8 < a.W;
+                const float* gplane = nullptr;
+                const float* bplane = nullptr;
+                if (a.gamma) {
+                    const long b = bc / a.C, c = bc - b * a.C;
+                    gplane = a.gamma + (b * 2 * a.C + c) * (long)a.H * a.W;
+                    bplane = a.beta + (b * 2 * a.C + c) * (long)a.H * a.W;
+                }
                 float hv[4][10], rv[4][10];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int yy = 2 * oy - 1 + r;
                     const bool in_y = yy >= 0 && yy < a.H;
-                    const float* rowp = plane + min(max(yy, 0), a.H - 1) * a.W;
+                    const int roff = min(max(yy, 0), a.H - 1) * a.W;
+                    const int xl = max(x0 - 1, 0), xr = min(x0 + 8, a.W - 1);
+                    const float* rowp = plane + roff;
                     const float4 q0 = *reinterpret_cast<const float4*>(rowp + x0);
                     const float4 q1 = *reinterpret_cast<const float4*>(rowp + x0 + 4);
-                    const float vals[10] = {rowp[max(x0 - 1, 0)], q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                            rowp[min(x0 + 8, a.W - 1)]};
+                    const float vals[10] = {rowp[xl], q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, rowp[xr]};
+                    float gv[10], bv[10];
+                    if (a.gamma) {
+                        const float* grow = gplane + roff;
+                        const float* brow = bplane + roff;
+                        const float4 g0 = *reinterpret_cast<const float4*>(grow + x0), g1 = *reinterpret_cast<const float4*>(grow + x0 + 4);
+                        const float4 b0 = *reinterpret_cast<const float4*>(brow + x0), b1 = *reinterpret_cast<const float4*>(brow + x0 + 4);
+                        const float gt[10] = {grow[xl], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, grow[xr]};
+                        const float bt[10] = {brow[xl], b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, brow[xr]};
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) { gv[j] = gt[j]; bv[j] = bt[j]; }
+                    }
 #pragma unroll
                     for (int j = 0; j < 10; ++j) {
                         const bool in = in_y && (j == 0 ? in_l : j == 9 ? in_r : true);
                         float v = vals[j];
                         if (a.coef) v = v * cA + cB;
+                        if (a.gamma) {                                   // fir_src's order
+                            v = v * (1.0f + gv[j]) + bv[j];
+                            v = v * sA + sB;
+                        }
                         if (a.act) v = silu1(v);
                         hv[r][j] = in ? v : 0.0f;
                         rv[r][j] = in ? vals[j] : 0.0f;
@@ -103,17 +128,6 @@ __global__ __launch_bounds__(256) void fir2_kernel(FirArgs a) {
                 for (int j = 0; j < 10; ++j) {
                     col[j] = (hv[0][j] + 3.0f * hv[1][j] + 3.0f * hv[2][j] + hv[3][j]) * 0.125f;
                     colr[j] = (rv[0][j] + 3.0f * rv[1][j] + 3.0f * rv[2][j] + rv[3][j]) * 0.125f;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 10; ++j) {
-                    const int xx = 2 * ox0 - 1 + j;
-                    const V2 v0 = fir_src(a, plane, pidx, 2 * oy - 1, xx, cA, cB, sA, sB);
-                    const V2 v1 = fir_src(a, plane, pidx, 2 * oy, xx, cA, cB, sA, sB);
-                    const V2 v2 = fir_src(a, plane, pidx, 2 * oy + 1, xx, cA, cB, sA, sB);
-                    const V2 v3 = fir_src(a, plane, pidx, 2 * oy + 2, xx, cA, cB, sA, sB);
-                    col[j] = (v0.h + 3.0f * v1.h + 3.0f * v2.h + v3.h) * 0.125f;
-                    colr[j] = (v0.r + 3.0f * v1.r + 3.0f * v2.r + v3.r) * 0.125f;
                 }
             }
 #pragma unroll
