@@ -139,7 +139,17 @@ def cpu_baseline(config, state_dict, subsample, budget_s=24.0, kept_fraction=1.0
     dt = time.perf_counter() - t0
     per_fwd = dt / max(n_steps, 1)
     fps = kept_fraction * B * config.data.num_frames / (per_fwd * (subsample + 1))      # autoregressive: kept / generated frames
-    return dict(value=round(fps, 4), unit="frames/s", cores=cores, kind="port", host_threads_available=ncpu,
+    pvr = {}
+    try:      # the ratio port / REAL reference, measured where both exist (the build container; tools/cpu_port_vs_reference.py)
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r05_cpu_port_vs_reference.json")))
+        pvr = dict(port_vs_reference=pj["port_vs_reference"],
+                   port_vs_reference_source="profiles/r05_cpu_port_vs_reference.json (build container, %d threads, %s B=%d: the Python reference "
+                                            "does not travel to the GPU box)" % (pj["threads"], pj["config"], pj["batch"]),
+                   reference_estimate=round(fps / pj["port_vs_reference"], 4),
+                   reference_estimate_note="value / port_vs_reference: the reference's own frames/s on this box's cores, estimated")
+    except Exception:
+        pass
+    return dict(value=round(fps, 4), unit="frames/s", cores=cores, kind="port", host_threads_available=ncpu, **pvr,
                 thread_sweep_s_per_forward={str(k): round(v, 4) for k, v in sweep.items()},
                 sample=f"oracle ddpm_sampler, B={B}, {n_steps} of {subsample + 1} forwards timed ({dt:.1f}s) at the best of the "
                        f"swept thread counts ({cores} of {ncpu} hardware threads), extrapolated linearly; torch {torch.__version__} CPU")
@@ -233,7 +243,9 @@ def roofline_of_leg(net, args, B, arith_name):
                     conv1x1_kernels={str(k): v for k, v in sorted(k1.items())},
                     all_conv3x3=dict(launches=c3["launches"], ms=round(c3["ms"], 3), tflops=round(c3["flops"] / c3["ms"] / 1e9, 2)),
                     forward_ms_events=round(fwd_ms, 3),
-                    forward_ms_events_note="sum of per-op event intervals of ONE instrumented forward: upper bound (event gaps, ~3 %)",
+                    forward_ms_events_note="sum of per-op event intervals of ONE instrumented forward, which runs op by op on the stream, OUTSIDE the "
+                                           "hipGraph every other forward of the call replays: an upper bound of a replayed forward (event gaps, no "
+                                           "overlap of neighbouring launches' ramp-up and tail); the line's forward_events_vs_step has the measured ratio",
                     breakdown=breakdown)
     n1 = sum(k1.values())
     if fam["wino_f16x2"]["launches"] or k1.get(14):
@@ -251,6 +263,44 @@ def roofline_of_leg(net, args, B, arith_name):
     else:
         arith = "f32 (fp32 MFMA / fp32 VALU everywhere)"
     return roofline, arith
+
+
+def pmc_traffic(args, roofline):
+    """`--pmc-traffic`: HBM-side bytes per launch of the dominant kernel family measured NOW, by two rocprofv3 PMC passes of this very
+    script on this GPU (one counter per pass, kernel-trace only -- MI355X_MICROARCH.md's recipe; the outer process is idle meanwhile),
+    under the same committed kernel table, 6 forwards each, no graph (one dispatch record per kernel).  Returns the roofline fields."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import summarize_prof
+    if shutil.which("rocprofv3") is None:
+        return dict(traffic_measured_in_run=False, traffic_note="--pmc-traffic: rocprofv3 not on PATH")
+    base = tempfile.mkdtemp(prefix="mcvd_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, TMPDIR="/tmp", MCVD_BENCH_INNER="1")
+    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", args.config, "--steps", "1", "--warmup", "0", "--subsample", "5",
+             "--no-cpu-baseline", "--no-f16x2-leg", "--no-selfcheck", "--graph", "0", "--f16x2", str(args.f16x2)]
+    if args.batch:
+        inner += ["--batch", str(args.batch)]
+    dirs = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        dirs[counter] = os.path.join(base, counter.lower())
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", dirs[counter], "-o", "bench", "--"] + inner
+        rc = subprocess.call(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        if rc != 0:
+            shutil.rmtree(base, ignore_errors=True)
+            return dict(traffic_measured_in_run=False, traffic_note=f"--pmc-traffic: the {counter} pass returned {rc}")
+    t = summarize_prof.family_traffic(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"], roofline["kernel"])
+    shutil.rmtree(base, ignore_errors=True)
+    if not t:
+        return dict(traffic_measured_in_run=False, traffic_note="--pmc-traffic: no dispatch of the dominant family in the PMC passes")
+    tb = t["traffic_bytes_per_launch"]
+    return dict(traffic=round(tb), traffic_from_file=False, traffic_measured_in_run=True, traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                "passes spawned by this run (6 forwards each, same kernel table, no graph)", traffic_file_sha16=None,
+                traffic_fetch_bytes_per_launch_corrected=round(t["fetch_bytes_per_launch_corrected"]),
+                traffic_write_bytes_per_launch=round(t["write_bytes_per_launch"]),
+                traffic_launches=[t["launches_fetch_pass"], t["launches_write_pass"]],
+                traffic_vs_algorithmic=round(tb / roofline["algorithmic_bytes_per_launch"], 3),
+                hbm_gbs=round(tb / (roofline["avg_launch_us"] * 1e-6) / 1e9, 1))
 
 
 def main():
@@ -275,6 +325,12 @@ def main():
                     "-- tests compare an N-rank job with the N = 1 job of the same global batch bit for bit")
     ap.add_argument("--no-f16x2-leg", "--no-fp32-leg", dest="no_second_leg", action="store_true",
                     help="skip the second, reported-only timing with the two-piece fp16 kernels offered")
+    ap.add_argument("--pmc-traffic", action="store_true", help="N = 1: measure roofline.traffic IN THIS RUN -- after the timed region, two short "
+                    "rocprofv3 passes of this script (--pmc FETCH_SIZE, then --pmc WRITE_SIZE; kernel-trace only, one counter per pass, 6 forwards "
+                    "under the same kernel table) and (2 x FETCH + WRITE) / launches of the dominant family (MI355X_MICROARCH.md, HBM section). "
+                    "Adds about a minute; without it the line quotes the committed PMC file (traffic_from_file)")
+    ap.add_argument("--selfcheck-tol", type=float, default=1e-6, help="the run FAILS (valid: false, exit code 3) when row 0 of the last timed "
+                    "call differs from the same row sampled alone by more than this (expected: exactly 0.0 under one kernel table)")
     ap.add_argument("--f16x2", type=int, default=0, help="1: the headline leg itself offers the two-piece fp16 kernels (narrower arithmetic "
                     "than the reference's: NOT the contract number; the default headline is the fp32-equivalent three-piece bf16 path)")
     args = ap.parse_args()
@@ -467,6 +523,17 @@ def main():
                                     selfcheck_max_abs=second["selfcheck_max_abs"],
                                     note="same workload, same K steps, context option f16x2 = 1 (1 warm-up call: re-tune or table load): "
                                          "reported only, narrower arithmetic than the reference's")
+        # the instrumented forward against the replayed ones: (its event sum x forwards per call) / measured time per call
+        res["roofline"]["forward_events_vs_step"] = round(main_leg["roofline"]["forward_ms_events"] * fwd_per_step / main_leg["ms_per_step"], 4)
+        if args.pmc_traffic and world == 1:
+            res["roofline"].update(pmc_traffic(args, main_leg["roofline"]))
+        # ---- validity: a throughput line whose frames are wrong is not a measurement
+        checks = [main_leg["selfcheck_max_abs"]] + ([second["selfcheck_max_abs"]] if second else [])
+        bad = [c for c in checks if c is not None and not (c <= args.selfcheck_tol)]
+        res["valid"] = not bad
+        if bad:
+            res["invalid_reason"] = (f"selfcheck_max_abs {bad[0]:.3e} > {args.selfcheck_tol:.1e}: row 0 of the benchmarked batch differs from the "
+                                     "same row sampled alone under the same kernel table (expected 0.0)")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(config, sd, subsample, kept_fraction=nfp / (n_blocks * nfr) if autoreg else 1.0)
@@ -475,6 +542,11 @@ def main():
             except Exception as e:      # the baseline is reporting only; never lose the GPU line
                 res["cpu_baseline"] = dict(value=None, unit="frames/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e}")
         print(json.dumps(res), flush=True)
+        if not res["valid"]:
+            print("bench.py: INVALID RUN -- " + res["invalid_reason"], file=sys.stderr, flush=True)
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(3)
     if world > 1:
         dist.destroy_process_group()
 

@@ -140,19 +140,40 @@ int mcvd_ctx_selftest(mcvd_ctx* ctx) {
     MCVD_HIP_CHECK(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     const float *x = dev, *w = dev + nx, *bias = w + nw, *coef = bias + Cout, *res = coef + 2 * Cin;
     float* y = dev + host.size();
-    const int saved_shape = ctx->conv_shape, saved_naive = ctx->naive_conv;
+    // The test runs under ITS OWN options: whatever the caller left set on the context (a forced kernel, a statistics buffer the
+    // epilogue would write 96-channel partials into, SPADE maps, a debug buffer, the f16x2 arithmetic) is put aside and restored.
+    // A launch that cannot run (hipMalloc, a launch error) is NOT a verdict: the state stays 0 ("not yet run"), bf16x3 stays as it
+    // was and the real error is returned; only a test that ran and mismatched switches the option off (MCVD_ESELFTEST).
+    struct Saved {
+        mcvd_ctx* c;
+        int conv_shape, naive_conv, f16x2, bf16x3, spade_fuse;
+        float* stats_buf;
+        const float *spade_gb, *spade_coef2;
+        unsigned long long* dbg;
+        explicit Saved(mcvd_ctx* c_) : c(c_), conv_shape(c_->conv_shape), naive_conv(c_->naive_conv), f16x2(c_->f16x2), bf16x3(c_->bf16x3),
+                                       spade_fuse(c_->spade_fuse), stats_buf(c_->stats_buf), spade_gb(c_->spade_gb), spade_coef2(c_->spade_coef2),
+                                       dbg(c_->dbg) {
+            c->naive_conv = 0; c->f16x2 = 0; c->bf16x3 = 1; c->spade_fuse = 0;
+            c->stats_buf = nullptr; c->spade_gb = nullptr; c->spade_coef2 = nullptr; c->dbg = nullptr;
+        }
+        ~Saved() {
+            c->conv_shape = conv_shape; c->naive_conv = naive_conv; c->f16x2 = f16x2; c->spade_fuse = spade_fuse;
+            if (c->wino_selftest >= 0) c->bf16x3 = bf16x3;            // a failed verdict keeps the option off
+            c->stats_buf = stats_buf; c->spade_gb = spade_gb; c->spade_coef2 = spade_coef2; c->dbg = dbg;
+        }
+    };
     const int shapes[3] = {4, 10, 16};
     int rc = 0, ran[3] = {-1, -1, -1};
-    ctx->naive_conv = 0;
-    for (int k = 0; k < 3 && rc == 0; ++k) {
-        ctx->conv_shape = shapes[k];
-        rc = mcvd_op_conv2d(ctx, x, Cin, nullptr, 0, w, bias, Cout, 3, coef, 1, res, 0.70710678f, y + k * ny, B, H, H);
-        ran[k] = last_conv_kernel();
-    }
-    ctx->conv_shape = saved_shape;
-    ctx->naive_conv = saved_naive;
-    if (rc) return rc;
     std::vector<float> out(3 * ny);
+    {
+        Saved saved(ctx);
+        for (int k = 0; k < 3 && rc == 0; ++k) {
+            ctx->conv_shape = shapes[k];
+            rc = mcvd_op_conv2d(ctx, x, Cin, nullptr, 0, w, bias, Cout, 3, coef, 1, res, 0.70710678f, y + k * ny, B, H, H);
+            ran[k] = last_conv_kernel();
+        }
+    }
+    if (rc) return rc;                     // could not run: mcvd_last_error has the launch's own message; state stays 0
     MCVD_HIP_CHECK(hipMemcpyAsync(out.data(), y, 3 * ny * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     MCVD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     float scale = 0.0f, d10 = 0.0f;

@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256) void dense_all_kernel(const float* __restrict_
 
 int launch_dense_all(const float* act, const float* wt, const float* bias, float* out, int B, int K, int N,
                      hipStream_t s) {
-    MCVD_REQUIRE(K <= 1152 && N % 4 == 0 && N >= 4, "dense_all: K=%d N=%d", K, N);
+    // N = NE = sum over the Dense_0 entries of 2 * channels, channels = ngf * ch_mult (+ a skip's): build_plan admits ngf % 4 == 0 only
+    // (model.cpp), so every entry starts at a multiple of 8 floats and N % 4 == 0 holds for every model the plan accepts (ADVICE r4 asked
+    // whether the float4 rows narrowed the supported widths: they did not -- the same plan check predates them).
+    MCVD_REQUIRE(K <= 1152 && N % 4 == 0 && N >= 4, "dense_all: K=%d N=%d (N is a sum of 2 * channels with ngf %% 4 == 0)", K, N);
     const int nb = (N / 4 + 15) / 16;
     if (B == 1)
         hipLaunchKernelGGL(dense_all_kernel<1>, dim3(nb, 1), dim3(256), 0, s, act, wt, bias, out, B, K, N);

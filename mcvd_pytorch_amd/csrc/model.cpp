@@ -589,11 +589,7 @@ int mcvd_model::ensure_workspace(int B) {
     MCVD_HIP_CHECK(hipMalloc((void**)&labels, (size_t)B * sizeof(int64_t)));
     MCVD_HIP_CHECK(hipMalloc((void**)&labels_f, (size_t)B * sizeof(float)));
     MCVD_HIP_CHECK(hipMalloc((void**)&eps_buf, per * B * sizeof(float)));
-    size_t kfl = 0;                               // K-split Winograd candidates: 3x3 layers at 8x8 / 16x16
-    for (const Op& op : ops)
-        if (op.kind == OP_CONV && op.ks == 3 && op.wpw >= 0 && op.H * op.W <= 256)
-            kfl = std::max(kfl, (size_t)8 * B * op.Cout * op.H * op.W);         // up to 8 parts (shape id 19)
-    if (kfl) MCVD_HIP_CHECK(hipMalloc((void**)&ksplit_buf, kfl * sizeof(float)));
+    ksplit_floats = 0;                            // sized by ensure_ksplit (prepare_B) for the deepest K split this batch can select
     if (d.noise_in_cond && d.num_frames_cond > 0)
         MCVD_HIP_CHECK(hipMalloc((void**)&cond_z, (size_t)d.channels * d.num_frames_cond * d.image_size * d.image_size * B * sizeof(float)));
     if (d.gamma) MCVD_HIP_CHECK(hipMalloc((void**)&noise_buf, per * B * sizeof(float)));
@@ -1072,8 +1068,42 @@ int mcvd_model::ensure_f16x2_weights() {
     return 0;
 }
 
+// Partial-output buffer of the K-split Winograd layers (H*W <= 256): `parts` x B x Cout x HW floats for the DEEPEST split anything can
+// select at this batch (it was 8 parts for every model and batch, ~200 MB for config 2 at B = 64 where no layer ever takes more
+// than 2): 2 parts everywhere; 4 / 8 where the autotuner's own rule offers shape ids 18 / 20 / 19 (few (region, cout tile) pairs:
+// autotune()), where a test forces one of them (conv_shape), or where an installed table for this batch names one.
+int mcvd_model::ensure_ksplit(int B) {
+    size_t need = 0;
+    const std::vector<int>* table = nullptr;
+    auto it = tuned_cache.find(B);
+    if (it != tuned_cache.end() && it->second.first.size() == ops.size()) table = &it->second.first;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const Op& op = ops[i];
+        if (!(op.kind == OP_CONV && op.ks == 3 && op.wpw >= 0 && op.H * op.W <= 256)) continue;
+        int parts = 2;
+        const bool g8 = op.H == 8 && op.W == 8;
+        const long pairs = (g8 ? (B + 1) / 2 : (long)B * (op.H / 8) * (op.W / 16)) * (op.CoutP / (32 * conv_wino_cout_tile(op.Cout)));
+        if (ctx->autotune && !table && tuned_B != B && 2 * pairs < 1024) parts = 4 * pairs < 1024 ? 8 : 4;    // the candidates autotune() is about to time
+        auto deepen = [&](int shape) { if (shape == 19) parts = std::max(parts, 8); else if (shape == 18 || shape == 20) parts = std::max(parts, 4); };
+        deepen(ctx->conv_shape);
+        if (table) deepen((*table)[i]);
+        if (tuned_B == B && i < tuned_shape.size()) deepen(tuned_shape[i]);
+        need = std::max(need, (size_t)parts * B * op.Cout * op.H * op.W);
+    }
+    if (need <= ksplit_floats) return 0;
+    MCVD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ksplit_buf) MCVD_HIP_CHECK(hipFree(ksplit_buf));
+    ksplit_buf = nullptr;
+    ksplit_floats = 0;
+    MCVD_HIP_CHECK(hipMalloc((void**)&ksplit_buf, need * sizeof(float)));
+    ksplit_floats = need;
+    ++epoch;                                      // captured graphs embed the pointer
+    return 0;
+}
+
 int mcvd_model::prepare_B(int B) {
     if (int rc = ensure_workspace(B)) return rc;
+    if (int rc = ensure_ksplit(B)) return rc;
     // (a forced two-piece kernel family -- the tests' conv_shape 12 / 13 / 14 -- needs the pieces as well as the option does)
     const bool forced_h = (ctx->conv_shape >= 12 && ctx->conv_shape <= 14) || ctx->conv_shape1 == 14;
     if (ctx->f16x2 || forced_h)

@@ -180,7 +180,8 @@ struct mcvd_model {
     float* labels_f = nullptr;        // [arena_B] float labels (F-PNDM midpoints)
     float* fp_buf = nullptr;          // F-PNDM device loop: 9 state-sized buffers (4 eps history, 3 Runge-Kutta eps, x temp, combination)
     int fp_B = 0;
-    float* ksplit_buf = nullptr;      // two partial outputs of the K-split Winograd layers (H*W <= 256), sized for arena_B
+    float* ksplit_buf = nullptr;      // partial outputs of the K-split Winograd layers (H*W <= 256): ensure_ksplit sizes it per batch
+    size_t ksplit_floats = 0;
 
     std::vector<float> betas, alphas, alphas_prev, freqs;
 
@@ -237,6 +238,7 @@ struct mcvd_model {
     int add_param(const std::string& name, std::initializer_list<int64_t> shape);
     int find_param(const char* name) const;
     int ensure_workspace(int B);
+    int ensure_ksplit(int B);                               // partial-output buffer of the K-split layers, for the deepest split selectable at B
     int uniform_labels = 0;        // every row of the forward in flight carries the SAME label (the sampler loops): the time MLP and
                                    //    the Dense_0 projections are evaluated for one row and read with stride 0
     int labels_f32 = 0;            // the labels of the forward in flight are float [B] instead of int64 [B] (mcvd_unet_forward_ft)

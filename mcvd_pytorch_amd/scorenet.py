@@ -172,6 +172,50 @@ class HipScoreNet:
         self._dirty = True
         return _IncompatibleKeys(missing, unexpected)
 
+    @torch.no_grad()
+    def reset_parameters(self, generator=None):
+        """The reference's construction-time initialisation, so that `get_model(config)` without a checkpoint holds what
+        `UNetMore_DDPM(config)` holds (runners/ncsn_runner.py:180-195 hands the fresh module straight to the trainer /
+        sampler).  Same distributions per tensor, not the same draws (the reference draws in module-construction order from the
+        global generator; `generator` here is an optional CPU torch.Generator):
+          * `default_init(scale)` = variance_scaling(scale, 'fan_avg', 'uniform'), scale 0 -> 1e-10 (models/better/layers.py:43-80):
+            U(+-sqrt(3 scale / fan_avg)), fan = shape[1 | 0] * receptive field -- scale 1 for the two time-MLP Linears
+            (ncsnpp_more.py:89-95), every Dense_0 (layerspp.py:505-507), the stem, Conv_0 and the 1x1 Conv_2 (layers.py:89-113);
+            scale 0 (init_scale = 0., ncsnpp_more.py:67) for every Conv_1, NIN_3 and the last conv (layerspp.py:586, :219;
+            ncsnpp_more.py:247, :586); scale 0.1 for NIN_0..2 (layers.py:536);
+          * every bias and NIN.b zero, GroupNorm / final-norm gains 1 (torch defaults, layerspp.py:215, :477);
+          * SPADE mlp_shared / mlp_gamma / mlp_beta are `ddpm_conv3x3` too (MySPADE is given `conv=conv3x3`, layerspp.py:103, :148-150;
+            ncsnpp_more.py:433-440): scale 1, zero bias;
+          * cond_emb: nn.Embedding default N(0, 1) (ncsnpp_more.py:98)."""
+        names = list(self._params.keys())
+        last_conv = max((int(k.split(".")[2]) for k in names if self._params[k].dim() == 4), default=-1)
+        for k, p in self._params.items():
+            shape = tuple(p.shape)
+            mod = int(k.split(".")[2])
+            if p.dim() == 1:
+                if k.endswith(".weight"):                                # GroupNorm_0.weight / Norm_0.weight
+                    t = torch.ones(shape)
+                else:                                                      # .bias, NIN .b
+                    t = torch.zeros(shape)
+            elif self._desc.cond_emb and p.dim() == 2 and mod == 2 and k.endswith(".weight"):
+                t = torch.randn(shape, generator=generator)                # nn.Embedding(2, nf // 2)
+            else:
+                if k.endswith(".W"):
+                    scale = 1e-10 if ".NIN_3." in k else 0.1
+                elif ".Conv_1." in k or (p.dim() == 4 and mod == last_conv):
+                    scale = 1e-10
+                else:
+                    scale = 1.0
+                rf = 1
+                for s_ in shape[2:]:
+                    rf *= s_
+                fan_avg = (shape[0] + shape[1]) * rf / 2.0
+                t = (torch.rand(shape, generator=generator) * 2 - 1) * math.sqrt(3.0 * scale / fan_avg)
+            p.data.copy_(t.to(dtype=torch.float32))
+        self._loaded = True
+        self._dirty = True
+        return self
+
     def mark_dirty(self):
         """Call after modifying parameter tensors in place (EMAHelper.ema does this through .data.copy_)."""
         self._dirty = True
@@ -203,9 +247,11 @@ class HipScoreNet:
         """mcvd_model_finalize runs the library's self-test of its hand-scheduled Winograd kernels once per context (include/mcvd_hip.h:
         mcvd_ctx_selftest).  A failure is not fatal -- the library falls back to its fp32-MFMA kernels -- but it must not be silent."""
         rc = _lib.lib.mcvd_ctx_selftest(self._ctx)
-        if rc < 0:
+        if rc == -6:               # MCVD_ESELFTEST: the test RAN and the kernels disagreed -> the library switched bf16x3 off
             import warnings
             warnings.warn("mcvd_hip: " + _lib.last_error() + " (results stay within the fp32 contract; throughput is lower)", RuntimeWarning)
+        elif rc < 0:               # the test could not run (allocation / launch error): nothing was switched off, nothing was verified
+            raise RuntimeError("mcvd_hip: the Winograd self-test could not run: " + _lib.last_error())
 
     def eval(self):
         self.training = False
@@ -389,5 +435,6 @@ class HipScoreNet:
 
 
 def get_model(config):
-    """Factory mirroring runners/ncsn_runner.py:180-195 for arch == 'unetmore'."""
-    return HipScoreNet(config, getattr(config, "device", None))
+    """Factory mirroring runners/ncsn_runner.py:180-195 for arch == 'unetmore': like `UNetMore_DDPM(config).to(config.device)`, the
+    returned net carries the reference's construction-time initialisation (`reset_parameters`) until a checkpoint is loaded."""
+    return HipScoreNet(config, getattr(config, "device", None)).reset_parameters()

@@ -22,7 +22,7 @@ def subsampled_schedule(alphas, alphas_prev, betas, subsample_steps):
     steps = np.arange(len(betas))
     if subsample_steps is not None and subsample_steps < len(alphas):
         skip = len(alphas) // subsample_steps
-        steps = torch.tensor(list(range(0, len(alphas), skip)))
+        steps = torch.tensor(list(range(0, len(alphas), skip)), device=alphas.device)     # :231 (device=alphas.device)
         alphas = alphas.index_select(0, steps)
         alphas_prev = torch.cat([alphas[1:], torch.tensor([1.0]).to(alphas)])
         betas = 1.0 - torch.div(alphas, alphas_prev)
@@ -67,7 +67,7 @@ def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=
         started = True
 
         c_beta, c_alpha, c_alpha_prev = betas[i], alphas[i], alphas_prev[i]
-        labels = (step * torch.ones(x_mod.shape[0])).long()           # :283
+        labels = (step * torch.ones(x_mod.shape[0], device=x_mod.device)).long()           # :283
         grad = scorenet(x_mod, labels, cond=cond)                     # :284
 
         x0 = (1 / c_alpha.sqrt()) * (x_mod - (1 - c_alpha).sqrt() * grad)   # :287
@@ -90,7 +90,7 @@ def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=
                 x_mod = x_mod + ((1 - c_alpha_prev) / (1 - c_alpha) * c_beta).sqrt() * noise
 
     if denoise:                                                       # :331-335 (label L-1, sic)
-        last = ((L - 1) * torch.ones(x_mod.shape[0])).long()
+        last = ((L - 1) * torch.ones(x_mod.shape[0], device=x_mod.device)).long()
         x_mod = x_mod - (1 - alphas[-1]).sqrt() * scorenet(x_mod, last, cond=cond)
         if not final_only:
             images.append(x_mod.clone())

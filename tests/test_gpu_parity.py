@@ -916,6 +916,46 @@ def test_sampler_vs_reference_golden(golden_dir, fx, key, kind, sub, extra, path
     assert err <= tol, f"final frames max-abs err {err:.3e}"
 
 
+@pytest.mark.parametrize("fx,key,kind,sub", [
+    ("smmnist_big5_b2.pt", "ddpm_100", "ddpm", 100),              # BASELINE config 1: 100 steps + denoise
+    ("tiny_b3.pt", "ddpm_10", "ddpm", 10),
+    ("tiny_b3.pt", "ddim_10", "ddim", 10),
+    ("tiny_spade_b2.pt", "ddpm_10", "ddpm", 10),                  # SPADE: the gamma/beta cache keyed by the cond tensor survives the foreign loop
+])
+def test_only_get_model_swapped_foreign_sampler_loop(golden_dir, fx, key, kind, sub):
+    """INTEGRATION.md section 2, the case where ONLY `get_model` is replaced and `get_sampler` is not: a sampler loop that is not
+    this package's -- the line-cited restatement of the reference's `ddpm_sampler` / `ddim_sampler` (oracle/sampler_ref.py, pinned to the
+    real loop by tests/test_oracle_golden.py), running its own torch arithmetic on the device as the reference does -- is handed a
+    `HipScoreNet` and uses nothing but the scorenet protocol of SURVEY 8b: `.alphas / .alphas_prev / .betas` device buffers
+    (models/__init__.py:221), `scorenet(x, labels, cond=cond)` with int64 device labels (:283-284), the `L - 1` denoise label (:332).
+    The frames must be the reference fixture's (1e-4) and this package's own host loop's (which fuses the update into one kernel:
+    one rounding per FMA instead of one per torch op, so equal to rounding, not bit for bit)."""
+    from mcvd_pytorch_amd.samplers import ddim_sampler, ddpm_sampler
+    g = torch.load(os.path.join(golden_dir, fx), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    noise = synth.make_noise(config, g["batch"], sub + 1, seed=2).cuda()
+    assert net.alphas.is_cuda and net.alphas_prev.is_cuda and net.betas.is_cuda and not hasattr(net, "module")
+    assert isinstance(getattr(net, "type"), (str, type(None)))                     # :226 `getattr(net, 'type')` must not raise
+    draws = [0]
+
+    def fn(i, like):
+        draws[0] += 1
+        return noise[draws[0] - 1].to(like)
+    out = sampler_ref.sample(x.cuda(), net, cond=cond.cuda(), kind=kind, final_only=True, denoise=True, subsample_steps=sub,
+                             clip_before=True, noise_fn=fn)
+    assert out.is_cuda and out.shape[0] == 1
+    ref = g["sampler_" + key]["result"]
+    err = (out.cpu() - ref).abs().max().item()
+    tol = 3e-4 if kind == "ddim" else 1e-4                                          # test_sampler_vs_reference_golden has the reasons
+    assert err <= tol, f"foreign loop + HipScoreNet vs reference fixture: {err:.3e}"
+    own = (ddpm_sampler if kind == "ddpm" else ddim_sampler)(
+        x.cuda(), net, cond=cond.cuda(), final_only=False, denoise=True, subsample_steps=sub, clip_before=True, verbose=False,
+        log=False, noise=noise)[-1:]
+    err2 = (out.cpu() - own).abs().max().item()
+    assert err2 <= (1e-4 if kind == "ddim" else 2e-5), f"foreign loop vs this package's host loop: {err2:.3e}"
+
+
 def test_fpndm_vs_reference_golden(golden_dir, ctx):
     """F-PNDM (FPNDM_sampler + models/pndm.py): every step of the clipped run vs the reference's (fixture); float, fractional and
     negative timesteps through mcvd_unet_forward_ft; the un-clipped run (|x| grows to ~360) at relative tolerance."""

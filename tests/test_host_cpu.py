@@ -230,3 +230,44 @@ def test_bench_multi_gpu_flag_spawns_ranks():
     env["WORLD_SIZE"] = "2"
     with pytest.raises(SystemExit):
         bench.plan_launch(4, env)                                               # launcher / flag disagree: refuse
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_spade", "tiny_condemb", "smmnist_big5"])
+def test_reset_parameters_has_the_reference_init_distributions(name, golden_dir):
+    """`get_model(config)` without a checkpoint must hold what the reference's fresh `UNetMore_DDPM(config)` holds
+    (models/better/layers.py:43-80 `default_init`; torch defaults for GroupNorm, SPADE convs, the cond_emb Embedding).  The fixture
+    holds min / max / mean / std of every parameter tensor of the REAL reference's construction (oracle/gen_golden.py
+    `gen_init_moments`); the draws differ (the reference draws in module-construction order from the global generator), the
+    distributions must not: constant tensors exactly, uniform tensors by their support and their standard deviation."""
+    import math
+    import os
+    from mcvd_pytorch_amd.scorenet import HipScoreNet
+    want = torch.load(os.path.join(golden_dir, "init_moments.pt"), weights_only=False)[name]
+    net = HipScoreNet(synth.make_config(name), plan_only=True)
+    assert all(float(p.detach().abs().max()) == 0.0 for p in net.parameters())              # as constructed: nothing yet
+    g = torch.Generator().manual_seed(11)
+    assert net.reset_parameters(generator=g) is net and net._loaded
+    have = dict(net.named_parameters())
+    assert list(have.keys()) == list(want.keys())
+    degenerate = 0
+    for k, w in want.items():
+        p = have[k].detach()
+        assert list(p.shape) == w["shape"], k
+        n = p.numel()
+        if w["min"] == w["max"]:                                                    # zeros (biases) / ones (norm gains)
+            assert float(p.min()) == w["min"] and float(p.max()) == w["max"], (k, float(p.min()), float(p.max()), w)
+            continue
+        # the reference tensor's extremes bound the support from inside: bound >= max|ref|, and for n samples of U(-b, b) the
+        # largest |value| is above b (1 - 8 / n) with probability 1 - e^-8
+        amax_ref, amax = max(abs(w["min"]), abs(w["max"])), float(p.abs().max())
+        if k.endswith(".weight") and p.dim() == 2 and p.shape[0] == 2 and "all_modules.2." in k and name == "tiny_condemb":
+            assert 0.5 < float(p.std()) < 1.6 and abs(float(p.mean())) < 0.8, k      # nn.Embedding: N(0, 1), 2 x 16 values
+            continue
+        slack = 1.0 + 12.0 / n
+        assert amax <= amax_ref * slack * 1.02 and amax_ref <= amax * slack * 1.02, (k, amax, amax_ref)
+        if n >= 256:
+            assert abs(float(p.double().std()) / w["std"] - 1.0) < 4.0 / math.sqrt(n) + 0.02, (k, float(p.std()), w["std"])
+            assert abs(float(p.double().mean())) < 6.0 * w["std"] / math.sqrt(n) + 1e-12, k
+        degenerate += amax < 1e-6
+    # SURVEY 9.6-1: init_scale = 0 -> 1e-10 leaves Conv_1 / NIN_3 / the last conv at |w| < 1e-6 (counted with the zero biases upstream)
+    assert degenerate == sum(1 for w in want.values() if w["min"] != w["max"] and max(abs(w["min"]), abs(w["max"])) < 1e-6) > 0

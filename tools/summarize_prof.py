@@ -128,6 +128,31 @@ def l2():
                 print(f"{k:52s} {int(n0):5d} launches, {ns / max(n0, 1) / 1e3:8.1f} us avg | " + "  ".join(parts) + extra)
 
 
+def family_traffic(fetch_dir, write_dir, dom_kernel_name):
+    """HBM-side bytes per launch of the dominant 3x3 family from two PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE output
+    directories): (2 x FETCH + WRITE) / launches -- `bench.py --pmc-traffic` measures `roofline.traffic` with this in the run it
+    describes.  The x2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM section)."""
+    if dom_kernel_name.startswith("conv_wino2h_kernel"):
+        fam = lambda k: k.startswith("conv_wino2h_kernel")
+    elif dom_kernel_name.startswith("conv_wino3_kernel"):
+        fam = lambda k: k.startswith("conv_wino3_kernel") or k.startswith("conv_wino3p_kernel")
+    else:
+        fam = lambda k: k.startswith("conv_wino_kernel") or k.startswith("wino_ksplit_reduce")
+    tot, n = {}, {}
+    for key, d, counter in (("fetch", fetch_dir, "FETCH_SIZE"), ("write", write_dir, "WRITE_SIZE")):
+        tot[key], n[key] = 0.0, 0
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == counter and fam(short(r["Kernel_Name"])):
+                    tot[key] += float(r["Counter_Value"]) * 1024.0           # rocprofv3 reports KiB
+                    n[key] += 1
+    if not n["fetch"] or not n["write"]:
+        return None
+    return dict(traffic_bytes_per_launch=2.0 * tot["fetch"] / n["fetch"] + tot["write"] / n["write"],
+                fetch_bytes_per_launch_corrected=2.0 * tot["fetch"] / n["fetch"], write_bytes_per_launch=tot["write"] / n["write"],
+                launches_fetch_pass=n["fetch"], launches_write_pass=n["write"])
+
+
 def traffic(out_json):
     """HBM-side bytes per conv launch of the Winograd kernel family from the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs,
     kernel-trace only), over the SAME population bench.py's `algorithmic_bytes_per_launch` averages: every Winograd-served 3x3 conv
