@@ -276,7 +276,7 @@ def pmc_traffic(args, roofline):
     if shutil.which("rocprofv3") is None:
         return dict(traffic_measured_in_run=False, traffic_note="--pmc-traffic: rocprofv3 not on PATH")
     base = tempfile.mkdtemp(prefix="mcvd_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
-    env = dict(os.environ, TMPDIR="/tmp", MCVD_BENCH_INNER="1")
+    env = dict(os.environ, TMPDIR="/tmp", MCVD_BENCH_INNER="1", MCVD_ALLOW_SHARED_DEVICE="1")      # this (idle) process holds the device lock
     inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", args.config, "--steps", "1", "--warmup", "0", "--subsample", "5",
              "--no-cpu-baseline", "--no-f16x2-leg", "--no-selfcheck", "--graph", "0", "--f16x2", str(args.f16x2)]
     if args.batch:
@@ -370,6 +370,10 @@ def main():
     autoreg = nfp > nfr
     n_blocks = -(-nfp // nfr)
     config.device = f"cuda:{local}"
+    if world > 1 and os.environ.get("MCVD_BENCH_SERIALIZE", "0") == "1":
+        # several ranks on ONE GPU taking turns (tests): the library refuses a second process on a device (one process per GPU, api.cpp)
+        # unless told that the sharing is deliberate
+        os.environ.setdefault("MCVD_ALLOW_SHARED_DEVICE", "1")
     net = HipScoreNet(config)
     sd = None
     if rank == 0:
@@ -378,6 +382,8 @@ def main():
     broadcast_weights(net, src=0)                    # ONE RCCL broadcast of the packed blob (no-op at N=1)
     net.set_option("profile", 1)
     net.set_option("graph", args.graph)
+    if world > 1 and os.environ.get("MCVD_BENCH_SERIALIZE", "0") == "1":
+        net.set_option("naive_attn", 4)      # a context that shares its device runs attention on the fp32 MFMA unless forced: every rank the same kernel
     for kv in os.environ.get("MCVD_BENCH_OPTS", "").split(","):      # diagnostics: context options, e.g. MCVD_BENCH_OPTS=conv_shape=10,naive_attn=2
         if kv:
             net.set_option(kv.split("=")[0], int(kv.split("=")[1]))

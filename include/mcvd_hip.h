@@ -85,7 +85,16 @@ typedef struct mcvd_unet_desc {
 #define MCVD_FLAG_GAMMA 8        /* gamma=True: step / re-noise draws are standardised gamma variates (:273-276, :319-322) */
 
 /* ---- context ---------------------------------------------------------------------- */
+/* One context per (device, stream); replaces the reference's implicit "current CUDA device + current stream" (op/upfirdn2d_kernel.cu:213-215).
+ * ONE PROCESS PER GPU is enforced: the first process to create a context on a device takes an advisory lock on it (a lock file keyed by
+ * the PCI bus id, released when the process exits); a second process gets MCVD_EBUSY -- kernels of two processes sharing the CUs of one
+ * MI355X corrupted each other's results (profiles/r04_two_process_corruption.txt).  MCVD_ALLOW_SHARED_DEVICE=1 in the second process's
+ * environment lets it in for callers that take turns on the device; such a context reports 1 from mcvd_ctx_device_shared and runs
+ * attention on the fp32 MFMA (the split-operand attention kernel was the aggressor in every observed corruption).  Several contexts
+ * of ONE process (one per stream) are allowed: measured clean, INTEGRATION.md section 4. */
+#define MCVD_EBUSY (-7)    /* mcvd_ctx_create: the device is held by another process of this library */
 int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out);
+int mcvd_ctx_device_shared(mcvd_ctx* ctx);
 void mcvd_ctx_destroy(mcvd_ctx* ctx);
 int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
 /* options (int values; an unknown key is MCVD_EINVAL):

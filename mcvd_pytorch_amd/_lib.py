@@ -35,6 +35,7 @@ _PROTOS = {
     "mcvd_last_error": (C.c_char_p, [_vp]),
     "mcvd_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
     "mcvd_ctx_destroy": (None, [_vp]),
+    "mcvd_ctx_device_shared": (_i, [_vp]),
     "mcvd_ctx_set_stream": (_i, [_vp, _vp]),
     "mcvd_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
     "mcvd_ctx_check_range": (_i, [_vp]),

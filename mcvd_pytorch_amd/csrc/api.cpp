@@ -1,12 +1,16 @@
 // extern "C" surface of libmcvd_hip.so (see include/mcvd_hip.h).  Nothing here throws.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <math.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -26,6 +30,87 @@ using namespace mcvd;
         return MCVD_EINVAL;                                   \
     }
 
+// ---- one process per GPU, enforced.  Kernels of two PROCESSES that share the CUs of one MI355X corrupted each other's results
+// (profiles/r04_two_process_corruption.txt: with attn_h2_kernel<3,3> of one process resident, 20-35 % of another process's elementwise
+// launches came back with 16 lanes of one VALU result wrong; cause below the ISA level, not identified).  The design never co-schedules
+// (DESIGN section 7), and this guard makes the unsupported configuration loud instead of silently wrong: every process that creates a
+// context on a device holds an advisory lock  <lock dir>/mcvd_hip_gpu_<pci bus id>.lock  (flock, released by the kernel when the process
+// exits, however it exits) for as long as it has a context there.  A second process is REFUSED (MCVD_EBUSY) unless MCVD_ALLOW_SHARED_DEVICE=1
+// is set in ITS environment at mcvd_ctx_create (tests that let ranks take turns on one device, profiler passes spawned by an idle parent);
+// with the override the context is marked shared and keeps the one kernel identified as the aggressor (the three-piece bf16 attention)
+// off the device -- attention then runs on the fp32 MFMA.  Best effort by construction: processes that do not see the same lock
+// directory (other containers, other users with a private /dev/shm) are not seen.
+namespace {
+std::mutex g_dev_mu;
+struct DevLock { int fd = -1; int refs = 0; bool exclusive = false; };
+DevLock g_dev_lock[64];
+std::vector<mcvd_ctx*> g_live_ctx[64];       // live contexts of THIS process per device (two streams of one process: see mcvd_ctx_shares_device)
+
+// returns 0 (this process holds the device alone), 1 (another process holds it; *we hold a shared lock*), < 0 error
+int device_lock_acquire(int device) {
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    if (device < 0 || device >= 64) return 0;
+    DevLock& L = g_dev_lock[device];
+    if (L.refs > 0) { ++L.refs; return L.exclusive ? 0 : 1; }
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) snprintf(bus, sizeof(bus), "dev%d", device);
+    for (char* c = bus; *c; ++c)
+        if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
+    const char* dirs[2] = {"/dev/shm", "/tmp"};
+    int fd = -1;
+    for (int i = 0; i < 2 && fd < 0; ++i) {
+        char path[256];
+        snprintf(path, sizeof(path), "%s/mcvd_hip_gpu_%s.lock", dirs[i], bus);
+        fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+    }
+    if (fd < 0) return 0;                                   // no lock directory: nothing to enforce with
+    L.fd = fd;
+    L.refs = 1;
+    if (flock(fd, LOCK_EX | LOCK_NB) == 0) { L.exclusive = true; return 0; }
+    L.exclusive = false;
+    (void)flock(fd, LOCK_SH | LOCK_NB);                     // a sharer: later arrivals still see the device as taken
+    return 1;
+}
+
+void device_lock_release(int device) {
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    if (device < 0 || device >= 64) return;
+    DevLock& L = g_dev_lock[device];
+    if (L.refs > 0 && --L.refs == 0) {
+        if (L.fd >= 0) close(L.fd);                         // drops the flock
+        L = DevLock{};
+    }
+}
+void ctx_register(mcvd_ctx* c) {
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    if (c->device < 0 || c->device >= 64) return;
+    for (mcvd_ctx* o : g_live_ctx[c->device]) ++o->epoch;      // their captured graphs embed an attention kernel chosen for a device of their own
+    g_live_ctx[c->device].push_back(c);
+}
+void ctx_unregister(mcvd_ctx* c) {
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    if (c->device < 0 || c->device >= 64) return;
+    auto& v = g_live_ctx[c->device];
+    v.erase(std::remove(v.begin(), v.end(), c), v.end());
+}
+}  // namespace
+
+// Does anything else run kernels on this context's device CONCURRENTLY with it?  Another process (the context was let in by
+// MCVD_ALLOW_SHARED_DEVICE=1), or another live context of this process bound to a DIFFERENT stream.  Round 5 measured the second case
+// (tools/diag_concurrent_streams.py, profiles/r05_two_stream_corruption.txt): two streams of ONE process corrupt each other exactly like two
+// processes do -- 55 % of the elementwise launches beside attn_h2_kernel<3,3> on the other stream came back with 16 lanes of one VALU
+// result wrong, none beside the fp32 attention kernel, none with the two sides on disjoint CU halves (HSA_CU_MASK).  Contexts that share
+// a stream are serialised by it and do not count.  The callers below keep the split-operand attention kernels off a shared device.
+bool mcvd_ctx_shares_device(const mcvd_ctx* c) {
+    if (!c) return false;
+    if (c->shared_device) return true;
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    if (c->device < 0 || c->device >= 64) return false;
+    for (const mcvd_ctx* o : g_live_ctx[c->device])
+        if (o != c && o->stream != c->stream) return true;
+    return false;
+}
+
 extern "C" {
 
 const char* mcvd_version(void) { return "mcvd_hip 0.1 (gfx950)"; }
@@ -43,8 +128,19 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     MCVD_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     MCVD_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "this library is built for gfx950 only; device %d is %s", device,
                  prop.gcnArchName);
+    const int taken = device_lock_acquire(device);
+    bool allow_shared = false;
+    if (const char* t = getenv("MCVD_ALLOW_SHARED_DEVICE")) allow_shared = atoi(t) != 0;
+    if (taken == 1 && !allow_shared) {
+        device_lock_release(device);
+        set_error("ctx_create: device %d is in use by ANOTHER PROCESS of this library.  One process per GPU is the supported configuration: "
+                  "co-resident kernels of two processes corrupted each other's results on MI355X (profiles/r04_two_process_corruption.txt).  "
+                  "Give each process its own GPU, or set MCVD_ALLOW_SHARED_DEVICE=1 if the processes take turns on the device", device);
+        return MCVD_EBUSY;
+    }
     mcvd_ctx* c = new mcvd_ctx();
     c->device = device;
+    c->shared_device = taken == 1 ? 1 : 0;
     c->stream = (hipStream_t)hip_stream;
     c->gn_inline_max_wg = 2 * prop.multiProcessorCount;
     if (const char* t = getenv("MCVD_AUTOTUNE")) c->autotune = atoi(t);
@@ -63,13 +159,18 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
         c->naive_conv = v & 1;
         c->naive_attn = (v >> 1) & 1;
     }
+    ctx_register(c);
     *out = c;
     return 0;
     API_CATCH
 }
 
+int mcvd_ctx_device_shared(mcvd_ctx* ctx) { return mcvd_ctx_shares_device(ctx) ? 1 : 0; }
+
 void mcvd_ctx_destroy(mcvd_ctx* ctx) {
     if (!ctx) return;
+    ctx_unregister(ctx);
+    device_lock_release(ctx->device);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->range_flag) (void)hipFree(ctx->range_flag);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
@@ -81,7 +182,12 @@ void mcvd_ctx_destroy(mcvd_ctx* ctx) {
 
 int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream) {
     MCVD_REQUIRE(ctx, "ctx is NULL");
-    ctx->stream = (hipStream_t)hip_stream;
+    if (ctx->stream != (hipStream_t)hip_stream) {
+        std::lock_guard<std::mutex> g(g_dev_mu);       // (mcvd_ctx_shares_device reads the streams of the device's live contexts)
+        ctx->stream = (hipStream_t)hip_stream;
+        if (ctx->device >= 0 && ctx->device < 64)
+            for (mcvd_ctx* o : g_live_ctx[ctx->device]) ++o->epoch;
+    }
     return 0;
 }
 
@@ -228,6 +334,8 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "gn_inline")) ctx->gn_inline = value;
     else if (!strcmp(key, "gn_inline_max_wg")) ctx->gn_inline_max_wg = value;
     else if (!strcmp(key, "spade_fuse")) ctx->spade_fuse = value;
+    else if (!strcmp(key, "spade_norm_fuse")) ctx->spade_norm_fuse = value;
+    else if (!strcmp(key, "spade_fuse_auto")) ctx->spade_fuse_auto = value;
     else {
         set_error("unknown option '%s'", key);
         return MCVD_EINVAL;
@@ -590,7 +698,7 @@ int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* co
     MCVD_REQUIRE(n == (int)m->ops.size(), "set_tuning: %d entries for a plan of %d ops (tuning of another model?)", n, (int)m->ops.size());
     for (int i = 0; i < n; ++i) {
         const bool conv = m->ops[i].kind == OP_CONV;
-        MCVD_REQUIRE(conv ? (shapes[i] >= -1 && shapes[i] <= 20 && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
+        MCVD_REQUIRE(conv ? (((shapes[i] >= -1 && shapes[i] <= 20) || shapes[i] == 36 || shapes[i] == 40) && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
                      "set_tuning: entry %d (shape %d, cout tile %d) does not fit op kind %d", i, shapes[i], cots[i], (int)m->ops[i].kind);
     }
     if (m->ctx) m->sync_tuning_options();         // the table belongs to the options in force now; a later option change drops it
@@ -1034,7 +1142,8 @@ int mcvd_op_gn_coef(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int
 
 int mcvd_op_attention(mcvd_ctx* ctx, const float* qkv, float* out, int B, int C, int heads, int HW) {
     MCVD_REQUIRE(ctx && qkv && out, "op_attention: NULL argument");
-    return launch_attention(ctx->naive_attn, ctx->f16x2, ctx->bf16x3, qkv, out, B, C, heads, HW, ctx->stream);
+    const bool shared = mcvd_ctx_shares_device(ctx);
+    return launch_attention(ctx->naive_attn, shared ? 0 : ctx->f16x2, shared ? 0 : ctx->bf16x3, qkv, out, B, C, heads, HW, ctx->stream);
 }
 
 int mcvd_op_fir2(mcvd_ctx* ctx, const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W) {

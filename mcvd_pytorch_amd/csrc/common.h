@@ -185,6 +185,12 @@ int launch_upfirdn2d(const float* in, const float* kernel_dev, int kh, int kw, i
                      float* out, int NC, int H, int W, int oh, int ow, hipStream_t s);
 int launch_spade_apply(const float* x0, int C0, const float* x1, int C1, const float* coef, const float* gb,
                        const float* coef2, float* y, int B, int HW, hipStream_t s);
+// GroupNorm finalize (from the producers' epilogue partials) + SPADE modulation + temb pair + SiLU in ONE launch: what gn_finalize +
+// spade_apply compute, bit for bit; coef_out (may be null) also receives the plain (A, B) table
+bool spade_norm_apply_supported(int C, int groups, int HW);
+int launch_spade_norm_apply(const float* x0, int C0, const float* x1, int C1, int groups, float eps, const float* st0, int np0,
+                            const float* st1, int np1, const float* gb, const float* coef2, float* y, float* coef_out, int B, int HW,
+                            hipStream_t s);
 int launch_coef2(const float* emb, int emb_stride, int emb_off, float* coef2, int B, int C, hipStream_t s);
 // all tables of a forward at once: desc_dev[3 t] = {arena offset per sample, emb_off, C} (device, int64); coef2 table t = arena + off * B
 int launch_coef2_all(const float* emb, int emb_stride, const long long* desc_dev, int ntab, int cmax, float* arena, int B, hipStream_t s);

@@ -641,6 +641,19 @@ int mcvd_model::launch_gn(const Op& op, const float* x, const void* lab, const f
     if (gn_deferred.size() != ops.size()) gn_deferred.assign(ops.size(), 0);
     gn_deferred[gi] = 0;
     if (ctx->gn_stats && np0 > 0 && np1 > 0) {
+        // a SPADE norm (mode 0) in front of a conv: the statistics are finalized INSIDE the kernel that modulates and activates the
+        // tensor (spade_norm_apply_kernel, launched by the conv op) -- no gn_finalize launch.  The conv op falls back to ensure_coef
+        // if it ends up on the fused Winograd loader, which reads the table.
+        if (may_defer && ctx->spade_norm_fuse && op.gn_mode == 0 && spade_norm_apply_supported(a.C0 + a.C1, op.groups, a.HW)) {
+            for (size_t ci = gi + 1; ci < ops.size(); ++ci)
+                if (ops[ci].gn_src == (int)gi) {
+                    if (ops[ci].kind == OP_CONV && ops[ci].gb.kind != REF_NONE) {
+                        gn_deferred[gi] = 2;
+                        return 0;
+                    }
+                    break;
+                }
+        }
         if (may_defer && ctx->gn_inline && np0 <= GN_INLINE_MAX_NP && np1 <= GN_INLINE_MAX_NP) {
             bool has_consumer = false;
             for (size_t ci = gi + 1; ci < ops.size() && !has_consumer; ++ci) has_consumer = ops[ci].gn_src == (int)gi;
@@ -658,7 +671,7 @@ int mcvd_model::launch_gn(const Op& op, const float* x, const void* lab, const f
 
 int mcvd_model::ensure_coef(int gn_index, const float* x, const void* lab, const float* cond, float* out, int B) {
     if (gn_index < 0 || (size_t)gn_index >= gn_deferred.size() || !gn_deferred[gn_index]) return 0;
-    --gn_inlined_total;
+    if (gn_deferred[gn_index] == 1) --gn_inlined_total;
     return launch_gn(ops[gn_index], x, lab, cond, out, B, false);       // (clears the flag)
 }
 
@@ -734,23 +747,42 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             }
             // epilogue statistics from the 3x3 (Winograd) producers; the 1x1 GEMM's epilogue can emit them too, but its 16*COT
             // 32-lane reductions per wave cost the NIN_3 launches more than the norms they spare save (measured): "gn_stats" = 2 only
-            if (op.gb.kind != REF_NONE && op.gn_src >= 0)       // SPADE: spade_apply / the fused loader read the table
-                if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
             if (op.gb.kind != REF_NONE) {
                 // SPADE norm in front of this conv: fused into the Winograd loader where that kernel takes the launch, otherwise
                 // spade_apply materialises silu(((A x + B)(1 + gamma) + beta) s1 + b2) and the conv reads it plainly
                 a.gb = resolve(op.gb, x, cond, out, B);
                 a.coef2 = op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B);
+                // shape ids 36 / 40 (= 32 + 4 / 8; tables only): THIS layer takes the SPADE modulation inside the fp32 Winograd loader -- the
+                // autotuner measured [gn_finalize + fused conv] against [spade_norm_apply + the best plain conv] and the fused form won
+                const bool table_fused = a.shape_hint == 36 || a.shape_hint == 40;
+                if (table_fused) a.shape_hint -= 32;
+                const bool want_fused = (ctx->spade_fuse || table_fused) && !ctx->naive_conv && ctx->winograd;
                 ConvArgs t = a;
                 t.shape_hint = (a.shape_hint == 8) ? 8 : 4;
                 t.ksplit = t.shape_hint == 8 ? 2 : 0;
-                bool fused = ctx->spade_fuse && !ctx->naive_conv && ctx->winograd && conv_wino_usable(t);
-                if (!fused && t.ksplit == 2) { t.ksplit = 0; t.shape_hint = 4; fused = ctx->spade_fuse && !ctx->naive_conv && ctx->winograd && conv_wino_usable(t); }
+                bool fused = want_fused && conv_wino_usable(t);
+                if (!fused && t.ksplit == 2) { t.ksplit = 0; t.shape_hint = 4; fused = want_fused && conv_wino_usable(t); }
+                if (table_fused && !fused) a.shape_hint = -1;        // (a table of another build: the dispatcher's own choice)
                 if (fused) {
+                    if (op.gn_src >= 0)                         // the fused loader reads the (A, B) table
+                        if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
                     a.shape_hint = t.shape_hint;
                 } else {
                     float* tmp = resolve(op.tmp, x, cond, out, B);
-                    if (int rc = launch_spade_apply(a.x0, a.C0, a.x1, a.C1, a.coef, a.gb, a.coef2, tmp, B, op.H * op.W, s)) return rc;
+                    if (op.gn_src >= 0 && gn_deferred[op.gn_src] == 2) {
+                        // normalisation statistics + SPADE modulation + temb pair + SiLU in one launch (kernels/fir.cpp)
+                        const Op& g = ops[op.gn_src];
+                        gn_deferred[op.gn_src] = 0;
+                        const int np0 = stats_np[g.prod0], np1 = a.C1 ? stats_np[g.prod1] : 1;
+                        if (int rc = launch_spade_norm_apply(a.x0, a.C0, a.x1, a.C1, g.groups, g.eps, resolve(ops[g.prod0].stats, x, cond, out, B), np0,
+                                                             a.C1 ? resolve(ops[g.prod1].stats, x, cond, out, B) : nullptr, np1, a.gb, a.coef2, tmp,
+                                                             nullptr, B, op.H * op.W, s))
+                            return rc;
+                    } else {
+                        if (op.gn_src >= 0)
+                            if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
+                        if (int rc = launch_spade_apply(a.x0, a.C0, a.x1, a.C1, a.coef, a.gb, a.coef2, tmp, B, op.H * op.W, s)) return rc;
+                    }
                     a.x0 = tmp; a.x1 = nullptr; a.C0 = a.Cin; a.C1 = 0; a.coef = nullptr; a.act = 0; a.gb = nullptr; a.coef2 = nullptr;
                 }
             }
@@ -858,8 +890,13 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                                       op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B),
                                       resolve(op.dst, x, cond, out, B), B, op.H * op.W, s);
         case OP_ATTN:
-            return launch_attention(ctx->naive_attn, ctx->f16x2, ctx->bf16x3, resolve(op.src0, x, cond, out, B), resolve(op.dst, x, cond, out, B), B,
+        {
+            // (a context that shares its device -- another process, or another stream of this one -- keeps the split-operand attention
+            // kernels off it: api.cpp, mcvd_ctx_shares_device)
+            const bool shared = mcvd_ctx_shares_device(ctx);
+            return launch_attention(ctx->naive_attn, shared ? 0 : ctx->f16x2, shared ? 0 : ctx->bf16x3, resolve(op.src0, x, cond, out, B), resolve(op.dst, x, cond, out, B), B,
                                     op.Cout, op.heads, op.H * op.W, s);
+        }
         default:
             set_error("forward: unknown op kind %d", (int)op.kind);
             return -1;
@@ -1022,6 +1059,61 @@ int mcvd_model::autotune(int B) {
                         if (int rc = time_candidate(9, 2)) return rc;
                 }
             }
+            // SPADE norm in front of this conv: the modulation inside the fp32 Winograd loader (gamma | beta by LDS-DMA, conv_wino.cpp PRO 3)
+            // against the materialising path, measured as what each really costs per norm:
+            //     fused:   gn_finalize  +  conv_wino_kernel<PRO 3> (fp32 MFMA)          plain:  spade_norm_apply  +  the best plain conv (bf16x3 ...)
+            // Shape ids 36 / 40 (32 + 4 / 8) mark the layers where the fused form wins.  Offered by default (option "spade_fuse_auto").
+            if (op.gb.kind != REF_NONE && !spade_fused && ctx->spade_fuse_auto && ctx->winograd && op.ks == 3 && op.gn_src >= 0 && choice.first >= 0 &&
+                ops[op.gn_src].prod0 >= 0 && (op.src1.kind == REF_NONE || ops[op.gn_src].prod1 >= 0)) {
+                const Op& g = ops[op.gn_src];
+                ConvArgs f = a;                                   // the conv as the fused loader sees it: raw sources + tables + maps
+                f.x0 = resolve(op.src0, scratch_io, scratch_io, scratch_io, B);
+                f.x1 = resolve(op.src1, scratch_io, scratch_io, scratch_io, B);
+                f.C0 = op.src0.C; f.C1 = op.src1.kind == REF_NONE ? 0 : op.src1.C;
+                f.coef = resolve(op.coef, scratch_io, scratch_io, scratch_io, B);
+                f.act = op.act;
+                f.gb = resolve(op.gb, scratch_io, scratch_io, scratch_io, B);
+                f.coef2 = op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, scratch_io, scratch_io, scratch_io, B);
+                f.cot = op.cot;
+                GnArgs ga{};
+                ga.C0 = f.C0; ga.C1 = f.C1; ga.groups = g.groups; ga.eps = g.eps; ga.mode = 0; ga.coef = const_cast<float*>(f.coef); ga.B = B; ga.HW = op.H * op.W;
+                const int HW = op.H * op.W;
+                const int np = std::max(1, HW / 128);             // what the Winograd producers emit (one partial per 8 x 16 region)
+                const float* st0 = resolve(ops[g.prod0].stats, scratch_io, scratch_io, scratch_io, B);
+                const float* st1 = f.C1 ? resolve(ops[g.prod1].stats, scratch_io, scratch_io, scratch_io, B) : nullptr;
+                float* tmp = resolve(op.tmp, scratch_io, scratch_io, scratch_io, B);
+                auto time_seq = [&](auto&& fn, float* ms_out) -> int {
+                    if (int rc = fn()) return rc;                                  // warm-up
+                    MCVD_HIP_CHECK(hipEventRecord(e0, s));
+                    for (int r = 0; r < 3; ++r)
+                        if (int rc = fn()) return rc;
+                    MCVD_HIP_CHECK(hipEventRecord(e1, s));
+                    MCVD_HIP_CHECK(hipEventSynchronize(e1));
+                    MCVD_HIP_CHECK(hipEventElapsedTime(ms_out, e0, e1));
+                    return 0;
+                };
+                if (spade_norm_apply_supported(cin, g.groups, HW)) {
+                    ConvArgs pa = a;                              // the plain winner
+                    pa.shape_hint = choice.first; pa.cot = choice.second;
+                    float ms_plain = 1e30f;
+                    if (int rc = time_seq([&]() -> int {
+                            if (int r2 = launch_spade_norm_apply(f.x0, f.C0, f.x1, f.C1, g.groups, g.eps, st0, np, st1, np, f.gb, f.coef2, tmp, nullptr, B, HW, s)) return r2;
+                            return launch_conv_mfma(pa, s);
+                        }, &ms_plain)) return rc;
+                    for (int shape : {4, 8}) {
+                        ConvArgs t = f;
+                        t.shape_hint = shape; t.ksplit = shape == 8 ? 2 : 0;
+                        if (!conv_wino_usable(t)) continue;
+                        float ms_fused = 1e30f;
+                        if (int rc = time_seq([&]() -> int {
+                                if (int r2 = launch_gn_finalize(ga, st0, np, st1, np, s)) return r2;
+                                ConvArgs u = f; u.shape_hint = shape;
+                                return launch_conv_mfma(u, s);
+                            }, &ms_fused)) return rc;
+                        if (ms_fused < ms_plain) { ms_plain = ms_fused; choice = {32 + shape, op.cot}; }
+                    }
+                }
+            }
             it = best.emplace(k, choice).first;
         }
         tuned_shape[i] = it->second.first;
@@ -1039,7 +1131,7 @@ int mcvd_model::autotune(int B) {
 // (mcvd_model_set_tuning stamps its table with the options in force at the import).
 void mcvd_model::sync_tuning_options() {
     const int sig = (ctx->winograd ? 1 : 0) | (ctx->conv_dma1 ? 2 : 0) | (ctx->bf16x3 ? 4 : 0) | (ctx->f16x2 ? 8 : 0) |
-                    (ctx->spade_fuse ? 16 : 0) | (ctx->conv_wdma ? 32 : 0);
+                    (ctx->spade_fuse ? 16 : 0) | (ctx->conv_wdma ? 32 : 0) | (ctx->spade_fuse_auto ? 64 : 0);
     if (sig != tuned_sig) {
         if (tuned_sig >= 0) { tuned_cache.clear(); tuned_B = 0; }
         tuned_sig = sig;

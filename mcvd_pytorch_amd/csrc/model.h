@@ -9,6 +9,8 @@
 
 struct mcvd_ctx {
     int device = 0;
+    int shared_device = 0;         // 1: another PROCESS held a context on this device when this one was created and MCVD_ALLOW_SHARED_DEVICE=1
+                                   //    let it in (api.cpp: device lock): the three-piece bf16 attention kernel stays off the device
     hipStream_t stream = nullptr;
     int naive_conv = 0;
     int naive_attn = 0;
@@ -37,6 +39,10 @@ struct mcvd_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int spade_fuse = 0;            // 1: SPADE modulation inside the Winograd conv loader (gamma | beta by LDS-DMA); 0: through spade_apply.
                                    //    Off by default: measured 3.5 % SLOWER end to end (profiles/r02_spade_fusion_ab.txt)
+    int spade_fuse_auto = 1;       // offer the fused SPADE loader to the autotuner PER LAYER (shape ids 36 / 40): it takes the layers where
+                                   //    [gn_finalize + fused fp32 Winograd conv] beats [spade_norm_apply + the best plain conv] in its own timing
+    int spade_norm_fuse = 1;       // SPADE norms in front of a conv: GroupNorm finalize + modulation + temb pair + SiLU in ONE launch
+                                   //    (spade_norm_apply_kernel) instead of gn_finalize + spade_apply; 0: the two launches (bit-identical results)
     int gn_stats = 1;              // GroupNorm statistics from the producing conv's epilogue (0: always one pass over the tensor)
     int gn_inline = 0;             // 1: a conv whose kernel can (conv_takes_gn_inline) reduces those partial statistics itself where a channel has
                                    //    at most GN_INLINE_MAX_NP of them: no gn_finalize launch for that norm (kernels/gn_inline.h).  Off by default:
@@ -53,6 +59,8 @@ struct mcvd_ctx {
     size_t scratch_bytes = 0;
     int ensure_scratch(size_t bytes);
 };
+
+bool mcvd_ctx_shares_device(const mcvd_ctx* c);     // api.cpp: another process, or another stream of this process, runs on the context's device
 
 namespace mcvd {
 

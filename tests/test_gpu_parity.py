@@ -1431,6 +1431,80 @@ def test_two_contexts_large_lds_kernels():
         _close(res[n][1], want1, what=f"ctx {n} 1x1 dma")
 
 
+def test_second_process_on_the_device_is_refused(ctx):
+    """One process per GPU, enforced: kernels of two processes co-resident on one MI355X corrupted each
+    other's results (profiles/r04_two_process_corruption.txt), so a second process that asks for a context on a device this process
+    holds gets MCVD_EBUSY -- loud, not silently wrong.  With MCVD_ALLOW_SHARED_DEVICE=1 (callers that take turns) it is let in, marked
+    shared, and its attention runs on the fp32 MFMA kernel (the split-operand attention kernel was the aggressor every time)."""
+    import subprocess
+    import sys
+    from mcvd_pytorch_amd import _lib
+    assert _lib.lib.mcvd_ctx_device_shared(ctx.h) == 0                      # this process came first
+    code = ("import ctypes as C, torch\n"
+            "from mcvd_pytorch_amd import _lib\n"
+            "h = C.c_void_p()\n"
+            "rc = _lib.lib.mcvd_ctx_create(0, None, C.byref(h))\n"
+            "print('rc', rc, 'shared', _lib.lib.mcvd_ctx_device_shared(h) if rc == 0 else -1, '|', _lib.last_error()[:80])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    env.pop("MCVD_ALLOW_SHARED_DEVICE", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rc -7 shared -1" in r.stdout and "ANOTHER PROCESS" in r.stdout, (r.stdout, r.stderr[-500:])
+    env["MCVD_ALLOW_SHARED_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rc 0 shared 1" in r.stdout, (r.stdout, r.stderr[-500:])
+
+
+def test_two_streams_of_one_process_are_fenced(ctx):
+    """Two contexts of ONE process on different streams overlap on the CUs like two processes do -- and corrupt each other the same way
+    (profiles/r05_two_stream_corruption.txt: 55 % of the elementwise launches beside attn_h2_kernel<3,3> on the other stream wrong, none
+    beside the fp32 attention kernel).  SURVEY 8b allows one context per stream, so the library fences it: while another live context of
+    the process is bound to a different stream, both report `mcvd_ctx_device_shared` and their attention runs on the fp32 MFMA kernel;
+    contexts on the SAME stream are serialised by it and stay on the default kernels.  Then the measurement itself, short: an
+    elementwise victim on one stream beside attention on the other, every launch bit-equal to its reference."""
+    import threading
+    from mcvd_pytorch_amd import _lib
+    from tests.hiputil import Ctx
+    same = Ctx()                                                    # same (current) stream as `ctx`
+    assert _lib.lib.mcvd_ctx_device_shared(ctx.h) == 0 and _lib.lib.mcvd_ctx_device_shared(same.h) == 0
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        c2 = Ctx()
+    assert _lib.lib.mcvd_ctx_device_shared(ctx.h) == 1 and _lib.lib.mcvd_ctx_device_shared(c2.h) == 1
+    g = _g(9)
+    xf = torch.randn(3, 192, 32, 32, generator=g).cuda()
+    coeff = torch.stack([1 + 0.3 * torch.randn(3, 192, generator=g), 0.3 * torch.randn(3, 192, generator=g)], dim=-1).cuda()
+    qkv = torch.randn(3, 3 * 2 * 96, 1024, generator=g).cuda()
+    ref = ctx.fir2(xf, 1, coef=coeff, act=1).clone()
+    want_attn = c2.attention(qkv, 2).clone()
+    torch.cuda.synchronize()
+    stop = threading.Event()
+
+    def aggressor():
+        with torch.cuda.stream(s2):
+            while not stop.is_set():
+                for _ in range(32):
+                    out = c2.attention(qkv, 2)                      # auto mode: fenced to the fp32 kernel while the device is shared
+                s2.synchronize()
+            assert torch.equal(out, want_attn)
+    th = threading.Thread(target=aggressor)
+    th.start()
+    bad = n = 0
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 2.0:
+        bad += not torch.equal(ctx.fir2(xf, 1, coef=coeff, act=1), ref)
+        n += 1
+    stop.set()
+    th.join()
+    assert n > 1000 and bad == 0, f"{bad} of {n} victim launches differ beside the fenced attention"
+    del c2
+    assert _lib.lib.mcvd_ctx_device_shared(ctx.h) == 0               # the fence lifts with the second stream's context
+    # (same arithmetic contract either way: the fp32 kernel against the split-operand one)
+    got = ctx.attention(qkv, 2)
+    assert (got - want_attn).abs().max().item() <= 2e-5 * want_attn.abs().max().item()
+
+
 def test_sampler_rejects_bad_shapes():
     """The device loop hands raw pointers to the library: wrong-shaped x / cond / too-short injected noise must raise, not read
     out of bounds."""
@@ -1692,7 +1766,7 @@ def test_direct_rccl_weight_broadcast_two_ranks(tmp_path):
     import sys
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MCVD_ALLOW_SHARED_DEVICE="1")      # device 0 is held by this (idle) pytest process
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_bcast_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(tmp_path)], env=env) for r in range(2)]
     for p in procs:
@@ -1707,7 +1781,9 @@ def _bench_job(tmp_path, tag, gpus, batch, backend=None, tune_cache=None, save_t
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # the children create contexts on a device this (idle) pytest process holds: let them in, and pin the attention kernel, which a context
+    # that shares its device would otherwise swap for the fp32 one (api.cpp: device lock) -- the jobs compared here must run ONE kernel set
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MCVD_ALLOW_SHARED_DEVICE="1", MCVD_BENCH_OPTS="naive_attn=4")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     if backend:

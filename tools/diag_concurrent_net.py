@@ -1,6 +1,7 @@
 """Whole-net bit-determinism while another process runs the same net on the same GPU: on a mismatch, the first module whose output
 differs from the reference run.  usage: diag_concurrent_net.py [worker TAG];  env OPTS=conv_shape=10,... NPROC=2 SECS=8"""
 import os, sys, subprocess, time
+os.environ.setdefault("MCVD_ALLOW_SHARED_DEVICE", "1")     # this tool puts two processes on one device ON PURPOSE (api.cpp: device lock)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 

@@ -1,6 +1,7 @@
 """Bit-determinism of single ops while ANOTHER process keeps the same GPU busy (two processes on one device: their workgroups share CUs,
 which a single-stream process never sees).  usage: diag_concurrent_ops.py [worker TAG]  -- without arguments starts two workers."""
 import os, sys, subprocess, time
+os.environ.setdefault("MCVD_ALLOW_SHARED_DEVICE", "1")     # this tool puts two processes on one device ON PURPOSE (api.cpp: device lock)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
