@@ -142,9 +142,18 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         graph, the redundant reduction in every workgroup does not -- measured 0.3-1 % slower on every config
  *         (profiles/r03_gn_inline_ab.txt).  "spade_fuse" (0): 1 = the SPADE modulation inside the fp32 Winograd conv loader (gamma | beta by
  *         LDS-DMA; measured 3.5 % slower end to end than the materialising spade_apply kernel).  "side_stream" (0): ResBlock shortcut
- *         convs on a second HIP stream (measured slower).  "profile" (0/1): see mcvd_model_profile_read.
+ *         convs on a second HIP stream (measured slower; UNSAFE beside the split-operand attention kernel: INTEGRATION.md section 4).
+ *         "spade_norm_fuse" (0): 1 = a SPADE norm in front of a conv is ONE launch -- GroupNorm finalize from the producers' epilogue partials +
+ *         (1 + gamma) / beta modulation + temb pair + SiLU (spade_norm_apply_kernel; layerspp.py:152-173, :530-535) -- instead of
+ *         gn_finalize + spade_apply; bit-identical; measured -1 ... +0.7 % end to end on config 4 (profiles/r05_spade_fusion_ab.txt): off.  "spade_fuse_auto" (1): the autotuner also times, per SPADE-normed 3x3 layer,
+ *         [gn_finalize + conv with the modulation in its fp32 Winograd loader] against [spade_norm_apply + the best plain conv] and marks the
+ *         layers where the fused loader wins with shape ids 36 / 40 (= 32 + 4 / 8).  "attn_presplit" (1): the fused q|k|v projection
+ *         writes K and V already split into the three bf16 pieces, in the LDS-image order of the attention kernel, which then stages its
+ *         tiles by LDS-DMA (head dims 32 / 64 / 96, default arithmetic, a device of its own); bit-identical to 0 (the attention kernel splits
+ *         K / V itself, once per query tile).  "profile" (0/1): see mcvd_model_profile_read.
  * Environment variables read ONCE at mcvd_ctx_create set the same options: MCVD_AUTOTUNE, MCVD_SIDE_STREAM, MCVD_WINOGRAD, MCVD_CONV_DMA1, MCVD_GN_INLINE,
- * MCVD_BF16X3, MCVD_F16X2, MCVD_GRAPH, MCVD_GN_STATS, MCVD_SPADE_FUSE, MCVD_NAIVE.  Nothing else in the production library reads the
+ * MCVD_BF16X3, MCVD_F16X2, MCVD_GRAPH, MCVD_GN_STATS, MCVD_SPADE_FUSE, MCVD_NAIVE; MCVD_ALLOW_SHARED_DEVICE (see mcvd_ctx_create) is read there
+ * too.  Nothing else in the production library reads the
  * environment (the diagnostics build, csrc/build.py --diag, adds timing-only ablation hooks). */
 int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value);
 /* Option "f16x2" only (the default three-piece bf16 arithmetic has the fp32 range and needs no guard): every UNet forward run while the
@@ -265,6 +274,11 @@ int mcvd_model_op_kernel(mcvd_model* m, int i);
  * forwards and graph captures of the model (a graph replay re-runs what its capture recorded).  Tests use it to assert that the
  * fused path really ran; -1 for a NULL model. */
 long mcvd_model_gn_inlined(mcvd_model* m);
+/* Launch counters of the fused forms that have no reference counterpart (diagnostics / tests), cumulative over the model's forwards:
+ * what = 0: attention blocks whose K and V went from the q|k|v projection to the attention kernel pre-split (option "attn_presplit",
+ * layerspp.py:236-245 computes the same products on fp32 rows); 1: SPADE norms finalized inside the modulating kernel (option
+ * "spade_norm_fuse", layerspp.py:152-173); 2: convs that took the SPADE modulation inside their loader (shape ids 36 / 40 or "spade_fuse"). */
+long mcvd_model_fused_launches(mcvd_model* m, int what);
 
 /* Debug/test aid: copy the output tensor of reference module `module` (index in all_modules, ncsnpp_more.py:249) from the
  * last forward at batch size B into dst_device ([B, C, H, H], capacity in floats).  The workspace keeps every intermediate of a

@@ -335,6 +335,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "gn_inline_max_wg")) ctx->gn_inline_max_wg = value;
     else if (!strcmp(key, "spade_fuse")) ctx->spade_fuse = value;
     else if (!strcmp(key, "spade_norm_fuse")) ctx->spade_norm_fuse = value;
+    else if (!strcmp(key, "attn_presplit")) ctx->attn_presplit = value;
     else if (!strcmp(key, "spade_fuse_auto")) ctx->spade_fuse_auto = value;
     else {
         set_error("unknown option '%s'", key);
@@ -698,7 +699,7 @@ int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* co
     MCVD_REQUIRE(n == (int)m->ops.size(), "set_tuning: %d entries for a plan of %d ops (tuning of another model?)", n, (int)m->ops.size());
     for (int i = 0; i < n; ++i) {
         const bool conv = m->ops[i].kind == OP_CONV;
-        MCVD_REQUIRE(conv ? (((shapes[i] >= -1 && shapes[i] <= 20) || shapes[i] == 36 || shapes[i] == 40) && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
+        MCVD_REQUIRE(conv ? (((shapes[i] >= -1 && shapes[i] <= 21) || shapes[i] == 36 || shapes[i] == 40) && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
                      "set_tuning: entry %d (shape %d, cout tile %d) does not fit op kind %d", i, shapes[i], cots[i], (int)m->ops[i].kind);
     }
     if (m->ctx) m->sync_tuning_options();         // the table belongs to the options in force now; a later option change drops it
@@ -787,6 +788,7 @@ int mcvd_model_op_kernel(mcvd_model* m, int i) {
 }
 
 long mcvd_model_gn_inlined(mcvd_model* m) { return m ? m->gn_inlined_total : -1; }
+long mcvd_model_fused_launches(mcvd_model* m, int what) { return (m && what >= 0 && what < 3) ? m->fused_launches[what] : -1; }
 
 int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst, int64_t capacity, int* C, int* H) {
     MCVD_REQUIRE(m && dst && B > 0 && B <= m->arena_B, "module_output: run a forward at batch >= B first");

@@ -98,7 +98,12 @@ struct ConvArgs {
     // replaces `coef` (which must still be non-null: it selects the affine prologue).  Only the launches conv_takes_gn_inline()
     // accepts (the three-piece bf16 Winograd and 1x1 kernels) may carry it.
     GnInline gni;
+    // q|k|v projection of an attention block (conv1x1_h2.cpp, KV): when non-null the K and V thirds of the output are written HERE as
+    // three-piece bf16 LDS images per (sample, head, key tile) instead of as fp32 rows of y: 3 * kv_C * HW dwords per sample
+    float* kv_img;
+    int kv_C, kv_D;       // channels of one of q / k / v; head dim
 };
+bool conv1x1_h2_kv_supported(const ConvArgs& a, int cot);
 bool conv_takes_gn_inline(const ConvArgs& a, int max_wg);   // the kernel launch_conv_mfma(a) dispatches to reduces the partials itself (and has <= max_wg workgroups)
 void set_last_conv_stats_np(int np);          // (launchers)
 int last_conv_stats_np();                     // partials per (sample, channel) the thread's last conv launch wrote to a.stats; 0 = none
@@ -107,6 +112,9 @@ int conv_chunk(int ks);                       // input-channel chunk the MFMA ke
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 int launch_conv_naive(const ConvArgs& a, hipStream_t s);
 int last_conv_kernel();                       // kernel family of this thread's last launch_conv_mfma (see conv.cpp)
+// fp32 VALU direct conv for layers with at most 16 output channels (the network's last conv; conv_small_cout.cpp): tile shape id 21
+bool conv_small_cout_usable(const ConvArgs& a);
+int launch_conv_small_cout(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2,3x3) kernel (conv_wino.cpp): tile shape id 4 of the dispatcher
 bool conv_wino_supported(int ks, int H, int W);      // geometry only (decides whether transformed weights are packed at all)
 int conv_wino_cout_tile(int Cout);
@@ -174,6 +182,10 @@ int launch_attention_naive(const float* qkv, float* out, int B, int C, int heads
 // two fp16 pieces): head dim 32..128 in steps of 32, HW % 32 == 0
 bool attention_h2_supported(int C, int heads, int HW);
 int launch_attention_h2(const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s, int np);
+// the same kernel (np = 3) fed with K and V ALREADY SPLIT by the q|k|v projection's epilogue (ConvArgs::kv_img): the tiles reach the LDS by
+// LDS-DMA, no VALU instruction touches them; head dims 32 / 64 / 96.  Bit-identical to launch_attention_h2(.., 3).
+bool attn_h2p_supported(int C, int heads, int HW);
+int launch_attention_h2p(const float* qkv, const float* kv_img, float* out, int B, int C, int heads, int HW, hipStream_t s);
 // which attention kernel a launch takes: mode = the "naive_attn" option (0 auto: the fp16-pipe kernel when f16x2 is on and it applies,
 // else the fp32 flash kernel; 1 the one-thread-per-query kernel; 2 the fp32 flash kernel; 3 the fp16-pipe kernel where it applies)
 int launch_attention(int mode, int f16x2, int bf16x3, const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);

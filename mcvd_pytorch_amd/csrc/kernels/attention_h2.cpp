@@ -230,6 +230,195 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
     }
 }
 
+// ---- the NP = 3 kernel fed with PRE-SPLIT K and V (round 5).  attn_h2_kernel<3, *> fetches a K / V tile through
+// registers, splits every element three ways and parks the pieces -- once per QUERY TILE, eight times per element at 32 x 32, 126 of the
+// 367 VALU instructions a wave issues per key tile -- and prefetches the next tile in 28 registers.  Here the q|k|v projection has
+// already written the pieces (conv1x1_h2.cpp, KV): per (sample, head, key tile) ONE contiguous image
+//     [K: step][piece][dword j][64 lanes]  [V: sub-tile][step s2][piece][64 lanes][4 dwords]            3072 DT dwords = 12 KB x DT
+// in exactly the order the two products read their operands from the LDS, so a tile reaches the LDS by LDS-DMA (16 bytes per lane, no
+// VALU instruction, no register) into one of TWO buffers: the DMA of tile t + 1 is issued behind the barrier that publishes tile t and
+// lands under that tile's products; one barrier per tile instead of two.  Same pieces, same products in the same order: the output is
+// bit-identical to attn_h2_kernel<3, DT>.  Head dims 32 / 64 / 96 (two 24 KB x DT buffers, two workgroups per CU).
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attn_h2p_kernel(const float* __restrict__ qkv, const unsigned* __restrict__ kv_img, float* __restrict__ out,
+                                                           int C, int heads, int S, float scale_s, int nbh, int nqt) {
+    typedef Pieces<3> PX;
+    constexpr int NP = 3, D = 32 * DT, NST = D / 16;
+    constexpr int IMG = 3072 * DT;                  // dwords of one (K | V) tile image
+    constexpr int NPC = IMG / 4;                    // its 16-byte pieces: 768 DT
+    constexpr int NR = (NPC + 255) / 256;           // DMA rounds per thread and tile
+    static_assert(NPC % 64 == 0, "a wave's 64 pieces are all inside the image or all outside");
+    extern __shared__ __attribute__((aligned(16))) float smem_attn_h2p[];
+    unsigned* sT = reinterpret_cast<unsigned*>(smem_attn_h2p);      // [2][IMG]: K image at 0, V image at 1536 DT
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bh = (slot / nqt) * 8 + xcd, qt = slot - (slot / nqt) * nqt;
+    if (bh >= nbh) return;
+    const int b = bh / heads, hd = bh - b * heads;
+    const float* qb = qkv + ((long)b * 3 * C + hd * D) * S;
+    const int q0 = qt * 128 + wave * 32;
+    const bool active = q0 < S;
+    const int ntiles = S / 32;
+    const unsigned* ib = kv_img + (long)bh * ntiles * IMG;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    auto dma = [&](int t) {
+        const unsigned* src = ib + (long)t * IMG;
+        unsigned* dst = sT + (t & 1) * IMG;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int q0p = r * 256 + wave_u * 64;                  // the wave's first piece of this round (wave-uniform)
+            if ((r + 1) * 256 <= NPC || q0p < NPC)                  // (only a ragged last round is predicated)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (q0p + lane) * 4),
+                                                 (__attribute__((address_space(3))) void*)(dst + q0p * 4), 16, 0, 0);
+        }
+    };
+    dma(0);
+
+    u32x4 qp[NST][NP];
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c0 = 16 * st + 4 * j + half;
+            const float a0 = active ? qb[(long)c0 * S + q0 + l31] : 0.0f;
+            const float a1 = active ? qb[(long)(c0 + 2) * S + q0 + l31] : 0.0f;
+            unsigned w[NP];
+            PX::template split<false>(a0, a1, w);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) qp[st][p][j] = w[p];
+        }
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.0f;
+    float m_run = -1e30f, l_run = 0.0f;
+
+    for (int t = 0; t < ntiles; ++t) {
+        // tile t has landed (the only VMEM operations in flight are its DMA pieces -- the Q loads were consumed above), every wave's part
+        // is visible behind the barrier, and every wave has finished tile t - 1: its buffer is free for tile t + 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < ntiles) dma(t + 1);
+        const unsigned* sK = sT + (t & 1) * IMG;
+        const unsigned* sV = sK + NST * NP * 256;
+
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+        const unsigned* sKl = sK + lane;
+#pragma unroll
+        for (int s = 0; s < NST; ++s) {
+            u32x4 kp[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kp[p][j] = sKl[((s * NP + p) * 4 + j) * 64];
+#pragma unroll
+            for (int k = 0; k < PX::NPROD; ++k) st = PX::mfma(kp[PX::PA(k)], qp[s][PX::PB(k)], st);
+        }
+
+        float mt = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] *= scale_s; mt = fmaxf(mt, st[r]); }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __expf(m_run - m_new);
+        const float shift = 0.0f - m_new;
+        float ps = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = __expf(st[r] + shift); ps += st[r]; }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        u32x4 pp[2][NP];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned w[NP];
+                PX::template split<false>(st[8 * s2 + 2 * j], st[8 * s2 + 2 * j + 1], w);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) pp[s2][p][j] = w[p];
+            }
+
+        const u32x4* sVl = reinterpret_cast<const u32x4*>(sV) + lane;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int c0 = 0; c0 < DT; c0 += 2) {
+                constexpr int G = 2;
+                u32x4 vp[G][NP];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (c0 + g < DT) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) vp[g][p] = sVl[(((c0 + g) * 2 + s2) * NP + p) * 64];
+                    }
+#pragma unroll
+                for (int k = 0; k < PX::NPROD; ++k)
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (c0 + g < DT) o[c0 + g] = PX::mfma(vp[g][PX::PA(k)], pp[s2][PX::PB(k)], o[c0 + g]);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (active) {
+        float* ob = out + ((long)b * C + hd * D) * S + q0 + l31;
+#pragma unroll
+        for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                ob[(long)c * S] = o[ct][r] * inv;
+            }
+    }
+}
+
+bool attn_h2p_supported(int C, int heads, int HW) {
+    if (heads <= 0 || C % heads != 0) return false;
+    const int D = C / heads;
+    return D % 32 == 0 && D >= 32 && D <= 96 && HW % 32 == 0;
+}
+
+int launch_attention_h2p(const float* qkv, const float* kv_img, float* out, int B, int C, int heads, int HW, hipStream_t s) {
+    MCVD_REQUIRE(attn_h2p_supported(C, heads, HW) && kv_img, "pre-split attention: unsupported (C=%d heads=%d HW=%d)", C, heads, HW);
+    const int D = C / heads;
+    const float scale_s = (float)pow((double)D, -0.5);
+    const int nqt = (HW + 127) / 128, nbh = B * heads;
+    dim3 grid((unsigned)(((nbh + 7) / 8) * 8 * nqt));
+    const size_t lds = (size_t)2 * 3072 * (D / 32) * sizeof(unsigned);
+    const unsigned* img = reinterpret_cast<const unsigned*>(kv_img);
+#define AHP_CASE(DT)                                                                                                      \
+    case DT: {                                                                                                            \
+        static PerDeviceOnce raised;                                                                                      \
+        if (lds > 48 * 1024 && raised.first_use()) {                                                                      \
+            MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_h2p_kernel<DT>),                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
+            raised.done();                                                                                                \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((attn_h2p_kernel<DT>), grid, dim3(256), lds, s, qkv, img, out, C, heads, HW, scale_s, nbh, nqt); \
+        break;                                                                                                            \
+    }
+    switch (D / 32) {
+        AHP_CASE(1) AHP_CASE(2) AHP_CASE(3)
+    }
+#undef AHP_CASE
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 bool attention_h2_supported(int C, int heads, int HW) {
     if (heads <= 0 || C % heads != 0) return false;
     const int D = C / heads;

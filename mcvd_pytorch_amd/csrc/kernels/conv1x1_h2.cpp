@@ -41,7 +41,12 @@ constexpr int Q1_MAXIMG = 4;     // images a pixel tile may span (HW >= 32)
 // PRO: 0 raw input, 1 affine, 2 affine + SiLU
 // EXP != 0 (built with -DMCVD_DIAG only; env MCVD_Q1_EXP): timing-only ablations of the K loop, wrong results: bit 0 no DMA behind the
 // first three chunks, bit 1 no MFMA, bit 2 no affine / SiLU / split, bit 3 no barrier; bit 4 (right results): the split is not pinned in front of the next barrier
-template <int NP, int COT, int PRO, int EXP = 0>
+// KV (NP = 3, PRO = 1: the fused q|k|v projection of an attention block, round 5): the K and V thirds of the output leave the kernel
+//     ALREADY SPLIT into the three bf16 pieces, as the LDS images attn_h2p_kernel (attention_h2.cpp) stages by LDS-DMA -- per (sample,
+//     head, key tile of 32 pixels) [K image: step][piece][dword j][64 lanes] [V image: sub-tile][step s2][piece][64 lanes][4 dwords] --
+//     instead of as fp32 rows (which nothing reads any more); the Q third is stored as before.  The attention kernel split every K / V
+//     element once per QUERY TILE (8 times at 32 x 32) and spent a third of its VALU instructions on it.
+template <int NP, int COT, int PRO, int EXP = 0, bool KV = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptiles, int nct) {
     typedef Pieces<NP> PX;
     constexpr int PT = Q1_PT, CK = Q1_CK, NB = Q1_NB, BCO = 32 * COT;
@@ -274,7 +279,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     // (profiles/r02_conv1x1_h2_timeline.txt).  The tile goes through the LDS instead ([cout][128 pixels], the K loop's buffers are
     // free) and leaves as global_store_dwordx4: four consecutive pixels per lane, 1 KiB contiguous per wave instruction.
     const float inv = NP == 2 ? a.wph[2] * (1.0f / PX::ACT_SCALE) : 1.0f;      // NP = 2: 1 / (weight scale * activation scale), a power of two
-    float* sO = smem;                                         // [BCO][PT]
+    float* sO = smem;                                         // [BCO][OPT]
+    constexpr int OPT = PT + 4;         // row pitch of the transposed tile: 132 = 4 (mod 64) dwords, so that the 16-byte reads of 16 DIFFERENT rows at
+                                        // one column (the V piece images below: a lane per channel) fall on 64 different banks; rows read along
+                                        // the pixels (the fp32 stores, the K images) are conflict-free at any pitch
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int px4 = tid & 31, cr = tid >> 5;                  // store role: 4 pixels px4*4 .. +3 of cout rows cr + 8*k
     const long gp = gp0 + px4 * 4;
@@ -299,13 +307,75 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     for (int ct = 0; ct < COT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            sO[(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PT + wave * 32 + l31] = acc[ct][r] * inv;
+            sO[(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * OPT + wave * 32 + l31] = acc[ct][r] * inv;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    bool kv_tile[COT];
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct) kv_tile[ct] = false;
+    if constexpr (KV) {
+        // sub-tile ct = couts co0 + 32 ct .. + 31 of [q | k | v] x [head][D]: K and V sub-tiles are written as piece images
+        const int Cq = a.kv_C, D = a.kv_D, DT = D >> 5, heads = Cq / D, ntl = HW >> 5;
+        unsigned* img = reinterpret_cast<unsigned*>(a.kv_img);
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) {
+            const int cs = co0 + ct * 32;
+            const int which = cs / Cq;                        // 0 q, 1 k, 2 v (>= 3: padding)
+            if (which != 1 && which != 2) continue;
+            kv_tile[ct] = true;
+            const int within = cs - which * Cq, head = within / D, ch0 = within - head * D;       // ch0: multiple of 32
+#pragma unroll
+            for (int rnd = 0; rnd < 2; ++rnd) {
+                const int item = rnd * 256 + tid;
+                if (which == 1) {
+                    // K: item = (row pair rp = (st_l, j, h), 4 pixels): channels c, c + 2 with c = ch0 + 16 st_l + 4 j + h
+                    const int rp = item >> 5, p4 = item & 31;
+                    const int st_l = rp >> 3, j = (rp >> 1) & 3, h = rp & 1;
+                    const int rl = ct * 32 + 16 * st_l + 4 * j + h;                                 // row of sO
+                    const long g = gp0 + p4 * 4;
+                    if (g < NPX) {
+                        const int bb = (int)(g / HW), pix = (int)(g - (long)bb * HW);
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sO + rl * OPT + p4 * 4) + a.bias[co0 + rl];
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sO + (rl + 2) * OPT + p4 * 4) + a.bias[co0 + rl + 2];
+                        unsigned w[4][3];
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4) Pieces<3>::template split<false>(v0[i4], v1[i4], w[i4]);
+                        const int st = (ch0 >> 4) + st_l;
+                        unsigned* d1 = img + ((long)(bb * heads + head) * ntl + (pix >> 5)) * (3072 * DT) + (st * 3 * 4 + j) * 64 + h * 32 + (pix & 31);
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(d1 + pc * 256) = u32x4{w[0][pc], w[1][pc], w[2][pc], w[3][pc]};
+                    }
+                } else {
+                    // V: item = (channel m of the sub-tile, key tile tt of the pixel tile, step s2, half h): keys 16 s2 + 4 h + {0..3} and + 8
+                    const int m = item & 31, grp = item >> 5;
+                    const int tt = grp >> 2, s2 = (grp >> 1) & 1, h = grp & 1;
+                    const int kb = 16 * s2 + 4 * h;
+                    const long g = gp0 + tt * 32;
+                    if (g < NPX) {
+                        const int bb = (int)(g / HW), pix = (int)(g - (long)bb * HW);
+                        const int rl = ct * 32 + m;
+                        const float bs = a.bias[co0 + rl];
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sO + rl * OPT + tt * 32 + kb) + bs;
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sO + rl * OPT + tt * 32 + kb + 8) + bs;
+                        unsigned wa[3], wb[3], wc[3], wd[3];
+                        Pieces<3>::template split<false>(v0[0], v0[1], wa);
+                        Pieces<3>::template split<false>(v0[2], v0[3], wb);
+                        Pieces<3>::template split<false>(v1[0], v1[1], wc);
+                        Pieces<3>::template split<false>(v1[2], v1[3], wd);
+                        unsigned* d1 = img + ((long)(bb * heads + head) * ntl + (pix >> 5)) * (3072 * DT) + 1536 * DT +
+                                       ((((ch0 >> 5) * 2 + s2) * 3) * 64 + h * 32 + m) * 4;
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(d1 + pc * 256) = u32x4{wa[pc], wb[pc], wc[pc], wd[pc]};
+                    }
+                }
+            }
+        }
+    }
     {
 #pragma unroll
         for (int k = 0; k < BCO / 8; ++k) {
+            if (KV && kv_tile[k >> 2]) continue;              // rows cr + 8 k of sub-tile k / 4: written as pieces above
             const int cl = cr + 8 * k, co = co0 + cl;
-            f32x4 v = *reinterpret_cast<const f32x4*>(sO + cl * PT + px4 * 4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(sO + cl * OPT + px4 * 4);
             v = (v + e_bias[k] + e_res[k]) * a.out_scale;
             if (valid && co < a.Cout) *reinterpret_cast<f32x4*>(a.y + obase + (long)co * HW) = v;
             if (a.stats && (HW >= PT || HW == 64)) {
@@ -364,7 +434,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
 
 static size_t q1_lds_bytes(int np, int cot, int Cin, int HW) {
     const int nimg = HW >= Q1_PT ? 1 : Q1_PT / HW;
-    return (size_t)(Q1_NB * (cot * np * 256) + Q1_NB * Q1_CK * Q1_PT + nimg * Cin * 2) * sizeof(float);
+    const size_t loop = (size_t)(Q1_NB * (cot * np * 256) + Q1_NB * Q1_CK * Q1_PT + nimg * Cin * 2) * sizeof(float);
+    const size_t epi = (size_t)(32 * cot) * (Q1_PT + 4) * sizeof(float);      // the transposed output tile (row pitch PT + 4) overlays the chunk buffers
+    return loop > epi ? loop : epi;
 }
 
 // Shape ids 15 (np = 3) / 14 (np = 2) apply to this launch (cot = cout tile in 32-channel units, 1..4).
@@ -393,6 +465,8 @@ static int q1_launch(const ConvArgs& a, hipStream_t s) {
         MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if constexpr (NP == 3)
+            MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, COT, 1, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised.done();
     }
 #ifdef MCVD_DIAG
@@ -442,6 +516,13 @@ static int q1_launch(const ConvArgs& a, hipStream_t s) {
         }
     }
 #endif
+    if constexpr (NP == 3) {
+        if (a.kv_img && a.coef && !a.act) {            // the q|k|v projection with its K and V thirds as piece images (conv1x1_h2_kv_supported)
+            hipLaunchKernelGGL((conv1x1_h2_kernel<3, COT, 1, 0, true>), grid, dim3(256), lds, s, a, ptiles, nct);
+            MCVD_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     if (!a.coef)
         hipLaunchKernelGGL((conv1x1_h2_kernel<NP, COT, 0>), grid, dim3(256), lds, s, a, ptiles, nct);
     else if (!a.act)
@@ -462,7 +543,15 @@ static int q1_launch_cot(const ConvArgs& a, int cot, hipStream_t s) {
     }
 }
 
+// The K / V piece-image epilogue applies: the fused q|k|v projection (Cout = 3 C, affine prologue, no activation / residual / scale) of an
+// attention block whose head dim the pre-split attention kernel serves (attention_h2.cpp: attn_h2p_supported)
+bool conv1x1_h2_kv_supported(const ConvArgs& a, int cot) {
+    return a.kv_img && a.kv_C > 0 && a.Cout == 3 * a.kv_C && a.kv_D % 32 == 0 && a.kv_C % a.kv_D == 0 && a.coef && !a.act && !a.res && a.out_scale == 1.0f &&
+           !a.stats && conv1x1_h2_supported(a, cot, 3);
+}
+
 int launch_conv1x1_h2(const ConvArgs& a, int cot, hipStream_t s, int np) {
+    MCVD_REQUIRE(!a.kv_img || (np == 3 && conv1x1_h2_kv_supported(a, cot)), "conv1x1 split-operand GEMM: K / V piece images requested for a launch that cannot write them");
     MCVD_REQUIRE(conv1x1_h2_supported(a, cot, np), "conv1x1 split-operand GEMM: unsupported (np=%d ks=%d H=%d W=%d Cin=%d C0=%d cot=%d, weight pieces %s)",
                  np, a.ks, a.H, a.W, a.Cin, a.C0, cot, (np == 2 ? a.wph : a.wpb) ? "present" : "missing");
     const int rc = np == 2 ? q1_launch_cot<2>(a, cot, s) : q1_launch_cot<3>(a, cot, s);

@@ -36,7 +36,16 @@ __device__ __forceinline__ float silu_w3p(float v) { return v * __builtin_amdgcn
 constexpr int WP_CK = 16;        // input channels per chunk = K of one bf16 MFMA
 constexpr int WP_T = 32;         // tiles per item (4 x 8 tiles = 8 x 16 output pixels)
 constexpr int WP_NT = 512;
-constexpr int WP_PP = 24;        // LDS patch row pitch
+#ifndef MCVD_W3_PP
+#define MCVD_W3_PP 24
+#endif
+// LDS patch row pitch in channel-pair columns (18 used; 20 for the two 8x8 images side by side).  The patch park stores a lane's four pixels as
+// single dwords at ((pair * 10 + row) * PP + col) * 2 + ce; the 32 lanes of a store group are 8 rows x 4 four-pixel items, bank = (row * 2 PP +
+// 8 item) mod 32: with 2 PP = 48 = 16 (mod 32) they fall on FOUR banks -- the "x4 patch park" conflict behind 27-29 percent of the LDS-active
+// cycles (profiles/r04_pmc_sq_wave_states.txt).  Round 5 built the conflict-free pitch (25: 2 PP = 18 mod 32, 16 banks, 2-way = free for
+// ds_write_b32) and measured it against 24 on one box (tools/build_variant.sh, -DMCVD_W3_PP=25; profiles/r05_patch_pitch_ab.txt): 5577 vs 5592
+// cycles per chunk, 248.1 / 248.5 vs 248.8 / 249.4 frames/s -- nothing.  The stores are not on the chunk's critical path; 24 stays.
+constexpr int WP_PP = MCVD_W3_PP;
 constexpr int WP_PW = 16 * 2 * 4 * WP_T;          // 32-bit words of one piece plane of a V chunk: [position][half][pair][tile]
 constexpr int WP_VW = 3 * WP_PW;                  // 32-bit words of one V chunk: [piece][position][half][pair][tile]
 constexpr int WP_NPL = 3;                         // patch-load instructions per thread and chunk (two four-pixel slots + one halo slot)

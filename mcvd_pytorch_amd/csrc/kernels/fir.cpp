@@ -333,6 +333,7 @@ struct SpadeNormArgs {
     const float* gb; const float* coef2; float* y; float* coef_out; int B, HW, parts;
 };
 constexpr int SN_KEEP = 8;
+constexpr int SN_PRE = 4;        // items per thread whose loads are issued in front of the reduction
 __global__ __launch_bounds__(256) void spade_norm_apply_kernel(SpadeNormArgs a) {
     __shared__ float sAB[2 * 64];
     const int C = a.C0 + a.C1;
@@ -342,6 +343,24 @@ __global__ __launch_bounds__(256) void spade_norm_apply_kernel(SpadeNormArgs a) 
     const int b = bg / a.groups, g = bg - b * a.groups;
     const int c0 = g * gs;
     const int tid = threadIdx.x, lane = tid & 63;
+    // the thread's first SN_PRE items (x, gamma, beta: 16 bytes each) are requested BEFORE the statistics are reduced: their latency
+    // passes under the reduction's two dependent round trips instead of behind them (most workgroups have 2-4 items per thread)
+    const int HW4 = a.HW >> 2;
+    const int per = (HW4 + a.parts - 1) / a.parts;                 // float4 columns of this part, for every channel of the group
+    const int p_lo = part_id * per, p_hi = min(HW4, p_lo + per);
+    const int span = p_hi - p_lo;
+    const int nitems = gs * span;
+    float4 pv[SN_PRE], pg[SN_PRE], pb[SN_PRE];
+#pragma unroll
+    for (int k = 0; k < SN_PRE; ++k) {
+        const int i = min(tid + 256 * k, nitems - 1);
+        const int cl = i / span, p4 = p_lo + (i - cl * span);
+        const int c = c0 + cl;
+        const float* src = (c < a.C0) ? a.x0 + ((long)b * a.C0 + c) * a.HW : a.x1 + ((long)b * a.C1 + (c - a.C0)) * a.HW;
+        pv[k] = reinterpret_cast<const float4*>(src)[p4];
+        pg[k] = reinterpret_cast<const float4*>(a.gb + ((long)b * 2 * C + c) * a.HW)[p4];
+        pb[k] = reinterpret_cast<const float4*>(a.gb + ((long)b * 2 * C + C + c) * a.HW)[p4];
+    }
     if (tid < 64) {                       // ---- gn_finalize_kernel's reduction, instruction for instruction (mode 0: no affine)
         const int n_in0 = max(0, min(c0 + gs, a.C0) - c0), n_in1 = gs - n_in0;
         const int P0 = n_in0 * a.np0, P = P0 + n_in1 * a.np1;
@@ -403,18 +422,21 @@ __global__ __launch_bounds__(256) void spade_norm_apply_kernel(SpadeNormArgs a) 
         }
     }
     __syncthreads();
-    const int HW4 = a.HW >> 2;
-    const int per = (HW4 + a.parts - 1) / a.parts;                 // float4 columns of this part, for every channel of the group
-    const int p_lo = part_id * per, p_hi = min(HW4, p_lo + per);
-    const int span = p_hi - p_lo;
-    for (int i = tid; i < gs * span; i += 256) {
+    for (int i = tid, k = 0; i < nitems; i += 256, ++k) {
         const int cl = i / span, p4 = p_lo + (i - cl * span);
         const int c = c0 + cl;
         const long bc = (long)b * C + c;
-        const float* src = (c < a.C0) ? a.x0 + ((long)b * a.C0 + c) * a.HW : a.x1 + ((long)b * a.C1 + (c - a.C0)) * a.HW;
-        const float4 v = reinterpret_cast<const float4*>(src)[p4];
-        const float4 gm = reinterpret_cast<const float4*>(a.gb + ((long)b * 2 * C + c) * a.HW)[p4];
-        const float4 be = reinterpret_cast<const float4*>(a.gb + ((long)b * 2 * C + C + c) * a.HW)[p4];
+        float4 v, gm, be;
+        if (k < SN_PRE) {
+#pragma unroll
+            for (int q = 0; q < SN_PRE; ++q)
+                if (q == k) { v = pv[q]; gm = pg[q]; be = pb[q]; }
+        } else {
+            const float* src = (c < a.C0) ? a.x0 + ((long)b * a.C0 + c) * a.HW : a.x1 + ((long)b * a.C1 + (c - a.C0)) * a.HW;
+            v = reinterpret_cast<const float4*>(src)[p4];
+            gm = reinterpret_cast<const float4*>(a.gb + ((long)b * 2 * C + c) * a.HW)[p4];
+            be = reinterpret_cast<const float4*>(a.gb + ((long)b * 2 * C + C + c) * a.HW)[p4];
+        }
         const float cA = sAB[2 * cl], cB = sAB[2 * cl + 1];
         float sA = 1.f, sB = 0.f;
         if (a.coef2) { sA = a.coef2[bc * 2]; sB = a.coef2[bc * 2 + 1]; }

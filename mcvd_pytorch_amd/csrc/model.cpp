@@ -358,13 +358,16 @@ struct Builder {
         TRef coef = alloc_floats(2 * ch, ch);
         m.ops.push_back(gn_op(idx, x, 1e-6f, 2, 0, m.params[gw].off, m.params[gb].off, coef));
         TRef qkv = alloc(3 * ch, H);
+        TRef kv = alloc_floats((int64_t)3 * ch * H * H, 3 * ch);        // K and V as three-piece bf16 LDS images (6 bytes per element)
         Op c{};
         c.kind = OP_CONV; c.module = idx; c.src0 = x.a; c.H = c.W = H; c.coef = coef; c.act = 0; c.dst = qkv;
+        c.kv = kv; c.heads = heads;
+        c.attn_op = (int)m.ops.size() + 1;
         conv_pack(c, {P + ".NIN_0.W", P + ".NIN_1.W", P + ".NIN_2.W"}, {P + ".NIN_0.b", P + ".NIN_1.b", P + ".NIN_2.b"}, ch, ch, 1, 1);
         m.ops.push_back(c);
         TRef o = alloc(ch, H);
         Op a{};
-        a.kind = OP_ATTN; a.module = idx; a.src0 = qkv; a.dst = o; a.H = a.W = H; a.heads = heads; a.Cout = ch;
+        a.kind = OP_ATTN; a.module = idx; a.src0 = qkv; a.dst = o; a.H = a.W = H; a.heads = heads; a.Cout = ch; a.kv = kv;
         m.ops.push_back(a);
         out->H = H;
         out->a = alloc(ch, H);
@@ -767,12 +770,14 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                     if (op.gn_src >= 0)                         // the fused loader reads the (A, B) table
                         if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
                     a.shape_hint = t.shape_hint;
+                    ++fused_launches[2];
                 } else {
                     float* tmp = resolve(op.tmp, x, cond, out, B);
                     if (op.gn_src >= 0 && gn_deferred[op.gn_src] == 2) {
                         // normalisation statistics + SPADE modulation + temb pair + SiLU in one launch (kernels/fir.cpp)
                         const Op& g = ops[op.gn_src];
                         gn_deferred[op.gn_src] = 0;
+                        ++fused_launches[1];
                         const int np0 = stats_np[g.prod0], np1 = a.C1 ? stats_np[g.prod1] : 1;
                         if (int rc = launch_spade_norm_apply(a.x0, a.C0, a.x1, a.C1, g.groups, g.eps, resolve(ops[g.prod0].stats, x, cond, out, B), np0,
                                                              a.C1 ? resolve(ops[g.prod1].stats, x, cond, out, B) : nullptr, np1, a.gb, a.coef2, tmp,
@@ -815,6 +820,25 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                 }
             }
             if (ran_kernel.size() != ops.size()) ran_kernel.assign(ops.size(), -1);
+            if (kv_live.size() != ops.size()) kv_live.assign(ops.size(), 0);
+            if (op.attn_op >= 0) {
+                // the q|k|v projection of an attention block: where the launch goes to the three-piece 1x1 GEMM and the attention op will run
+                // the three-piece kernel on a device of its own, K and V leave this kernel pre-split (conv1x1_h2.cpp KV -> attn_h2p_kernel)
+                kv_live[op.attn_op] = 0;
+                const Op& at = ops[op.attn_op];
+                const bool want = ctx->attn_presplit && !ctx->naive_conv && ctx->bf16x3 && !ctx->f16x2 && (ctx->naive_attn == 0 || ctx->naive_attn == 4) &&
+                                  !mcvd_ctx_shares_device(ctx) && attn_h2p_supported(at.Cout, at.heads, at.H * at.W) && a.shape_hint == 15;
+                if (want) {
+                    ConvArgs t = a;
+                    t.kv_img = resolve(op.kv, x, cond, out, B);
+                    t.kv_C = at.Cout;
+                    t.kv_D = at.Cout / at.heads;
+                    if (conv1x1_h2_kv_supported(t, t.cot)) {
+                        a = t;
+                        kv_live[op.attn_op] = 1;
+                    }
+                }
+            }
             if (ctx->naive_conv) {
                 stats_np[oi] = 0;
                 ran_kernel[oi] = -2;
@@ -894,6 +918,13 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             // (a context that shares its device -- another process, or another stream of this one -- keeps the split-operand attention
             // kernels off it: api.cpp, mcvd_ctx_shares_device)
             const bool shared = mcvd_ctx_shares_device(ctx);
+            const size_t ai = (size_t)(&op - ops.data());
+            if (ai < kv_live.size() && kv_live[ai]) {                     // K and V were written pre-split by the projection of this forward
+                kv_live[ai] = 0;
+                ++fused_launches[0];
+                return launch_attention_h2p(resolve(op.src0, x, cond, out, B), resolve(op.kv, x, cond, out, B), resolve(op.dst, x, cond, out, B), B,
+                                            op.Cout, op.heads, op.H * op.W, s);
+            }
             return launch_attention(ctx->naive_attn, shared ? 0 : ctx->f16x2, shared ? 0 : ctx->bf16x3, resolve(op.src0, x, cond, out, B), resolve(op.dst, x, cond, out, B), B,
                                     op.Cout, op.heads, op.H * op.W, s);
         }
@@ -982,6 +1013,8 @@ int mcvd_model::autotune(int B) {
                 }
             }
             a.cot = op.cot;
+            if (op.ks == 3 && op.Cout <= 16 && !spade_fused && conv_small_cout_usable(a))      // 21 = fp32 VALU direct conv for the last layer's handful of couts
+                if (int rc = time_candidate(21, op.cot)) return rc;
             if (op.ks == 3 && ctx->winograd) {             // 8 = Winograd with a 2-way K split (more workgroups: 8x8 layers)
                 ConvArgs b = a;
                 b.ksplit = 2;

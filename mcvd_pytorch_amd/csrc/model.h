@@ -39,10 +39,15 @@ struct mcvd_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int spade_fuse = 0;            // 1: SPADE modulation inside the Winograd conv loader (gamma | beta by LDS-DMA); 0: through spade_apply.
                                    //    Off by default: measured 3.5 % SLOWER end to end (profiles/r02_spade_fusion_ab.txt)
+    int attn_presplit = 1;         // the q|k|v projection writes K and V pre-split (three bf16 pieces, LDS-image order) and the attention kernel
+                                   //    stages them by LDS-DMA (attn_h2p_kernel; head dims 32 / 64 / 96, default arithmetic only); 0: attn_h2_kernel
+                                   //    splits them itself, once per query tile.  Bit-identical results either way.
     int spade_fuse_auto = 1;       // offer the fused SPADE loader to the autotuner PER LAYER (shape ids 36 / 40): it takes the layers where
                                    //    [gn_finalize + fused fp32 Winograd conv] beats [spade_norm_apply + the best plain conv] in its own timing
-    int spade_norm_fuse = 1;       // SPADE norms in front of a conv: GroupNorm finalize + modulation + temb pair + SiLU in ONE launch
-                                   //    (spade_norm_apply_kernel) instead of gn_finalize + spade_apply; 0: the two launches (bit-identical results)
+    int spade_norm_fuse = 0;       // 1: SPADE norms in front of a conv: GroupNorm finalize + modulation + temb pair + SiLU in ONE launch
+                                   //    (spade_norm_apply_kernel) instead of gn_finalize + spade_apply (bit-identical results).  Off by default:
+                                   //    measured 0.7 % faster, then 1 % SLOWER end to end on config 4 (profiles/r05_spade_fusion_ab.txt) -- every
+                                   //    workgroup pays the reduction's two dependent round trips in front of its stream
     int gn_stats = 1;              // GroupNorm statistics from the producing conv's epilogue (0: always one pass over the tensor)
     int gn_inline = 0;             // 1: a conv whose kernel can (conv_takes_gn_inline) reduces those partial statistics itself where a channel has
                                    //    at most GN_INLINE_MAX_NP of them: no gn_finalize launch for that norm (kernels/gn_inline.h).  Off by default:
@@ -108,6 +113,9 @@ struct Op {
     int up = 0;
     // attention
     int heads = 0;
+    TRef kv;                       // q|k|v projection and its attention op: K and V as three-piece bf16 LDS images (3 C HW dwords per sample;
+                                   // conv1x1_h2.cpp KV epilogue -> attn_h2p_kernel); which form a forward uses: mcvd_model::kv_live
+    int attn_op = -1;              // q|k|v projection: index of the attention op that consumes it
     // SPADE: gb = cached [2C] (gamma | beta) maps, coef2 = (1 + scale, shift) per (sample, channel)
     TRef gb, coef2;
     TRef tmp;                      // conv with a SPADE norm in front: where spade_apply materialises its input when the kernel cannot fuse it
@@ -195,8 +203,10 @@ struct mcvd_model {
 
     // conv tile choice per op for the batch size it was tuned at: (shape, cot); filled by autotune()
     std::vector<int> stats_np;        // per op: partials per (sample, channel) its last launch wrote (0: none)
+    std::vector<signed char> kv_live;       // per OP_ATTN of the forward in flight: 1 = its projection wrote the K / V piece images (set by the conv launch)
     std::vector<signed char> gn_deferred;   // per OP_GN of the forward in flight: 1 = not launched, its consumers reduce the partials
                                       //    themselves (or launch it late, the first that cannot): launch_op / ensure_coef
+    long fused_launches[3] = {0, 0, 0};   // mcvd_model_fused_launches: pre-split attention blocks, fused SPADE norms, convs with the SPADE loader
     long gn_inlined_total = 0;        // norms that never needed a launch (diagnostics: mcvd_model_stat)
     int launch_gn(const mcvd::Op& op, const float* x, const void* labels, const float* cond, float* out, int B, bool may_defer);
     int ensure_coef(int gn_index, const float* x, const void* labels, const float* cond, float* out, int B);

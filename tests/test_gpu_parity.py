@@ -203,6 +203,45 @@ def test_conv2d(ctx, case, naive):
     _close(got, want, what=f"conv {case}")
 
 
+@pytest.mark.parametrize("B,C0,C1,Cout,H,use_coef,act,use_res", [
+    (2, 96, 0, 5, 64, True, 1, False),      # the headline net's last layer: GroupNorm + SiLU -> conv3x3(96 -> 5)
+    (3, 128, 0, 15, 32, True, 1, False),    # 15 = 3 channels x 5 frames (BASELINE configs 4 / 5), odd batch
+    (2, 40, 24, 8, 16, True, 0, True),      # concat input, affine without SiLU, residual + scale, ragged last chunk (64 = 8 chunks; 40 + 24)
+    (1, 20, 0, 3, 128, False, 0, False),    # raw input, ragged chunk (20 channels), 128 x 128
+])
+def test_conv_small_cout_direct_kernel(ctx, B, C0, C1, Cout, H, use_coef, act, use_res):
+    """Shape id 21 (conv_small_cout.cpp): the fp32 VALU direct conv for layers with at most 16 output channels -- the network's last conv,
+    which the matrix-pipe kernels serve on a 32-cout tile that is 27 / 32 zeros.  Exact fp32 FMA chains; against
+    F.conv2d at the per-op tolerance and against an fp64 convolution (layers.py:107-113)."""
+    from mcvd_pytorch_amd import _lib
+    g = _g(37)
+    Cin = C0 + C1
+    x0 = torch.randn(B, C0, H, H, generator=g)
+    x1 = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = 0.1 * torch.randn(Cout, generator=g)
+    coef = torch.stack([1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], dim=-1) if use_coef else None
+    res = torch.randn(B, Cout, H, H, generator=g) if use_res else None
+    scale = 0.70710678 if use_res else 1.0
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    if use_coef:
+        xin = xin * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]
+    if act:
+        xin = unet_ref.silu(xin)
+    want64 = F.conv2d(xin.double(), w.double(), bias.double(), padding=1)
+    if use_res:
+        want64 = want64 + res.double()
+    want64 = want64 * scale
+    dev = lambda t: t.cuda().contiguous() if t is not None else None
+    ctx.opt("conv_shape", 21)
+    got = ctx.conv2d(dev(x0), dev(w), dev(bias), x1=dev(x1), coef=dev(coef), act=act, res=dev(res), scale=scale)
+    assert _lib.lib.mcvd_last_conv_kernel() == 21
+    ctx.opt("conv_shape", -1)
+    _close(got, want64.float(), what="small-cout conv")
+    err = ((got.cpu().double() - want64).abs().max() / want64.abs().max()).item()
+    assert err < 3e-6, err
+
+
 def _structured(kind, B, Cin, H, g):
     """Inputs on which operand-representation errors do NOT average out: constant planes, one dominant channel, sums that
     cancel (channel pairs carry the same plane; the test pairs the weights w, -w), and plain Gaussian data."""
@@ -530,6 +569,88 @@ def test_spade_fused_and_materialised_paths_agree():
     net.set_option("spade_fuse", 0)
     assert not torch.equal(a, b)
     assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t.cpu(), cond)
+    assert (a.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("cfg,B", [("tiny_spade", 3), ("bair_big_spade", 2)])
+def test_spade_norm_fused_into_one_launch_is_bit_identical(cfg, B):
+    """north_star: "SPADE gamma/beta fused into the normalization epilogue".  Option spade_norm_fuse (round 5): the GroupNorm finalize of a SPADE
+    norm (statistics from the producers' epilogue partials), the modulation (1 + gamma) / beta, the temb pair and SiLU are ONE launch
+    (spade_norm_apply_kernel) instead of gn_finalize + spade_apply -- the same reduction order and the same expression, so eps is bit-identical
+    to the two-launch path (option spade_norm_fuse = 0), and the counter says the fused kernel served the norms (layerspp.py:152-173, :530-535)."""
+    from mcvd_pytorch_amd import _lib
+    config, sd, net = _net(cfg)
+    net.set_option("spade_fuse_auto", 0)                # (the per-layer fused-loader candidates are another test's subject)
+    net.set_option("spade_norm_fuse", 1)                # (opt-in: measured no faster than the two launches, profiles/r05_spade_fusion_ab.txt)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = torch.tensor([700, 20, 333][:B]).cuda()
+    n0 = _lib.lib.mcvd_model_fused_launches(net._model, 1)
+    a = net(x.cuda(), t, cond=cond.cuda()).clone()
+    n1 = _lib.lib.mcvd_model_fused_launches(net._model, 1)
+    assert n1 - n0 >= (14 if cfg == "tiny_spade" else 40), (n0, n1)      # every SPADE norm in front of a conv whose producer emits statistics
+    net.set_option("spade_norm_fuse", 0)
+    b = net(x.cuda(), t, cond=cond.cuda()).clone()
+    assert _lib.lib.mcvd_model_fused_launches(net._model, 1) == n1
+    net.set_option("spade_norm_fuse", 1)
+    assert torch.equal(a, b), f"fused SPADE norm differs from gn_finalize + spade_apply: {float((a - b).abs().max()):.3e}"
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t.cpu(), cond)
+    assert (a.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_spade_loader_fusion_offered_per_layer():
+    """The SPADE modulation inside the conv loader (fp32 Winograd, gamma | beta by LDS-DMA) is a candidate of the autotuner for every
+    SPADE-normed 3x3 conv (shape ids 36 / 40): it takes the layers where [gn_finalize + fused conv] beats [spade_norm_apply + the best plain
+    conv] in its own timing.  Whatever it picks, the forward stays inside the contract; a table that names 36 / 40 is honoured
+    (mcvd_model_fused_launches(2)) and survives export / import."""
+    from mcvd_pytorch_amd import _lib
+    config, sd, net = _net("tiny_spade")
+    x, cond = synth.make_inputs(config, 2, seed=0)
+    t = torch.tensor([700, 20]).cuda()
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t.cpu(), cond)
+    a = net(x.cuda(), t, cond=cond.cuda()).clone()                        # autotuned, fused candidates offered
+    assert (a.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    table = net.get_tuning(2)
+    import ctypes
+    info = (ctypes.c_int * 8)()
+    forced = []
+    for i, (sh, cot) in enumerate(table):
+        _lib.check(_lib.lib.mcvd_model_op_info(net._model, i, info), "op_info")
+        is_spade_conv3 = info[0] == 3 and info[2] == 3 and info[7] != 0 and info[1] >= 0 and info[3] >= 16      # a 3x3 conv behind a (SPADE) norm, not a cond-only prep conv
+        forced.append((36 if (is_spade_conv3 and i % 2 == 0 and sh not in (36, 40)) else sh, cot))
+    net.set_tuning(2, forced)
+    n0 = _lib.lib.mcvd_model_fused_launches(net._model, 2)
+    b = net(x.cuda(), t, cond=cond.cuda()).clone()
+    n_forced = sum(1 for (sh, _), (sh0, _c) in zip(forced, table) if sh == 36)
+    assert n_forced > 0 and _lib.lib.mcvd_model_fused_launches(net._model, 2) - n0 >= 1
+    assert (b.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert net.get_tuning(2) == forced
+
+
+@pytest.mark.parametrize("cfg,B", [("smmnist_big5_ngf96", 2), ("smmnist_big5", 3), ("tiny", 3)])
+def test_attention_with_presplit_kv_is_bit_identical(cfg, B):
+    """the fused q|k|v projection writes K and V ALREADY SPLIT into the three bf16 pieces, in the LDS-image order the
+    attention kernel reads its operands in (conv1x1_h2.cpp KV epilogue), and attn_h2p_kernel stages the tiles by LDS-DMA instead of
+    splitting every element once per query tile.  Same pieces, same products in the same order: eps must be BIT-IDENTICAL to the forward
+    with the option attn_presplit = 0 (attn_h2_kernel), at head dims 96 / 64 / 32, 32 x 32 ... 8 x 8 tokens (pixel tiles that span two
+    images), odd batch; the counter says every attention block took the new path (layerspp.py:236-245)."""
+    from mcvd_pytorch_amd import _lib
+    config, sd, net = _net(cfg)
+    _apply_mode(net, "bf16x3")                                              # every 1x1 conv on the three-piece GEMM, attention three-piece
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = torch.tensor([990, 130, 555][:B]).cuda()
+    n0 = _lib.lib.mcvd_model_fused_launches(net._model, 0)
+    a = net(x.cuda(), t, cond=cond.cuda()).clone()
+    used = _lib.lib.mcvd_model_fused_launches(net._model, 0) - n0
+    assert used >= 3, used
+    net.set_option("attn_presplit", 0)
+    b = net(x.cuda(), t, cond=cond.cuda()).clone()
+    assert _lib.lib.mcvd_model_fused_launches(net._model, 0) - n0 == used
+    net.set_option("attn_presplit", 1)
+    assert torch.equal(a, b), f"pre-split K / V attention differs from the in-kernel split: {float((a - b).abs().max()):.3e}"
     with torch.no_grad():
         ref = unet_ref.unet_forward(sd, config, x, t.cpu(), cond)
     assert (a.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
