@@ -238,15 +238,18 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
 // in exactly the order the two products read their operands from the LDS, so a tile reaches the LDS by LDS-DMA (16 bytes per lane, no
 // VALU instruction, no register) into one of TWO buffers: the DMA of tile t + 1 is issued behind the barrier that publishes tile t and
 // lands under that tile's products; one barrier per tile instead of two.  Same pieces, same products in the same order: the output is
-// bit-identical to attn_h2_kernel<3, DT>.  Head dims 32 / 64 / 96 (two 24 KB x DT buffers, two workgroups per CU).
-template <int DT>
-__global__ __launch_bounds__(256, 2) void attn_h2p_kernel(const float* __restrict__ qkv, const unsigned* __restrict__ kv_img, float* __restrict__ out,
-                                                           int C, int heads, int S, float scale_s, int nbh, int nqt) {
+// bit-identical to attn_h2_kernel<3, DT>.  Head dims 32 ... 128.
+// NW = waves per workgroup = 32-query tiles that share a staged K / V tile: 4 for head dims up to 96 (two workgroups per CU, 24 KB x DT of
+// LDS each), 8 for head dim 128 (ONE workgroup of 256 queries per CU: its two 48 KB buffers are 96 KB; two waves per SIMD as before, and
+// none of attn_h2_kernel<3, 4>'s 17 spilled registers -- the staging registers are gone).
+template <int DT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_h2p_kernel(const float* __restrict__ qkv, const unsigned* __restrict__ kv_img, float* __restrict__ out,
+                                                              int C, int heads, int S, float scale_s, int nbh, int nqt) {
     typedef Pieces<3> PX;
-    constexpr int NP = 3, D = 32 * DT, NST = D / 16;
+    constexpr int NP = 3, D = 32 * DT, NST = D / 16, NT = 64 * NW;
     constexpr int IMG = 3072 * DT;                  // dwords of one (K | V) tile image
     constexpr int NPC = IMG / 4;                    // its 16-byte pieces: 768 DT
-    constexpr int NR = (NPC + 255) / 256;           // DMA rounds per thread and tile
+    constexpr int NR = (NPC + NT - 1) / NT;         // DMA rounds per thread and tile
     static_assert(NPC % 64 == 0, "a wave's 64 pieces are all inside the image or all outside");
     extern __shared__ __attribute__((aligned(16))) float smem_attn_h2p[];
     unsigned* sT = reinterpret_cast<unsigned*>(smem_attn_h2p);      // [2][IMG]: K image at 0, V image at 1536 DT
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void attn_h2p_kernel(const float* __restric
     if (bh >= nbh) return;
     const int b = bh / heads, hd = bh - b * heads;
     const float* qb = qkv + ((long)b * 3 * C + hd * D) * S;
-    const int q0 = qt * 128 + wave * 32;
+    const int q0 = qt * (32 * NW) + wave * 32;
     const bool active = q0 < S;
     const int ntiles = S / 32;
     const unsigned* ib = kv_img + (long)bh * ntiles * IMG;
@@ -268,8 +271,8 @@ __global__ __launch_bounds__(256, 2) void attn_h2p_kernel(const float* __restric
         unsigned* dst = sT + (t & 1) * IMG;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int q0p = r * 256 + wave_u * 64;                  // the wave's first piece of this round (wave-uniform)
-            if ((r + 1) * 256 <= NPC || q0p < NPC)                  // (only a ragged last round is predicated)
+            const int q0p = r * NT + wave_u * 64;                   // the wave's first piece of this round (wave-uniform)
+            if ((r + 1) * NT <= NPC || q0p < NPC)                   // (only a ragged last round is predicated)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (q0p + lane) * 4),
                                                  (__attribute__((address_space(3))) void*)(dst + q0p * 4), 16, 0, 0);
         }
@@ -389,30 +392,32 @@ __global__ __launch_bounds__(256, 2) void attn_h2p_kernel(const float* __restric
 bool attn_h2p_supported(int C, int heads, int HW) {
     if (heads <= 0 || C % heads != 0) return false;
     const int D = C / heads;
-    return D % 32 == 0 && D >= 32 && D <= 96 && HW % 32 == 0;
+    if (D % 32 != 0 || D < 32 || D > 128 || HW % 32 != 0) return false;
+    return D <= 96 || HW >= 256;                    // head dim 128: 256-query workgroups (8 x 8 images stay on attn_h2_kernel)
 }
 
 int launch_attention_h2p(const float* qkv, const float* kv_img, float* out, int B, int C, int heads, int HW, hipStream_t s) {
     MCVD_REQUIRE(attn_h2p_supported(C, heads, HW) && kv_img, "pre-split attention: unsupported (C=%d heads=%d HW=%d)", C, heads, HW);
     const int D = C / heads;
     const float scale_s = (float)pow((double)D, -0.5);
-    const int nqt = (HW + 127) / 128, nbh = B * heads;
+    const int NWq = D <= 96 ? 4 : 8;
+    const int nqt = (HW + 32 * NWq - 1) / (32 * NWq), nbh = B * heads;
     dim3 grid((unsigned)(((nbh + 7) / 8) * 8 * nqt));
     const size_t lds = (size_t)2 * 3072 * (D / 32) * sizeof(unsigned);
     const unsigned* img = reinterpret_cast<const unsigned*>(kv_img);
-#define AHP_CASE(DT)                                                                                                      \
+#define AHP_CASE(DT, NW)                                                                                                  \
     case DT: {                                                                                                            \
         static PerDeviceOnce raised;                                                                                      \
         if (lds > 48 * 1024 && raised.first_use()) {                                                                      \
-            MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_h2p_kernel<DT>),                       \
+            MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_h2p_kernel<DT, NW>),                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
             raised.done();                                                                                                \
         }                                                                                                                 \
-        hipLaunchKernelGGL((attn_h2p_kernel<DT>), grid, dim3(256), lds, s, qkv, img, out, C, heads, HW, scale_s, nbh, nqt); \
+        hipLaunchKernelGGL((attn_h2p_kernel<DT, NW>), grid, dim3(64 * NW), lds, s, qkv, img, out, C, heads, HW, scale_s, nbh, nqt); \
         break;                                                                                                            \
     }
     switch (D / 32) {
-        AHP_CASE(1) AHP_CASE(2) AHP_CASE(3)
+        AHP_CASE(1, 4) AHP_CASE(2, 4) AHP_CASE(3, 4) AHP_CASE(4, 8)
     }
 #undef AHP_CASE
     MCVD_HIP_CHECK(hipGetLastError());

@@ -373,16 +373,55 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
     const unsigned long long t_red_end = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---------------- epilogue: scale, coalesced NCHW stores (bias/residual are already in the accumulators)
+    // GroupNorm partials of the FINAL values (ConvArgs::stats; round 5: the stem runs this kernel, and without them BOTH norms that read its
+    // output -- the first ResBlock's and, through the skip stack, the last up block's concat norm -- took a pass over the tensor, the only two
+    // gn_coef launches of a forward, 29 us each).  Non-split tiles of whole rows of ONE image: a wave's PXT * 32 pixels are one contiguous
+    // pixel block of the image = one partial; the 32 lanes of a half-wave hold one cout.  Pilot-shifted moments as in conv_wino3.cpp.
+    const bool emit_stats = !SPLIT && a.stats != nullptr && g.nimg == 1 && pvalid[0];
+    const int st_np = HW / (PXT * 32), st_p = (y0 * W + wpx0) / (PXT * 32);
 #pragma unroll
     for (int ct = 0; ct < COT; ++ct) {
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
             const int cos = co0 + ct * 32 + (rg & 3) + 8 * (rg >> 2);
             float* yb = a.y + (long)cos * HW;
+            float vv[PXT];
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt) vv[pt] = acc[ct][pt][rg] * a.out_scale;
             if (cos + 4 * half < a.Cout) {
 #pragma unroll
                 for (int pt = 0; pt < PXT; ++pt)
-                    if (pvalid[pt]) yb[voff[pt]] = acc[ct][pt][rg] * a.out_scale;
+                    if (pvalid[pt]) yb[voff[pt]] = vv[pt];
+            }
+            if (!SPLIT && emit_stats) {
+                const int pv = __builtin_bit_cast(int, vv[0]);
+                const int s0 = __builtin_amdgcn_readlane(pv, 0), s2 = __builtin_amdgcn_readlane(pv, 32);
+                const float pil = __builtin_bit_cast(float, (lane & 32) ? s2 : s0);
+                float sm = 0.0f, qm = 0.0f;
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt) {
+                    const float d = vv[pt] - pil;
+                    sm += d;
+                    qm += d * d;
+                }
+#define MCVD_MERGE(CTRL, ROWMASK)                                                                                     \
+                {                                                                                                   \
+                    sm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm), CTRL, ROWMASK, 0xf, false)); \
+                    qm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qm), CTRL, ROWMASK, 0xf, false)); \
+                }
+                MCVD_MERGE(0xB1, 0xf)                 // quad_perm [1,0,3,2]
+                MCVD_MERGE(0x4E, 0xf)                 // quad_perm [2,3,0,1]
+                MCVD_MERGE(0x124, 0xf)                // row_ror:4
+                MCVD_MERGE(0x128, 0xf)                // row_ror:8: every lane of a row of 16 holds the row's totals
+                MCVD_MERGE(0x142, 0xa)                // row_bcast:15: lanes 16-31 / 48-63 add the totals of the row below
+#undef MCVD_MERGE
+                const int co = cos + 4 * half;
+                if (l31 == 31 && co < a.Cout) {
+                    const float npix = (float)(PXT * 32);
+                    float* q = a.stats + (((long)b0 * a.Cout + co) * st_np + st_p) * 2;
+                    q[0] = sm + npix * pil;
+                    q[1] = fmaxf(qm - sm * sm * (1.0f / npix), 0.0f);
+                }
             }
         }
     }
@@ -439,6 +478,7 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     dim3 grid(g.n_ptiles, a.CoutP / Cfg::BCO);
     hipLaunchKernelGGL((conv_mfma_kernel<KS, CK, COT, PXT, SPLIT, WDMA, WDBF>), grid, dim3(256), lds, s, a, g);
     MCVD_HIP_CHECK(hipGetLastError());
+    if (!SPLIT && a.stats && g.nimg == 1) set_last_conv_stats_np(a.H * a.W / (PXT * 32));      // one partial per wave's pixel block (epilogue)
     return 0;
 }
 
