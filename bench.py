@@ -231,7 +231,7 @@ def roofline_of_leg(net, args, B, arith_name):
                           "HIP-event time of its launches in one forward of the timed region / that pipe's dense peak, i.e. the matrix-pipe "
                           "utilisation (agrees with PMC SQ_VALU_MFMA_BUSY_CYCLES, profiles/); algorithmic_* applies the contract's "
                           "direct-form count 2*B*HW*Cout*Cin*9 against the FP32 matrix peak (the precision the path delivers) and may exceed 1; "
-                          "traffic is read from a committed PMC file (traffic_from_file), not measured in this run"),
+                          + TRAFFIC_NOTE_FILE),
                     algorithmic_achieved=round(algorithmic, 2), algorithmic_frac=round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
                     algorithmic_bytes_per_launch=round(dom["bytes"] / dom["launches"]),
                     launches=dom["launches"], avg_launch_us=round(1e3 * dom["ms"] / dom["launches"], 1),
@@ -265,6 +265,10 @@ def roofline_of_leg(net, args, B, arith_name):
     return roofline, arith
 
 
+TRAFFIC_NOTE_FILE = "traffic is read from a committed PMC file (traffic_from_file), not measured in this run"
+TRAFFIC_NOTE_RUN = "traffic was measured by this run's own rocprofv3 PMC passes (traffic_measured_in_run)"
+
+
 def pmc_traffic(args, roofline):
     """`--pmc-traffic`: HBM-side bytes per launch of the dominant kernel family measured NOW, by two rocprofv3 PMC passes of this very
     script on this GPU (one counter per pass, kernel-trace only -- MI355X_MICROARCH.md's recipe; the outer process is idle meanwhile),
@@ -294,7 +298,8 @@ def pmc_traffic(args, roofline):
     if not t:
         return dict(traffic_measured_in_run=False, traffic_note="--pmc-traffic: no dispatch of the dominant family in the PMC passes")
     tb = t["traffic_bytes_per_launch"]
-    return dict(traffic=round(tb), traffic_from_file=False, traffic_measured_in_run=True, traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+    return dict(traffic=round(tb), traffic_from_file=False, traffic_measured_in_run=True,
+                note=roofline["note"].replace(TRAFFIC_NOTE_FILE, TRAFFIC_NOTE_RUN), traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                 "passes spawned by this run (6 forwards each, same kernel table, no graph)", traffic_file_sha16=None,
                 traffic_fetch_bytes_per_launch_corrected=round(t["fetch_bytes_per_launch_corrected"]),
                 traffic_write_bytes_per_launch=round(t["write_bytes_per_launch"]),
