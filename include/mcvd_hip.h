@@ -143,6 +143,8 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         (profiles/r03_gn_inline_ab.txt).  "spade_fuse" (0): 1 = the SPADE modulation inside the fp32 Winograd conv loader (gamma | beta by
  *         LDS-DMA; measured 3.5 % slower end to end than the materialising spade_apply kernel).  "side_stream" (0): ResBlock shortcut
  *         convs on a second HIP stream (measured slower; UNSAFE beside the split-operand attention kernel: INTEGRATION.md section 4).
+ *         "fir_form" (0): 0 = the x2 FIR resamplers stage a strip of 1024 input elements through the LDS (prologue applied once per
+ *         element; power-of-two widths 8..256), 1 = the register-window forms only; bit-identical (up_or_down_sampling.py:196-258).
  *         "spade_norm_fuse" (0): 1 = a SPADE norm in front of a conv is ONE launch -- GroupNorm finalize from the producers' epilogue partials +
  *         (1 + gamma) / beta modulation + temb pair + SiLU (spade_norm_apply_kernel; layerspp.py:152-173, :530-535) -- instead of
  *         gn_finalize + spade_apply; bit-identical; measured -1 ... +0.7 % end to end on config 4 (profiles/r05_spade_fusion_ab.txt): off.  "spade_fuse_auto" (1): the autotuner also times, per SPADE-normed 3x3 layer,

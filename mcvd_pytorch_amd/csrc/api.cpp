@@ -314,6 +314,8 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     ++ctx->epoch;                  // captured graphs embed the kernels the options select
     if (!strcmp(key, "naive_conv")) ctx->naive_conv = value;
     else if (!strcmp(key, "naive_attn")) ctx->naive_attn = value;
+    else if (!strcmp(key, "fir_form")) ctx->fir_form = value;
+    else if (!strcmp(key, "dbg_skip_finalize")) ctx->dbg_skip_finalize = value;
     else if (!strcmp(key, "graph")) ctx->graph = value;
     else if (!strcmp(key, "conv_shape")) ctx->conv_shape = value;
     else if (!strcmp(key, "conv_shape1")) ctx->conv_shape1 = value;
@@ -1150,7 +1152,7 @@ int mcvd_op_attention(mcvd_ctx* ctx, const float* qkv, float* out, int B, int C,
 
 int mcvd_op_fir2(mcvd_ctx* ctx, const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W) {
     MCVD_REQUIRE(ctx && x && y, "op_fir2: NULL argument");
-    return launch_fir2(x, coef, act, up, y, B, C, H, W, nullptr, nullptr, nullptr, nullptr, ctx->stream);
+    return launch_fir2(x, coef, act, up, y, B, C, H, W, nullptr, nullptr, nullptr, nullptr, ctx->stream, ctx->fir_form);
 }
 
 }  // extern "C"

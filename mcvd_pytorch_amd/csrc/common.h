@@ -191,8 +191,9 @@ int launch_attention_h2p(const float* qkv, const float* kv_img, float* out, int 
 int launch_attention(int mode, int f16x2, int bf16x3, const float* qkv, float* out, int B, int C, int heads, int HW, hipStream_t s);
 
 // ------------------------------------------------------------------ FIR resampling
+// form 0: the LDS-strip kernels where their geometry applies (power-of-two widths 8..256), else the register forms; 1: register forms only
 int launch_fir2(const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W,
-                const float* gamma, const float* beta, const float* coef2, float* y_raw, hipStream_t s);
+                const float* gamma, const float* beta, const float* coef2, float* y_raw, hipStream_t s, int form = 0);
 int launch_upfirdn2d(const float* in, const float* kernel_dev, int kh, int kw, int up, int down, int pad0, int pad1,
                      float* out, int NC, int H, int W, int oh, int ow, hipStream_t s);
 int launch_spade_apply(const float* x0, int C0, const float* x1, int C1, const float* coef, const float* gb,

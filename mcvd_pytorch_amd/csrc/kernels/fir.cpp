@@ -15,6 +15,22 @@ struct FirArgs {
 
 struct V2 { float h, r; };    // (prologue-transformed, raw)
 
+// The arithmetic of the resamplers, spelled out so that every form below (element-wise, register window, LDS strip) rounds alike
+// whatever the compiler would contract: the kernel a shape takes may differ between batch sizes (strip geometry), the bits must not.
+__device__ __forceinline__ float fir_pro(const FirArgs& a, float v, float cA, float cB, float g, float bt, float sA, float sB);
+__device__ __forceinline__ float fir_mix(float wa, float pa, float wb, float pb) {      // wa * pa + wb * pb
+#pragma clang fp contract(off)
+    const float t = wb * pb;
+    return __builtin_fmaf(wa, pa, t);
+}
+__device__ __forceinline__ float fir_1331(float p0, float p1, float p2, float p3) {      // (p0 + 3 p1 + 3 p2 + p3) / 8
+#pragma clang fp contract(off)
+    float t = __builtin_fmaf(3.0f, p1, p0);
+    t = __builtin_fmaf(3.0f, p2, t);
+    t = t + p3;
+    return t * 0.125f;
+}
+
 // (transformed, raw) value of the input plane at (yy, xx); zero outside (padding applies after the activation)
 __device__ __forceinline__ V2 fir_src(const FirArgs& a, const float* plane, long pidx, int yy, int xx, float cA,
                                       float cB, float sA, float sB) {
@@ -22,17 +38,27 @@ __device__ __forceinline__ V2 fir_src(const FirArgs& a, const float* plane, long
     if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) return o;
     float v = plane[yy * a.W + xx];
     o.r = v;
-    if (a.coef) v = v * cA + cB;
+    float g = 0.0f, bt = 0.0f;
     if (a.gamma) {
         const long bc = pidx / ((long)a.H * a.W);
         const long b = bc / a.C, c = bc - b * a.C;
         const long gi = ((b * 2 * a.C + c) * a.H + yy) * a.W + xx;
-        v = v * (1.0f + a.gamma[gi]) + a.beta[gi];
-        v = v * sA + sB;
+        g = a.gamma[gi]; bt = a.beta[gi];
+    }
+    o.h = fir_pro(a, v, cA, cB, g, bt, sA, sB);
+    return o;
+}
+
+__device__ __forceinline__ float fir_pro(const FirArgs& a, float v, float cA, float cB, float g, float bt, float sA, float sB) {
+#pragma clang fp contract(off)
+    if (a.coef) v = __builtin_fmaf(v, cA, cB);
+    if (a.gamma) {                                       // (1 + gamma) * normalised + beta, then the temb pair (layerspp.py:164-171)
+        const float g1 = 1.0f + g;
+        v = __builtin_fmaf(v, g1, bt);
+        v = __builtin_fmaf(v, sA, sB);
     }
     if (a.act) v = silu1(v);
-    o.h = v;
-    return o;
+    return v;
 }
 
 __global__ __launch_bounds__(256) void fir2_kernel(FirArgs a) {
@@ -60,17 +86,17 @@ __global__ __launch_bounds__(256) void fir2_kernel(FirArgs a) {
             for (int j = 0; j < 4; ++j) {
                 const int xx = nx0 - 1 + j;
                 const V2 p = fir_src(a, plane, pidx, ya, xx, cA, cB, sA, sB), q = fir_src(a, plane, pidx, yb, xx, cA, cB, sA, sB);
-                col[j] = wya * p.h + wyb * q.h;
-                colr[j] = wya * p.r + wyb * q.r;
+                col[j] = fir_mix(wya, p.h, wyb, q.h);
+                colr[j] = fir_mix(wya, p.r, wyb, q.r);
             }
-            o[0] = 0.25f * col[0] + 0.75f * col[1];
-            o[1] = 0.75f * col[1] + 0.25f * col[2];
-            o[2] = 0.25f * col[1] + 0.75f * col[2];
-            o[3] = 0.75f * col[2] + 0.25f * col[3];
-            r[0] = 0.25f * colr[0] + 0.75f * colr[1];
-            r[1] = 0.75f * colr[1] + 0.25f * colr[2];
-            r[2] = 0.25f * colr[1] + 0.75f * colr[2];
-            r[3] = 0.75f * colr[2] + 0.25f * colr[3];
+            o[0] = fir_mix(0.25f, col[0], 0.75f, col[1]);
+            o[1] = fir_mix(0.75f, col[1], 0.25f, col[2]);
+            o[2] = fir_mix(0.25f, col[1], 0.75f, col[2]);
+            o[3] = fir_mix(0.75f, col[2], 0.25f, col[3]);
+            r[0] = fir_mix(0.25f, colr[0], 0.75f, colr[1]);
+            r[1] = fir_mix(0.75f, colr[1], 0.25f, colr[2]);
+            r[2] = fir_mix(0.25f, colr[1], 0.75f, colr[2]);
+            r[3] = fir_mix(0.75f, colr[2], 0.25f, colr[3]);
         } else {
             // per axis: y[m] = (x[2m-1] + 3x[2m] + 3x[2m+1] + x[2m+2]) / 8
             float col[10], colr[10];
@@ -113,27 +139,21 @@ __global__ __launch_bounds__(256) void fir2_kernel(FirArgs a) {
 #pragma unroll
                     for (int j = 0; j < 10; ++j) {
                         const bool in = in_y && (j == 0 ? in_l : j == 9 ? in_r : true);
-                        float v = vals[j];
-                        if (a.coef) v = v * cA + cB;
-                        if (a.gamma) {                                   // fir_src's order
-                            v = v * (1.0f + gv[j]) + bv[j];
-                            v = v * sA + sB;
-                        }
-                        if (a.act) v = silu1(v);
+                        const float v = fir_pro(a, vals[j], cA, cB, a.gamma ? gv[j] : 0.0f, a.gamma ? bv[j] : 0.0f, sA, sB);
                         hv[r][j] = in ? v : 0.0f;
                         rv[r][j] = in ? vals[j] : 0.0f;
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 10; ++j) {
-                    col[j] = (hv[0][j] + 3.0f * hv[1][j] + 3.0f * hv[2][j] + hv[3][j]) * 0.125f;
-                    colr[j] = (rv[0][j] + 3.0f * rv[1][j] + 3.0f * rv[2][j] + rv[3][j]) * 0.125f;
+                    col[j] = fir_1331(hv[0][j], hv[1][j], hv[2][j], hv[3][j]);
+                    colr[j] = fir_1331(rv[0][j], rv[1][j], rv[2][j], rv[3][j]);
                 }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                o[k] = (col[2 * k] + 3.0f * col[2 * k + 1] + 3.0f * col[2 * k + 2] + col[2 * k + 3]) * 0.125f;
-                r[k] = (colr[2 * k] + 3.0f * colr[2 * k + 1] + 3.0f * colr[2 * k + 2] + colr[2 * k + 3]) * 0.125f;
+                o[k] = fir_1331(col[2 * k], col[2 * k + 1], col[2 * k + 2], col[2 * k + 3]);
+                r[k] = fir_1331(colr[2 * k], colr[2 * k + 1], colr[2 * k + 2], colr[2 * k + 3]);
             }
         }
         *reinterpret_cast<float4*>(a.y + (bc * OH + oy) * OW + ox0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -185,13 +205,7 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(FirArgs a) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const bool in = in_y && (j == 0 ? in_l : j == 5 ? in_r : true);
-                float v = vals[j];
-                if (a.coef) v = v * cA + cB;
-                if (a.gamma) {
-                    v = v * (1.0f + gv[j]) + bv[j];
-                    v = v * sA + sB;
-                }
-                if (a.act) v = silu1(v);
+                const float v = fir_pro(a, vals[j], cA, cB, a.gamma ? gv[j] : 0.0f, a.gamma ? bv[j] : 0.0f, sA, sB);
                 hv[r][j] = in ? v : 0.0f;
                 rv[r][j] = in ? vals[j] : 0.0f;
             }
@@ -203,16 +217,16 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(FirArgs a) {
             float col[6], colr[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                col[j] = rr == 0 ? 0.25f * hv[0][j] + 0.75f * hv[1][j] : 0.75f * hv[1][j] + 0.25f * hv[2][j];
-                colr[j] = rr == 0 ? 0.25f * rv[0][j] + 0.75f * rv[1][j] : 0.75f * rv[1][j] + 0.25f * rv[2][j];
+                col[j] = rr == 0 ? fir_mix(0.25f, hv[0][j], 0.75f, hv[1][j]) : fir_mix(0.75f, hv[1][j], 0.25f, hv[2][j]);
+                colr[j] = rr == 0 ? fir_mix(0.25f, rv[0][j], 0.75f, rv[1][j]) : fir_mix(0.75f, rv[1][j], 0.25f, rv[2][j]);
             }
             float o[8], r8[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                o[2 * k] = 0.25f * col[k] + 0.75f * col[k + 1];
-                o[2 * k + 1] = 0.75f * col[k + 1] + 0.25f * col[k + 2];
-                r8[2 * k] = 0.25f * colr[k] + 0.75f * colr[k + 1];
-                r8[2 * k + 1] = 0.75f * colr[k + 1] + 0.25f * colr[k + 2];
+                o[2 * k] = fir_mix(0.25f, col[k], 0.75f, col[k + 1]);
+                o[2 * k + 1] = fir_mix(0.75f, col[k + 1], 0.25f, col[k + 2]);
+                r8[2 * k] = fir_mix(0.25f, colr[k], 0.75f, colr[k + 1]);
+                r8[2 * k + 1] = fir_mix(0.75f, colr[k + 1], 0.25f, colr[k + 2]);
             }
             const long orow = (bc * 2 * a.H + 2 * ny + rr) * OW + 2 * nx0;
             *reinterpret_cast<float4*>(a.y + orow) = make_float4(o[0], o[1], o[2], o[3]);
@@ -225,10 +239,200 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(FirArgs a) {
     }
 }
 
+// ---- the two resamplers through the LDS (round 5).  The register forms above activate every input element once per thread whose window
+// holds it -- 4.5 x (up: 3 x 6 window per 4 inputs) and 2.5 x (down: 4 x 10 window per 4 outputs) the SiLU's exp + rcp, two quarter-rate
+// instructions, on kernels that should run at the HBM rate -- and read the window as 3-4 row requests per thread.  Here a workgroup takes a
+// strip of 1024 input elements (whole planes where a plane is smaller; R = 1024 / W rows of one plane otherwise), every thread loads ONE
+// aligned float4 (+ the strip's two halo rows by the first 2 W / 4 threads), applies the prologue ONCE and parks the result in the LDS
+// behind a zero frame; the FIR then reads its windows from the LDS with the operation order of the register forms (bit-identical) and
+// writes rows of consecutive float4 / float2.
+// rows of a plane per strip, planes per strip, LDS row pitch, LDS rows per plane slot (R + 2), log2(W / 4), log2(R), strips per plane
+struct FirStrip { int R, P, pitch, rows, lw4, lr, spp; };
+
+__device__ __forceinline__ float4 fir_act4(const FirArgs& a, float4 v, long goff, float cA, float cB, float sA, float sB, const float* gpl,
+                                           const float* bpl) {
+    float e[4] = {v.x, v.y, v.z, v.w};
+    float g[4] = {0.f, 0.f, 0.f, 0.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.gamma) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gpl + goff), b4 = *reinterpret_cast<const float4*>(bpl + goff);
+        g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w; bt[0] = b4.x; bt[1] = b4.y; bt[2] = b4.z; bt[3] = b4.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = fir_pro(a, e[j], cA, cB, g[j], bt[j], sA, sB);
+    return make_float4(e[0], e[1], e[2], e[3]);
+}
+
+// one aligned float4 of plane `plane` at element offset off: (prologue-transformed, raw)
+__device__ __forceinline__ void fir_load4(const FirArgs& a, unsigned plane, long off, float4* h, float4* r) {
+    const long HW = (long)a.H * a.W;
+    *r = *reinterpret_cast<const float4*>(a.x + plane * HW + off);
+    float cA = 1.f, cB = 0.f, sA = 1.f, sB = 0.f;
+    if (a.coef) { const float2 c = *reinterpret_cast<const float2*>(a.coef + 2L * plane); cA = c.x; cB = c.y; }
+    if (a.coef2) { const float2 c = *reinterpret_cast<const float2*>(a.coef2 + 2L * plane); sA = c.x; sB = c.y; }
+    const float* gpl = nullptr; const float* bpl = nullptr;
+    if (a.gamma) {
+        const unsigned b = plane / (unsigned)a.C, c = plane - b * (unsigned)a.C;
+        gpl = a.gamma + ((long)b * 2 * a.C + c) * HW; bpl = a.beta + ((long)b * 2 * a.C + c) * HW;
+    }
+    *h = fir_act4(a, *r, off, cA, cB, sA, sB, gpl, bpl);
+}
+
+// fills the strip's LDS image(s): sh = prologue-transformed, shr = raw (RAW only).  Row l of plane slot p sits at (p * rows + l) * pitch,
+// l = 0 / R + 1 the halo rows; column x at + 4 + x, the zero frame at + 3 and + 4 + W.  plane0 / r0: first plane and first row of the strip.
+template <bool RAW, int NL>
+__device__ __forceinline__ void fir_strip_fill(const FirArgs& a, const FirStrip& st, unsigned plane0, int r0, float* sh, float* shr) {
+    const int tid = threadIdx.x;
+    const int W4 = 1 << st.lw4;
+    float4 h[NL], r[NL];
+    int l[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {   // interior: thread -> NL x (plane slot, row, float4 column); all the loads of a thread in flight together
+        const int i = k * 256 + tid;
+        const int c4 = i & (W4 - 1), rr = (i >> st.lw4) & (st.R - 1), p = i >> (st.lw4 + st.lr);
+        fir_load4(a, plane0 + p, (long)(r0 + rr) * a.W + c4 * 4, &h[k], &r[k]);
+        l[k] = (p * st.rows + rr + 1) * st.pitch + 4 + c4 * 4;
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        *reinterpret_cast<float4*>(sh + l[k]) = h[k];
+        if (RAW) *reinterpret_cast<float4*>(shr + l[k]) = r[k];
+    }
+    if (tid < 2 * st.P * W4) {   // halo rows: 2 per plane slot; outside the image -> zeros
+        const int c4 = tid & (W4 - 1), which = (tid >> st.lw4) & 1, p = tid >> (st.lw4 + 1);
+        const int yy = which ? r0 + st.R : r0 - 1;
+        float4 hh = make_float4(0.f, 0.f, 0.f, 0.f), rh = hh;
+        if (yy >= 0 && yy < a.H) fir_load4(a, plane0 + p, (long)yy * a.W + c4 * 4, &hh, &rh);
+        const int lh = (p * st.rows + (which ? st.R + 1 : 0)) * st.pitch + 4 + c4 * 4;
+        *reinterpret_cast<float4*>(sh + lh) = hh;
+        if (RAW) *reinterpret_cast<float4*>(shr + lh) = rh;
+    }
+}
+
+// value of the lane below / above in the wave (the strip's rows are power-of-two runs of lanes: the caller masks the row ends)
+__device__ __forceinline__ float lane_prev(float v) { return __shfl_up(v, 1); }
+__device__ __forceinline__ float lane_next(float v) { return __shfl_down(v, 1); }
+
+template <int NL>
+__global__ __launch_bounds__(256) void fir_up2_lds_kernel(FirArgs a, FirStrip st, unsigned nstrips) {
+    extern __shared__ __attribute__((aligned(16))) float fir_sh[];
+    const int OW = 2 * a.W, OC4 = a.W >> 1;               // output float4 columns per row
+    for (unsigned strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const unsigned plane0 = st.P > 1 ? strip * st.P : strip / (unsigned)st.spp;
+        const int r0 = st.P > 1 ? 0 : (int)(strip - plane0 * st.spp) * st.R;
+        fir_strip_fill<false, NL>(a, st, plane0, r0, fir_sh, nullptr);
+        __syncthreads();
+        // item -> (plane slot, input row ny, output float4 column): output rows 2 ny, 2 ny + 1, columns 4 oc4 .. 4 oc4 + 3 from input
+        // rows ny - 1 .. ny + 1, columns 2 oc4 - 1 .. 2 oc4 + 2: one aligned float2 per row, the outer two columns from the neighbour lanes
+#pragma unroll
+        for (int k = 0; k < 2 * NL; ++k) {
+            const int it = k * 256 + threadIdx.x;
+            const int oc4 = it & (OC4 - 1), ny = (it >> (st.lw4 + 1)) & (st.R - 1), p = it >> (st.lw4 + 1 + st.lr);
+            const float* base = fir_sh + (p * st.rows + ny) * st.pitch + 4 + 2 * oc4;       // row ny - 1, column 2 oc4
+            float hv[3][4];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float2 q = *reinterpret_cast<const float2*>(base + r * st.pitch);
+                const float lo = lane_prev(q.y), hi = lane_next(q.x);
+                hv[r][0] = oc4 == 0 ? 0.0f : lo; hv[r][1] = q.x; hv[r][2] = q.y; hv[r][3] = oc4 == OC4 - 1 ? 0.0f : hi;
+            }
+            float* orow = a.y + ((long)(plane0 + p) * 2 * a.H + 2 * (r0 + ny)) * OW + 4 * oc4;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                float col[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    col[j] = rr == 0 ? fir_mix(0.25f, hv[0][j], 0.75f, hv[1][j]) : fir_mix(0.75f, hv[1][j], 0.25f, hv[2][j]);
+                const float4 o = make_float4(fir_mix(0.25f, col[0], 0.75f, col[1]), fir_mix(0.75f, col[1], 0.25f, col[2]),
+                                             fir_mix(0.25f, col[1], 0.75f, col[2]), fir_mix(0.75f, col[2], 0.25f, col[3]));
+                *reinterpret_cast<float4*>(orow + rr * OW) = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NL>
+__global__ __launch_bounds__(256) void fir_down2_lds_kernel(FirArgs a, FirStrip st, unsigned nstrips) {
+    extern __shared__ __attribute__((aligned(16))) float fir_sh[];
+    const int OH = a.H >> 1, OW = a.W >> 1, OC2 = a.W >> 2;       // output float2 columns per row
+    float* shr = fir_sh + st.P * st.rows * st.pitch;
+    for (unsigned strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const unsigned plane0 = st.P > 1 ? strip * st.P : strip / (unsigned)st.spp;
+        const int r0 = st.P > 1 ? 0 : (int)(strip - plane0 * st.spp) * st.R;
+        if (a.y_raw) fir_strip_fill<true, NL>(a, st, plane0, r0, fir_sh, shr);
+        else fir_strip_fill<false, NL>(a, st, plane0, r0, fir_sh, nullptr);
+        __syncthreads();
+        // waves 0, 1: the transformed tensor, waves 2, 3: the raw one; item -> (plane slot, output row, output float2 column):
+        // outputs (oy, 2 oc2), (oy, 2 oc2 + 1) from input rows 2 oy - 1 .. 2 oy + 2, columns 4 oc2 - 1 .. 4 oc2 + 4: one aligned
+        // float4 per row, the outer two columns from the neighbour lanes
+        const int half = threadIdx.x >> 7;
+        if (half == 0 || a.y_raw) {
+#pragma unroll 1
+            for (int k = 0; k < NL; ++k) {
+                const int it = k * 128 + (threadIdx.x & 127);
+                const int oc2 = it & (OC2 - 1), oyl = (it >> st.lw4) & ((st.R >> 1) - 1), p = it >> (st.lw4 + st.lr - 1);
+                const float* base = (half ? shr : fir_sh) + (p * st.rows + 2 * oyl) * st.pitch + 4 + 4 * oc2;    // row 2 oy - 1, column 4 oc2
+                float w[4][6];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 q = *reinterpret_cast<const float4*>(base + r * st.pitch);
+                    const float lo = lane_prev(q.w), hi = lane_next(q.x);
+                    w[r][0] = oc2 == 0 ? 0.0f : lo; w[r][1] = q.x; w[r][2] = q.y; w[r][3] = q.z; w[r][4] = q.w; w[r][5] = oc2 == OC2 - 1 ? 0.0f : hi;
+                }
+                float col[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) col[j] = fir_1331(w[0][j], w[1][j], w[2][j], w[3][j]);
+                const float2 o = make_float2(fir_1331(col[0], col[1], col[2], col[3]), fir_1331(col[2], col[3], col[4], col[5]));
+                *reinterpret_cast<float2*>((half ? a.y_raw : a.y) + ((long)(plane0 + p) * OH + (r0 >> 1) + oyl) * OW + 2 * oc2) = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// strip geometry of the LDS forms, or false where they do not apply (the register forms above take those)
+static bool fir_strip_geometry(int up, int nl, long planes, int H, int W, bool raw, FirStrip* st, unsigned* nstrips) {
+    if (W < 8 || W > (up ? 128 : 256) || (W & (W - 1)) || H < 2 || (up && raw)) return false;     // (a row of items = at most one wave)
+    const long HW = (long)H * W;
+    const int E = 1024 * nl;                          // input elements of a strip: nl aligned float4 per thread
+    int R, P;
+    if (HW <= E) {
+        if (E % HW) return false;
+        P = (int)(E / HW); R = H;
+        if (planes % P) return false;
+    } else {
+        P = 1; R = E / W;
+        if (H % R) return false;
+    }
+    if (R & (R - 1)) return false;                    // (whole planes of a non-power-of-two height: the register forms)
+    if (!up && R < 2) return false;
+    const long n = P > 1 ? planes / P : planes * (H / R);
+    if (n >= (1L << 31) || planes >= (1L << 31)) return false;
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    st->R = R; st->P = P; st->rows = R + 2; st->pitch = W + 8; st->lw4 = lg(W / 4); st->lr = lg(R); st->spp = P > 1 ? 1 : H / R;
+    *nstrips = (unsigned)n;
+    return true;
+}
+
 int launch_fir2(const float* x, const float* coef, int act, int up, float* y, int B, int C, int H, int W,
-                const float* gamma, const float* beta, const float* coef2, float* y_raw, hipStream_t s) {
+                const float* gamma, const float* beta, const float* coef2, float* y_raw, hipStream_t s, int form) {
     MCVD_REQUIRE((up ? W * 2 : W / 2) % 4 == 0 && H % 2 == 0, "fir2: H=%d W=%d unsupported", H, W);
     FirArgs a{x, coef, act, up, y, B, C, H, W, y_raw, gamma, beta, coef2};
+    FirStrip st; unsigned nstrips = 0;
+    // strips of 2048 elements for the down kernel (it reads 4 bytes for every 2 it writes: two loads per thread in flight -- 1024-element
+    // strips measured 3.1 TB/s on the 64 x 64 layer, latency-bound), 1024 for the up kernel (write-bound: 5.4 TB/s)
+    int nl = up ? 1 : 2;
+    bool ok = form == 0 && fir_strip_geometry(up, nl, (long)B * C, H, W, y_raw != nullptr, &st, &nstrips);
+    if (!ok && form == 0 && nl == 2) { nl = 1; ok = fir_strip_geometry(up, nl, (long)B * C, H, W, y_raw != nullptr, &st, &nstrips); }
+    if (ok) {
+        const size_t lds = (size_t)st.P * st.rows * st.pitch * sizeof(float) * (y_raw ? 2 : 1);
+        const int blocks = (int)(nstrips > 65536u ? 65536u : nstrips);
+        if (up) hipLaunchKernelGGL(fir_up2_lds_kernel<1>, dim3(blocks), dim3(256), lds, s, a, st, nstrips);
+        else if (nl == 2) hipLaunchKernelGGL(fir_down2_lds_kernel<2>, dim3(blocks), dim3(256), lds, s, a, st, nstrips);
+        else hipLaunchKernelGGL(fir_down2_lds_kernel<1>, dim3(blocks), dim3(256), lds, s, a, st, nstrips);
+        MCVD_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (up && W % 4 == 0) {
         const long n = (long)B * C * H * (W / 4);
         const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);

@@ -666,6 +666,10 @@ int mcvd_model::launch_gn(const Op& op, const float* x, const void* lab, const f
                 return 0;
             }
         }
+        // timing-only ablation (option "dbg_skip_finalize", WRONG results after the first step): the captured graph carries no finalize
+        // launch -- the table keeps the values of the eager first forward.  The upper bound of what ANY scheme that removes these launches
+        // (producer-side last arriver, consumer-side reduction) can gain (profiles/r05_tail_launch_bound.txt).
+        if (ctx->dbg_skip_finalize && op_stream) return 0;
         return launch_gn_finalize(a, resolve(ops[op.prod0].stats, x, cond, out, B), np0,
                                   a.C1 ? resolve(ops[op.prod1].stats, x, cond, out, B) : nullptr, np1, s);
     }
@@ -858,7 +862,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                                resolve(op.dst, x, cond, out, B), B, op.src0.C, op.H, op.W, gb,
                                gb ? gb + (size_t)op.src0.C * op.H * op.W : nullptr,
                                op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B),
-                               op.dst2.kind == REF_NONE ? nullptr : resolve(op.dst2, x, cond, out, B), s);
+                               op.dst2.kind == REF_NONE ? nullptr : resolve(op.dst2, x, cond, out, B), s, ctx->fir_form);
         }
         case OP_NEAREST:
             MCVD_REQUIRE(cond, "forward: SPADE model needs the conditioning tensor");

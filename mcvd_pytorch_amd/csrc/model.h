@@ -14,6 +14,8 @@ struct mcvd_ctx {
     hipStream_t stream = nullptr;
     int naive_conv = 0;
     int naive_attn = 0;
+    int dbg_skip_finalize = 0; // timing-only: no gn_finalize launches inside a captured graph (wrong results)
+    int fir_form = 0;          // 0: FIR x2 resamplers through the LDS where the geometry applies; 1: register forms only (A/B)
     int graph = 0;                 // 1: replay each forward as a hipGraph (captured on the second use of the same
                                    //    (x, labels, cond, out, B) pointer set; the sampler loop reuses one set for all steps)
     hipStream_t cap = nullptr;     // private capture stream (the caller's stream may be the legacy default stream, which

@@ -742,6 +742,41 @@ def test_fir2(ctx, up, pro):
     _close(got, want, rtol=1e-5, atol=2e-6, what="fir2")
 
 
+@pytest.mark.parametrize("up", [0, 1])
+@pytest.mark.parametrize("B,C,H", [(3, 12, 16), (2, 16, 8), (2, 6, 32), (1, 3, 64), (1, 2, 128), (2, 5, 16)])
+def test_fir2_lds_strip_form_is_bit_identical(ctx, up, B, C, H):
+    """The x2 resamplers through the LDS (round 5: one aligned float4 per thread, prologue applied once per element, windows from the LDS)
+    against the register forms (option fir_form = 1) they replace: same operation order, torch.equal; and against the oracle.  (2, 5, 16):
+    10 planes do not fill strips of 4 planes -- the geometry refuses and the register form runs under either option."""
+    g = _g(4)
+    x = torch.randn(B, C, H, H, generator=g)
+    coef = torch.stack([1 + 0.3 * torch.randn(B, C, generator=g), 0.3 * torch.randn(B, C, generator=g)], dim=-1)
+    for pro in (0, 1):
+        xin = unet_ref.silu(x * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]) if pro else x
+        want = unet_ref.fir_up2(xin) if up else unet_ref.fir_down2(xin)
+        ctx.opt("fir_form", 0)
+        got = ctx.fir2(x.cuda(), up, coef=coef.cuda() if pro else None, act=pro)
+        ctx.opt("fir_form", 1)
+        old = ctx.fir2(x.cuda(), up, coef=coef.cuda() if pro else None, act=pro)
+        ctx.opt("fir_form", 0)
+        assert torch.equal(got, old), f"LDS strip form differs from the register form: {float((got - old).abs().max()):.3e}"
+        _close(got, want, rtol=1e-5, atol=2e-6, what="fir2")
+
+
+@pytest.mark.parametrize("cfg,B", [("tiny", 3), ("tiny_spade", 2), ("smmnist_big5_ngf96", 2)])
+def test_fir2_lds_strip_form_in_the_network(cfg, B):
+    """The same A/B through a whole forward: the down blocks take the two-output form (FIR(act(norm(x))) and FIR(x) from one read), SPADE
+    configs the gamma | beta prologue (layerspp.py:600-601, up_or_down_sampling.py:196-258)."""
+    config, sd, net = _net(cfg)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = torch.tensor([700, 20, 333][:B]).cuda()
+    a = net(x.cuda(), t, cond=cond.cuda()).clone()
+    net.set_option("fir_form", 1)
+    b = net(x.cuda(), t, cond=cond.cuda()).clone()
+    net.set_option("fir_form", 0)
+    assert torch.equal(a, b), f"LDS strip FIR differs from the register forms: {float((a - b).abs().max()):.3e}"
+
+
 def test_upfirdn2d_against_reference_golden(ctx, golden_dir):
     """The reference's own native op (op/upfirdn2d.py:163-204), fixtures from upfirdn2d_native."""
     g = torch.load(os.path.join(golden_dir, "fir.pt"), weights_only=False)
