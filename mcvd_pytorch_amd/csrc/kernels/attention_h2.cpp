@@ -43,6 +43,56 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float AH_P_LOG = 8.317766166719343f;        // 12 ln 2: NP = 2 probabilities times 2^12
+// NP = 3 softmax (round 5): Q enters the S product times D^-0.5 log2(e), so the scores arrive in the base-2 exponent domain -- no score
+// scaling, no multiply inside the exponential (32 of the ~240 VALU instructions a wave issued per key tile) -- and the running
+// reference of the exponent is LAZY: O and l are rescaled only when a tile's maximum exceeds the reference by more than 2^AH_LAZY
+// (wave-uniform branch; in practice the first tile only), not by exp(m_old - m_new) on every tile (48 + multiplies per tile at D = 96).
+// Probabilities then range up to 2^AH_LAZY instead of 1 -- the three bf16 pieces carry the fp32 exponent, the row sum carries the same
+// factor and it cancels in O / l; the global maximum's own term is >= 1 (the reference never exceeds a tile maximum), so l cannot
+// underflow.  Same accuracy, different rounding than exp(s - m_running).  Measured: attention -1.3 ... -3.2 % (the kernel is not bound by
+// its VALU count, nor -- each ablated or A/B-ed on the same box -- by the DMA prefetch depth, the V operand reads' latency, the LDS
+// operand traffic or the wave priorities: profiles/r05_attention_experiments.txt).
+constexpr float AH_LOG2E = 1.4426950408889634f;
+constexpr float AH_LAZY = 40.0f;
+
+// the NP = 3 online softmax of one key tile: st = scores (base-2 domain) -> probabilities relative to the lazy reference m_run;
+// o / l_run rescaled only when some lane's tile maximum outgrows its reference (alpha == 1 exactly for the lanes that do not need it)
+#ifdef MCVD_AH_EAGER      /* A/B build only (tools/build_variant.sh): round 4's softmax, exp(s - m_running) with the rescale on every tile */
+#define AH_SOFTMAX_LAZY                                                                                            \
+    {                                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) { st[r] *= scale_s; mt = fmaxf(mt, st[r]); }               \
+        mt = fmaxf(mt, __shfl_xor(mt, 32));                                                                        \
+        const float m_new = fmaxf(m_run, mt);                                                                      \
+        const float alpha = __expf(m_run - m_new);                                                                 \
+        const float shift = 0.0f - m_new;                                                                          \
+        float ps = 0.0f;                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) { st[r] = __expf(st[r] + shift); ps += st[r]; }            \
+        l_run = l_run * alpha + ps;                                                                                \
+        m_run = m_new;                                                                                             \
+        _Pragma("unroll") for (int ct = 0; ct < DT; ++ct)                                                          \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;                                      \
+    }
+#define AH_QS(scale_s) 1.0f
+#else
+#define AH_SOFTMAX_LAZY                                                                                            \
+    {                                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[r]);                                      \
+        mt = fmaxf(mt, __shfl_xor(mt, 32));                                                                        \
+        const bool need = mt > m_run + AH_LAZY;                                                                    \
+        if (__builtin_amdgcn_ballot_w64(need)) {                                                                   \
+            const float m_new = need ? mt : m_run;                                                                 \
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                             \
+            l_run *= alpha;                                                                                        \
+            _Pragma("unroll") for (int ct = 0; ct < DT; ++ct)                                                      \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;                                  \
+            m_run = m_new;                                                                                         \
+        }                                                                                                          \
+        float ps = 0.0f;                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_run); ps += st[r]; } \
+        l_run += ps;                                                                                               \
+    }
+#define AH_QS(scale_s) ((scale_s) * AH_LOG2E)
+#endif
 
 template <int NP, int DT>   // head dim D = 32*DT
 __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int heads, int S,
@@ -72,6 +122,7 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
     const bool active = q0 < S;
 
     // Q pieces: lane (query l31, half) holds channels 16 st + 2e + half, e = 0..7 of every step; dword j = elements (2j, 2j+1)
+    const float qs = NP == 3 ? AH_QS(scale_s) : OPS;              // NP = 3: the score scale and log2(e) ride on Q (see AH_LAZY)
     u32x4 qp[NST][NP];
 #pragma unroll
     for (int st = 0; st < NST; ++st)
@@ -81,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
             const float a0 = active ? qb[(long)c0 * S + q0 + l31] : 0.0f;
             const float a1 = active ? qb[(long)(c0 + 2) * S + q0 + l31] : 0.0f;
             unsigned w[NP];
-            PX::template split<false>(a0 * OPS, a1 * OPS, w);
+            PX::template split<false>(a0 * qs, a1 * qs, w);
 #pragma unroll
             for (int p = 0; p < NP; ++p) qp[st][p][j] = w[p];
         }
@@ -166,21 +217,25 @@ __global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict
 
         // ---- online softmax over keys (this lane: 16 keys of query l31; partner lane^32 holds the other 16); NP = 2: p times 2^12
         float mt = -1e30f;
+        if constexpr (NP == 3) {
+            AH_SOFTMAX_LAZY
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { st[r] *= scale_s; mt = fmaxf(mt, st[r]); }
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __expf(m_run - m_new);
-        const float shift = (NP == 2 ? AH_P_LOG : 0.0f) - m_new;
-        float ps = 0.0f;
+            for (int r = 0; r < 16; ++r) { st[r] *= scale_s; mt = fmaxf(mt, st[r]); }
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __expf(m_run - m_new);
+            const float shift = AH_P_LOG - m_new;
+            float ps = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { st[r] = __expf(st[r] + shift); ps += st[r]; }
-        l_run = l_run * alpha + ps;               // per-half partial sum; halves are added at the end
-        m_run = m_new;
+            for (int r = 0; r < 16; ++r) { st[r] = __expf(st[r] + shift); ps += st[r]; }
+            l_run = l_run * alpha + ps;               // per-half partial sum; halves are added at the end
+            m_run = m_new;
 #pragma unroll
-        for (int ct = 0; ct < DT; ++ct)
+            for (int ct = 0; ct < DT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        }
         u32x4 pp[2][NP];                          // B operand of the PV product: step s2, dword j = registers 8 s2 + 2j, + 1
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
@@ -279,6 +334,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_h2p_kernel(const float* __res
     };
     dma(0);
 
+    const float qs = AH_QS(scale_s);                // as attn_h2_kernel<3, DT>: bit-identical to it
     u32x4 qp[NST][NP];
 #pragma unroll
     for (int st = 0; st < NST; ++st)
@@ -288,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_h2p_kernel(const float* __res
             const float a0 = active ? qb[(long)c0 * S + q0 + l31] : 0.0f;
             const float a1 = active ? qb[(long)(c0 + 2) * S + q0 + l31] : 0.0f;
             unsigned w[NP];
-            PX::template split<false>(a0, a1, w);
+            PX::template split<false>(a0 * qs, a1 * qs, w);
 #pragma unroll
             for (int p = 0; p < NP; ++p) qp[st][p][j] = w[p];
         }
@@ -327,21 +383,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_h2p_kernel(const float* __res
         }
 
         float mt = -1e30f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { st[r] *= scale_s; mt = fmaxf(mt, st[r]); }
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __expf(m_run - m_new);
-        const float shift = 0.0f - m_new;
-        float ps = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { st[r] = __expf(st[r] + shift); ps += st[r]; }
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
-#pragma unroll
-        for (int ct = 0; ct < DT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        AH_SOFTMAX_LAZY
         u32x4 pp[2][NP];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)

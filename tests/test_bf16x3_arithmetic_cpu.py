@@ -165,3 +165,64 @@ def test_two_piece_fp16_is_measurably_worse_on_structured_data(kind):
     e3 = _representation_error(split3(u)[:3], split3(v)[:3], PRODUCTS, u, v)
     assert e3.max() < 2.0 ** -23.4
     assert np.median(e3) * 4 < np.median(e2) and e3.max() * 2 < e2.max(), (np.median(e3), np.median(e2), e3.max(), e2.max())
+
+
+# ---- the lazy exponent reference of the three-piece attention kernel (attention_h2.cpp AH_SOFTMAX_LAZY), restated in fp32 numpy
+def lazy_softmax_rows(scores2, v, lazy=40.0, tile=32):
+    """scores2: [queries, keys] in the base-2 exponent domain (fp32), v: [keys, channels].  One row per 'lane': the reference m moves
+    only when a tile's maximum exceeds it by more than `lazy`; O and l carry 2^(m_true - m) until the final division."""
+    nq, nk = scores2.shape
+    m = np.full(nq, -1e30, np.float32)
+    l = np.zeros(nq, np.float32)
+    o = np.zeros((nq, v.shape[1]), np.float32)
+    rescales = 0
+    for t in range(0, nk, tile):
+        st = scores2[:, t:t + tile].astype(np.float32)
+        mt = st.max(1)
+        need = mt > m + np.float32(lazy)
+        if need.any():
+            rescales += 1
+            m_new = np.where(need, mt, m).astype(np.float32)
+            alpha = np.exp2((m - m_new).astype(np.float32)).astype(np.float32)
+            assert np.all(alpha[~need] == 1.0)
+            l = (l * alpha).astype(np.float32)
+            o = (o * alpha[:, None]).astype(np.float32)
+            m = m_new
+        p = np.exp2((st - m[:, None]).astype(np.float32)).astype(np.float32)
+        assert np.isfinite(p).all() and p.max() <= 2.0 ** (lazy + 1e-3)
+        l = (l + p.sum(1, dtype=np.float32)).astype(np.float32)
+        o = (o + p @ v[t:t + tile].astype(np.float32)).astype(np.float32)
+    return o / l[:, None], rescales
+
+
+@pytest.mark.parametrize("pattern", ["ramp_up", "ramp_down", "spike_late", "flat", "huge_first", "gauss"])
+def test_lazy_softmax_reference_is_softmax(pattern):
+    """The recurrence keeps  O / l == softmax(s) V  whatever the reference does: the factor 2^(m_true - m) is common to O and l.  The
+    global maximum's own term is >= 1 (the reference never exceeds a tile maximum), so l cannot underflow; probabilities stay below
+    2^40 (finite in fp32, exactly splittable into three bf16 pieces); and the rescale fires on the first tile and then only when the
+    scores really move (ramp: every second tile; Gaussian scores: once)."""
+    rng = np.random.default_rng(5)
+    nq, nk, D = 32, 1024, 16
+    tile = np.arange(nk) // 32
+    if pattern == "ramp_up":
+        prof = 30.3 * tile + rng.standard_normal(nk)
+    elif pattern == "ramp_down":
+        prof = -30.3 * tile + rng.standard_normal(nk)
+    elif pattern == "spike_late":
+        prof = rng.standard_normal(nk); prof[nk - 3] = 430.0
+    elif pattern == "flat":
+        prof = np.full(nk, 7.0)
+    elif pattern == "huge_first":
+        prof = rng.standard_normal(nk); prof[:32] += 290.0
+    else:
+        prof = 3.0 * rng.standard_normal(nk)
+    s2 = (prof[None, :] + 0.3 * rng.standard_normal((nq, nk))).astype(np.float32)
+    v = rng.standard_normal((nk, D)).astype(np.float32)
+    got, rescales = lazy_softmax_rows(s2, v)
+    s64 = s2.astype(np.float64) * np.log(2.0)
+    w = np.exp(s64 - s64.max(1, keepdims=True)); w /= w.sum(1, keepdims=True)
+    want = w @ v.astype(np.float64)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    expect = {"ramp_up": (12, 32), "ramp_down": (1, 1), "spike_late": (2, 2), "flat": (1, 1), "huge_first": (1, 1), "gauss": (1, 1)}[pattern]
+    assert expect[0] <= rescales <= expect[1], rescales

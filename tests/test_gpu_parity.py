@@ -728,6 +728,49 @@ def test_attention(ctx, B, C, heads, H, naive):
     _close(got, want, what="attention")
 
 
+@pytest.mark.parametrize("pattern", ["ramp_up", "ramp_down", "spike_late", "flat", "huge_first"])
+@pytest.mark.parametrize("D", [32, 96, 128])
+def test_attention_lazy_softmax_reference(ctx, pattern, D):
+    """The three-piece attention kernel keeps a LAZY exponent reference (attention_h2.cpp AH_LAZY: O and l are rescaled only when a key
+    tile's maximum outgrows the reference by more than 2^40, the score scale and log2(e) ride on Q): scores built to walk the reference --
+    rising by ~30 (base 2) per key tile so that probabilities above 1 accumulate before a rescale triggers, falling, one late spike 300 above
+    everything, all equal, a first tile far above the rest -- against softmax in fp64 (layerspp.py:240-243)."""
+    g = _g(21)
+    B, heads, H = 2, 2, 16
+    S, C = H * H, heads * D
+    q = torch.zeros(B, C, S)
+    k = torch.zeros(B, C, S)
+    v = torch.randn(B, C, S, generator=g)
+    # scores[query, key] = scale * q0[query] * k0[key] with scale = D^-0.5 through channel 0 of every head; the other channels add noise
+    kk = torch.arange(S).float()
+    tile = (kk // 32)
+    if pattern == "ramp_up":
+        prof = 21.0 * tile + 0.5 * torch.randn(S, generator=g)          # natural-log units: 21 = 30.3 in base 2 per tile
+    elif pattern == "ramp_down":
+        prof = -21.0 * tile + 0.5 * torch.randn(S, generator=g)
+    elif pattern == "spike_late":
+        prof = torch.randn(S, generator=g); prof[S - 3] = 300.0
+    elif pattern == "flat":
+        prof = torch.full((S,), 7.0)
+    else:
+        prof = torch.randn(S, generator=g); prof[:32] += 200.0
+    for h in range(heads):
+        q[:, h * D] = (D ** 0.5)                                             # so that scale * q0 = 1
+        k[:, h * D] = prof
+        q[:, h * D + 1:(h + 1) * D] = 0.05 * torch.randn(B, D - 1, S, generator=g)
+        k[:, h * D + 1:(h + 1) * D] = 0.05 * torch.randn(B, D - 1, S, generator=g)
+    qkv = torch.cat([q, k, v], dim=1)
+    qd, kd, vd = (t.double().reshape(B * heads, D, S) for t in (q, k, v))
+    w = torch.softmax(torch.matmul(qd.transpose(1, 2), kd) * (D ** -0.5), dim=-1)
+    want = torch.matmul(vd, w.transpose(1, 2)).reshape(B, C, S).float()
+    ctx.opt("naive_attn", 4)
+    got = ctx.attention(qkv.cuda(), heads)
+    ctx.opt("naive_attn", 0)
+    assert torch.isfinite(got).all()
+    # scores of magnitude 200-300 carry half an fp32 ulp of 1e-5 each (in ANY fp32 evaluation of q . k): the weights inherit it
+    _close(got, want, what=f"attention ({pattern})")
+
+
 # ------------------------------------------------------------------------------------------------ FIR / upfirdn2d
 @pytest.mark.parametrize("up", [0, 1])
 @pytest.mark.parametrize("pro", [0, 1])
