@@ -179,8 +179,9 @@ def roofline_of_leg(net, args, B, arith_name):
                  for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     # ---- dominant kernel: the 3x3 convs, by the kernel family each layer REALLY ran
     FAM3 = {4: "wino_f32", 8: "wino_f32", 10: "wino_bf16x3", 11: "wino_bf16x3", 12: "wino_f16x2", 13: "wino_f16x2",
-            16: "wino_bf16x3", 17: "wino_bf16x3", 18: "wino_bf16x3", 19: "wino_bf16x3", 20: "wino_bf16x3"}          # 16 / 17: the same kernel as persistent workgroups (conv_wino3p.cpp)
-    fam = {k: dict(launches=0, ms=0.0, flops=0.0, bytes=0.0) for k in ("wino_f32", "wino_bf16x3", "wino_f16x2", "direct")}
+            16: "wino_bf16x3", 17: "wino_bf16x3", 18: "wino_bf16x3", 19: "wino_bf16x3", 20: "wino_bf16x3",          # 16 / 17: the same kernel as persistent workgroups (conv_wino3p.cpp)
+            22: "gemm_bf16x3", 23: "gemm_bf16x3"}                  # the stem / last conv as a 1x1 GEMM on the three-piece kernel (conv_gemm_forms.cpp)
+    fam = {k: dict(launches=0, ms=0.0, flops=0.0, bytes=0.0) for k in ("wino_f32", "wino_bf16x3", "wino_f16x2", "gemm_bf16x3", "direct")}
     k1 = {}
     for i in range(n):
         if kinds[i] != 3 or ms[i] == 0.0:
@@ -204,6 +205,8 @@ def roofline_of_leg(net, args, B, arith_name):
                         BF16_MFMA_PEAK_TFLOPS),
         "wino_f16x2": ("conv_wino2h_kernel (3x3 conv, Winograd F(2x2,3x3), operands split into 2 fp16 pieces = 22 significant bits, weights "
                        "pre-split at pack time, 3 piece products on v_mfma_f32_32x32x16_f16, fp32 accumulate)", 3.0 * 16.0 / 36.0, BF16_MFMA_PEAK_TFLOPS),
+        "gemm_bf16x3": ("conv1x1_h2_kernel behind an im2col / in front of a shift-and-add pass (3x3 conv with few channels on one side as a 1x1 "
+                        "GEMM, three bf16 pieces per operand, 6 piece products)", 6.0, BF16_MFMA_PEAK_TFLOPS),
         "direct": ("conv_mfma_kernel<3x3> (direct implicit GEMM, v_mfma_f32_32x32x2_f32)", 1.0, FP32_MFMA_PEAK_TFLOPS),
     }
     dom_name, mult_ratio, pipe_peak = FAMILY[dom_key]
@@ -259,7 +262,7 @@ def roofline_of_leg(net, args, B, arith_name):
                  "32..128) as SIX bf16 piece products of operands split EXACTLY into three bf16 pieces (all 24 bits, fp32 exponent range, less "
                  "than one fp32 rounding per product; tests/test_gpu_parity.py::test_conv_bf16x3_is_fp32_accurate, "
                  "test_default_kernels_have_the_fp32_range); the rest on the fp32 MFMA / fp32 VALU"
-                 % (fam["wino_bf16x3"]["launches"], c3["launches"], k1.get(15, 0), n1))
+                 % (fam["wino_bf16x3"]["launches"] + fam["gemm_bf16x3"]["launches"], c3["launches"], k1.get(15, 0), n1))
     else:
         arith = "f32 (fp32 MFMA / fp32 VALU everywhere)"
     return roofline, arith

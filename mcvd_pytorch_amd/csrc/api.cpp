@@ -538,6 +538,10 @@ int mcvd_model_finalize(mcvd_model* m) {
                 if (int rc = launch_pack_wino_weight(m->blob + w.off, m->packed + p.wpw, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
             if (p.wpb >= 0 && p.ks == 3)
                 if (int rc = launch_pack_wino3_weight(m->blob + w.off, m->packed + p.wpb, p.Cout_each, p.Cin, p.CinP, p.CoutP, s)) return rc;
+            if (p.alt_kind) {              // the conv's GEMM form: its fp32 matrix, then the three bf16 pieces of it (kernels/conv_gemm_forms.cpp)
+                if (int rc = launch_pack_conv_gemm_form(m->blob + w.off, m->packed + p.alt_wp, p.Cout_each, p.Cin, p.alt_kind, p.alt_CoutP, s)) return rc;
+                if (int rc = launch_pack_conv1x1_h2(m->packed + p.alt_wp, m->packed + p.alt_wpb, p.alt_CinP, p.alt_CoutP, s, 3)) return rc;
+            }
         }
         if (p.wpb >= 0 && p.ks == 1)           // from the packed fp32 matrix: every fused weight (q | k | v) and the padding are in place
             if (int rc = launch_pack_conv1x1_h2(m->packed + p.wp, m->packed + p.wpb, p.CinP, p.CoutP, s, 3)) return rc;
@@ -701,7 +705,7 @@ int mcvd_model_set_tuning(mcvd_model* m, int B, const int* shapes, const int* co
     MCVD_REQUIRE(n == (int)m->ops.size(), "set_tuning: %d entries for a plan of %d ops (tuning of another model?)", n, (int)m->ops.size());
     for (int i = 0; i < n; ++i) {
         const bool conv = m->ops[i].kind == OP_CONV;
-        MCVD_REQUIRE(conv ? (((shapes[i] >= -1 && shapes[i] <= 21) || shapes[i] == 36 || shapes[i] == 40) && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
+        MCVD_REQUIRE(conv ? (((shapes[i] >= -1 && shapes[i] <= 23) || shapes[i] == 36 || shapes[i] == 40) && cots[i] >= 0 && cots[i] <= 9) : shapes[i] == -1,
                      "set_tuning: entry %d (shape %d, cout tile %d) does not fit op kind %d", i, shapes[i], cots[i], (int)m->ops[i].kind);
     }
     if (m->ctx) m->sync_tuning_options();         // the table belongs to the options in force now; a later option change drops it

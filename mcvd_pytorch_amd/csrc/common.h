@@ -114,6 +114,10 @@ int launch_conv_naive(const ConvArgs& a, hipStream_t s);
 int last_conv_kernel();                       // kernel family of this thread's last launch_conv_mfma (see conv.cpp)
 // fp32 VALU direct conv for layers with at most 16 output channels (the network's last conv; conv_small_cout.cpp): tile shape id 21
 bool conv_small_cout_usable(const ConvArgs& a);
+// 3x3 convs with a handful of channels on one side as 1x1 GEMMs (conv_gemm_forms.cpp): shape ids 22 (taps as outputs + shift-and-add) / 23 (im2col)
+int launch_im2col3x3(const float* x0, int C0, const float* x1, int C1, float* col, int B, int H, int W, int K, hipStream_t s);
+int launch_taps_shift_add(const float* z, const float* bias, const float* res, float scale, float* y, int B, int Cout, int H, int W, hipStream_t s);
+int launch_pack_conv_gemm_form(const float* w, float* wp, int Cout, int Cin, int form, int CoutP, hipStream_t s);
 int launch_conv_small_cout(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2,3x3) kernel (conv_wino.cpp): tile shape id 4 of the dispatcher
 bool conv_wino_supported(int ks, int H, int W);      // geometry only (decides whether transformed weights are packed at all)

@@ -1,0 +1,117 @@
+// Two 3x3 convs of the network have almost no channels on one side -- the stem (5 + 5 frame channels -> ngf) and the last conv (ngf -> 5
+// or 15 frame channels) -- and the 3x3 kernels serve them badly: the direct fp32 kernel pads the stem's 10 input channels to 16 and runs
+// on the fp32 matrix pipe (110 us for a launch whose traffic is worth 20), the Winograd kernel stages all ngf input channels of the last
+// conv for a padded 32-cout tile (106 us).  Both are run as 1x1 GEMMs on the three-piece bf16 kernel (conv1x1_h2.cpp) instead
+// (ncsnpp_more.py: the first conv3x3 of all_modules and the last one; layerspp.py conv3x3 = layers.py:107-113):
+//   shape id 23, "im2col":  col[b][c * 9 + t][p] = x[b][c][p + offset(t)] (zero outside the image; rows up to a multiple of 16 zero), then
+//                           y = W' col + bias with W'[co][c * 9 + t] = W[co][c][t]  -- the GEMM's epilogue (residual, scale, GroupNorm
+//                           partials) is the conv's;
+//   shape id 22, "taps as outputs":  z[b][t * Cout + co][p] = sum_c W[co][c][t] x'[b][c][p]  (x' = the conv's prologue-transformed input:
+//                           the GEMM's prologue is the conv's), then  y[b][co][p] = bias[co] + sum_t z[b][t * Cout + co][p + offset(t)]
+//                           with z read as zero outside the image (the conv pads x' with zeros, and z is linear in x').
+// The products are the same fp32-equivalent six piece products; the summation order differs from the 3x3 kernels' (tolerance, not bits).
+#include "../common.h"
+
+namespace mcvd {
+
+// one thread per (b, k, 4 pixels): K rows of `col` per sample, rows >= 9 * (C0 + C1) are zero
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x0, int C0, const float* __restrict__ x1, int C1, float* __restrict__ col,
+                                                        int B, int H, int W, int K) {
+    const int W4 = W >> 2, HW = H * W;
+    const long n = (long)B * K * H * W4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int xq = (int)(i % W4) * 4;
+        const int y = (int)((i / W4) % H);
+        const int k = (int)((i / ((long)W4 * H)) % K);
+        const int b = (int)(i / ((long)W4 * H * K));
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = k / 9, t = k - 9 * c;
+        if (c < C0 + C1) {
+            const int yy = y + t / 3 - 1, dx = t % 3 - 1;
+            if (yy >= 0 && yy < H) {
+                const float* row = (c < C0 ? x0 + ((long)b * C0 + c) * HW : x1 + ((long)b * C1 + (c - C0)) * HW) + (long)yy * W;
+                if (dx == 0) {
+                    o = *reinterpret_cast<const float4*>(row + xq);
+                } else {
+                    const float4 q = *reinterpret_cast<const float4*>(row + xq);
+                    if (dx < 0) o = make_float4(xq > 0 ? row[xq - 1] : 0.0f, q.x, q.y, q.z);
+                    else o = make_float4(q.y, q.z, q.w, xq + 4 < W ? row[xq + 4] : 0.0f);
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(col + ((long)b * K + k) * HW + (long)y * W + xq) = o;
+    }
+}
+
+int launch_im2col3x3(const float* x0, int C0, const float* x1, int C1, float* col, int B, int H, int W, int K, hipStream_t s) {
+    MCVD_REQUIRE(W % 4 == 0 && K >= 9 * (C0 + C1), "im2col: W=%d K=%d", W, K);
+    const long n = (long)B * K * H * (W / 4);
+    const int blocks = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks), dim3(256), 0, s, x0, C0, x1, C1, col, B, H, W, K);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// one thread per (b, co, 4 pixels): nine shifted reads of z (row t * Cout + co of the sample's 9 * Cout rows), summed in tap order behind the bias
+__global__ __launch_bounds__(256) void taps_shift_add_kernel(const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ res,
+                                                             float scale, float* __restrict__ y, int B, int Cout, int H, int W) {
+    const int W4 = W >> 2, HW = H * W;
+    const long n = (long)B * Cout * H * W4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int xq = (int)(i % W4) * 4;
+        const int yv = (int)((i / W4) % H);
+        const int co = (int)((i / ((long)W4 * H)) % Cout);
+        const int b = (int)(i / ((long)W4 * H * Cout));
+        const float bs = bias[co];
+        float acc[4] = {bs, bs, bs, bs};
+        const float* zb = z + (long)b * 9 * Cout * HW;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = yv + t / 3 - 1, dx = t % 3 - 1;
+            if (yy < 0 || yy >= H) continue;
+            const float* row = zb + ((long)t * Cout + co) * HW + (long)yy * W;
+            const float4 q = *reinterpret_cast<const float4*>(row + xq);
+            float v[4];
+            if (dx == 0) { v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+            else if (dx < 0) { v[0] = xq > 0 ? row[xq - 1] : 0.0f; v[1] = q.x; v[2] = q.y; v[3] = q.z; }
+            else { v[0] = q.y; v[1] = q.z; v[2] = q.w; v[3] = xq + 4 < W ? row[xq + 4] : 0.0f; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += v[j];
+        }
+        const long o = ((long)b * Cout + co) * HW + (long)yv * W + xq;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res) r = *reinterpret_cast<const float4*>(res + o);
+        *reinterpret_cast<float4*>(y + o) = make_float4((acc[0] + r.x) * scale, (acc[1] + r.y) * scale, (acc[2] + r.z) * scale, (acc[3] + r.w) * scale);
+    }
+}
+
+int launch_taps_shift_add(const float* z, const float* bias, const float* res, float scale, float* y, int B, int Cout, int H, int W, hipStream_t s) {
+    MCVD_REQUIRE(W % 4 == 0, "taps_shift_add: W=%d", W);
+    const long n = (long)B * Cout * H * (W / 4);
+    const int blocks = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+    hipLaunchKernelGGL(taps_shift_add_kernel, dim3(blocks), dim3(256), 0, s, z, bias, res, scale, y, B, Cout, H, W);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// [Cout][Cin][3][3] -> the packed fp32 matrix wp[k * CoutP + n] of the GEMM form (the layout launch_pack_conv1x1_h2 splits into pieces):
+//   form 23: k = ci * 9 + t, n = co;          form 22: k = ci, n = t * Cout + co.       (wp zeroed by the caller: padding rows / columns)
+__global__ void pack_conv_gemm_form_kernel(const float* w, float* wp, int Cout, int Cin, int form, int CoutP) {
+    const long n = (long)Cout * Cin * 9;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % 9), ci = (int)((i / 9) % Cin), co = (int)(i / (9L * Cin));
+        if (form == 23) wp[((long)ci * 9 + t) * CoutP + co] = w[i];
+        else wp[(long)ci * CoutP + t * Cout + co] = w[i];
+    }
+}
+
+int launch_pack_conv_gemm_form(const float* w, float* wp, int Cout, int Cin, int form, int CoutP, hipStream_t s) {
+    MCVD_REQUIRE(form == 22 || form == 23, "pack_conv_gemm_form: form %d", form);
+    const long n = (long)Cout * Cin * 9;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_gemm_form_kernel, dim3(blocks), dim3(256), 0, s, w, wp, Cout, Cin, form, CoutP);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mcvd

@@ -181,6 +181,30 @@ struct Builder {
         if (p.wpw >= 0) p.wpb = alloc_packed(conv_wino3_weight_floats(p.CinP, p.CoutP));       // three bf16 pieces (conv_wino3.cpp)
         if (ks == 1) p.wph = alloc_packed_h(conv1x1_h2_weight_floats(p.CinP, p.CoutP, 2)); // two fp16 pieces of the packed matrix (conv1x1_h2.cpp): offset into packed_h
         if (ks == 1) p.wpb = alloc_packed(conv1x1_h2_weight_floats(p.CinP, p.CoutP, 3));   // three bf16 pieces of it
+        // the GEMM forms of a 3x3 conv with a handful of channels on one side (conv_gemm_forms.cpp), offered to the autotuner
+        if (ks == 3 && wnames.size() == 1 && !nin && op.W % 4 == 0 && (op.H * op.W) % 32 == 0 && op.H == op.W) {
+            if (9 * Cout <= 64) {                        // taps as outputs: Cin -> 9 * Cout, then shift-and-add
+                p.alt_kind = 22;
+                p.alt_CinP = round_up(Cin, 16);
+                p.alt_CoutP = round_up(9 * Cout, 32);
+            } else if (9 * Cin <= 96) {                  // im2col: 9 * Cin -> Cout
+                p.alt_kind = 23;
+                p.alt_CinP = round_up(9 * Cin, 16);
+                p.alt_CoutP = p.CoutP;
+            }
+            if (p.alt_kind && (p.alt_kind == 22 ? Cin % 16 != 0 : false)) p.alt_kind = 0;      // (the GEMM stages whole 16-channel chunks of real data)
+            if (p.alt_kind) {
+                p.alt_wp = alloc_packed((int64_t)p.alt_CinP * p.alt_CoutP);
+                p.alt_wpb = alloc_packed(conv1x1_h2_weight_floats(p.alt_CinP, p.alt_CoutP, 3));
+                op.alt_kind = p.alt_kind;
+                op.alt_wp = p.alt_wp;
+                op.alt_wpb = p.alt_wpb;
+                op.alt_CinP = p.alt_CinP;
+                op.alt_CoutP = p.alt_CoutP;
+                op.alt_bias = p.alt_kind == 22 ? alloc_packed(p.alt_CoutP) : -1;           // (the packed blob is zero-filled: a zero bias)
+                op.alt_buf = p.alt_kind == 22 ? alloc(9 * Cout, op.H) : alloc(p.alt_CinP, op.H);
+            }
+        }
         op.wpw = p.wpw;
         op.wph = p.wph;
         op.wpb = p.wpb;
@@ -682,6 +706,53 @@ int mcvd_model::ensure_coef(int gn_index, const float* x, const void* lab, const
     return launch_gn(ops[gn_index], x, lab, cond, out, B, false);       // (clears the flag)
 }
 
+// ---- the GEMM forms of a 3x3 conv (kernels/conv_gemm_forms.cpp; shape ids 22 / 23).  `a` = the conv's arguments as launch_op built them.
+bool mcvd_model::gemm_form_usable(const Op& op, const ConvArgs& a) const {
+    if (!op.alt_kind || a.shape_hint != op.alt_kind || !ctx->bf16x3 || a.gb || a.gni.st0 || a.ks != 3) return false;
+    if (op.alt_kind == 22 && (a.stats || a.C1 != 0)) return false;        // (the shift-and-add pass emits no GroupNorm partials; one source)
+    if (op.alt_kind == 23 && (a.coef || a.act)) return false;             // (im2col copies raw values)
+    ConvArgs g = gemm_form_args(op, a, nullptr);
+    for (int c = 4; c >= 1; --c)
+        if (conv1x1_h2_supported(g, c, 3)) return true;
+    return false;
+}
+
+// the 1x1 GEMM's arguments; buf = the op's per-call buffer (im2col rows / z planes)
+ConvArgs mcvd_model::gemm_form_args(const Op& op, const ConvArgs& a, float* buf) const {
+    ConvArgs g = a;
+    g.ks = 1;
+    g.wp = packed + op.alt_wp;
+    g.wpb = packed + op.alt_wpb;
+    g.wpw = nullptr; g.wph = nullptr;
+    g.part = nullptr;
+    g.shape_hint = 15;
+    g.CinP = op.alt_CinP;
+    g.CoutP = op.alt_CoutP;
+    if (op.alt_kind == 22) {                 // Cin -> 9 * Cout planes of z; bias / residual / scale belong to the shift-and-add pass
+        g.Cout = 9 * a.Cout;
+        g.bias = packed + op.alt_bias;
+        g.res = nullptr; g.out_scale = 1.0f; g.stats = nullptr;
+        g.y = buf;
+    } else {                                 // the im2col rows -> Cout; the epilogue is the conv's
+        g.x0 = buf; g.x1 = nullptr;
+        g.C0 = g.Cin = op.alt_CinP; g.C1 = 0;
+    }
+    int cot = a.cot;
+    if (cot < 1 || cot > 4 || !conv1x1_h2_supported(g, cot, 3))
+        for (cot = 4; cot > 1 && !conv1x1_h2_supported(g, cot, 3); --cot) {}
+    g.cot = cot;
+    return g;
+}
+
+int mcvd_model::launch_gemm_form(const Op& op, const ConvArgs& a, float* buf, hipStream_t s) {
+    const ConvArgs g = gemm_form_args(op, a, buf);
+    if (op.alt_kind == 23)
+        if (int rc = launch_im2col3x3(a.x0, a.C0, a.x1, a.C1, buf, a.B, a.H, a.W, op.alt_CinP, s)) return rc;
+    if (int rc = launch_conv_mfma(g, s)) return rc;
+    if (op.alt_kind == 22) return launch_taps_shift_add(buf, a.bias, a.res, a.out_scale, a.y, a.B, a.Cout, a.H, a.W, s);
+    return 0;
+}
+
 int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const float* cond, float* out, int B) {
     hipStream_t s = op_stream ? op_stream : ctx->stream;
     switch (op.kind) {
@@ -847,6 +918,16 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                 stats_np[oi] = 0;
                 ran_kernel[oi] = -2;
                 return launch_conv_naive(a, s);
+            }
+            if (a.shape_hint == 22 || a.shape_hint == 23) {
+                if (gemm_form_usable(op, a)) {
+                    const int rc = launch_gemm_form(op, a, resolve(op.alt_buf, x, cond, out, B), s);
+                    stats_np[oi] = a.stats ? last_conv_stats_np() : 0;
+                    ran_kernel[oi] = op.alt_kind;
+                    return rc;
+                }
+                a.shape_hint = -1;               // (forced for the whole network, or a table of another build: the dispatcher's own choice)
+                a.cot = op.cot;
             }
             const int rc = launch_conv_mfma(a, s);
             stats_np[oi] = a.stats ? last_conv_stats_np() : 0;
@@ -1019,6 +1100,26 @@ int mcvd_model::autotune(int B) {
             a.cot = op.cot;
             if (op.ks == 3 && op.Cout <= 16 && !spade_fused && conv_small_cout_usable(a))      // 21 = fp32 VALU direct conv for the last layer's handful of couts
                 if (int rc = time_candidate(21, op.cot)) return rc;
+            if (op.alt_kind && !spade_fused && op.gb.kind == REF_NONE) {         // 22 / 23 = the conv as a 1x1 GEMM on the three-piece kernel + its copy / shift pass
+                ConvArgs t = a;
+                t.shape_hint = op.alt_kind;
+                t.stats = (ctx->gn_stats && op.stats.kind != REF_NONE) ? resolve(op.stats, scratch_io, scratch_io, scratch_io, B) : nullptr;
+                float* buf = resolve(op.alt_buf, scratch_io, scratch_io, scratch_io, B);
+                for (int c = 4; c >= 1; --c) {
+                    t.cot = c;
+                    if (!gemm_form_usable(op, t)) break;
+                    if (gemm_form_args(op, t, buf).cot != c) continue;
+                    if (launch_gemm_form(op, t, buf, s)) continue;            // warm-up (and validity check)
+                    MCVD_HIP_CHECK(hipEventRecord(e0, s));
+                    for (int r = 0; r < 3; ++r)
+                        if (int rc = launch_gemm_form(op, t, buf, s)) return rc;
+                    MCVD_HIP_CHECK(hipEventRecord(e1, s));
+                    MCVD_HIP_CHECK(hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    MCVD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best_ms) { best_ms = ms; choice = {op.alt_kind, c}; }
+                }
+            }
             if (op.ks == 3 && ctx->winograd) {             // 8 = Winograd with a 2-way K split (more workgroups: 8x8 layers)
                 ConvArgs b = a;
                 b.ksplit = 2;

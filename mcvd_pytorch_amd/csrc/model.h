@@ -111,6 +111,13 @@ struct Op {
     int64_t wpb = -1;              // the same, pre-split into three bf16 pieces (conv_wino3.cpp / conv1x1_h2.cpp), else -1
     int CinP = 0, CoutP = 0, cot = 0;
     float out_scale = 1.f;
+    // 3x3 conv that can also run as a 1x1 GEMM on the three-piece bf16 kernel (kernels/conv_gemm_forms.cpp): alt_kind = 23 im2col (few
+    // input channels: the stem), 22 taps as outputs (few output channels: the last conv); the GEMM's packed matrix / pieces / zero bias,
+    // its padded dims and the per-sample buffer (the im2col rows, or the 9 * Cout planes of z)
+    int alt_kind = 0;
+    int64_t alt_wp = -1, alt_wpb = -1, alt_bias = -1;
+    int alt_CinP = 0, alt_CoutP = 0;
+    TRef alt_buf;
     // fir
     int up = 0;
     // attention
@@ -147,6 +154,9 @@ struct ConvPack {
     int64_t wpw = -1;
     int64_t wph = -1;
     int64_t wpb = -1;
+    int alt_kind = 0;                   // 22 / 23: the conv's GEMM form is packed too (Op::alt_kind)
+    int64_t alt_wp = -1, alt_wpb = -1;
+    int alt_CinP = 0, alt_CoutP = 0;
     bool zero_bias = false;             // the packed bias stays zero (the shortcut GEMM of an up block: its bias is added elsewhere)
     std::string extra_bias;             // a second bias parameter added into this conv's packed bias (that shortcut's)
 };
@@ -265,5 +275,9 @@ struct mcvd_model {
     int forward(const float* x, const void* labels, const float* cond, float* out, int B);
     int forward_unchecked(const float* x, const void* labels, const float* cond, float* out, int B);
     int launch_op(const mcvd::Op& op, const float* x, const void* labels, const float* cond, float* out, int B);
+    // 3x3 conv as a 1x1 GEMM on the three-piece kernel (shape ids 22 / 23; kernels/conv_gemm_forms.cpp)
+    bool gemm_form_usable(const mcvd::Op& op, const mcvd::ConvArgs& a) const;
+    mcvd::ConvArgs gemm_form_args(const mcvd::Op& op, const mcvd::ConvArgs& a, float* buf) const;
+    int launch_gemm_form(const mcvd::Op& op, const mcvd::ConvArgs& a, float* buf, hipStream_t s);
     float* resolve(const mcvd::TRef& r, const float* x, const float* cond, float* out, int B) const;
 };

@@ -634,6 +634,32 @@ def test_spade_loader_fusion_offered_per_layer():
     assert net.get_tuning(2) == forced
 
 
+@pytest.mark.parametrize("cfg,B", [("smmnist_big5_ngf96", 2), ("smmnist_big5", 3), ("tiny", 3), ("kth64_big_ngf128", 2), ("cityscapes_big", 1)])
+@pytest.mark.parametrize("form", [22, 23])
+def test_conv3x3_as_gemm_forms(cfg, B, form):
+    """The two 3x3 convs with a handful of channels on one side as 1x1 GEMMs on the three-piece bf16 kernel (kernels/conv_gemm_forms.cpp):
+    shape id 23 = im2col + GEMM for the stem (frame channels -> ngf; its epilogue still emits the GroupNorm partials of the next norm),
+    22 = GEMM to 9 * Cout planes + shift-and-add for the last conv (ngf -> frame channels, GroupNorm + SiLU in the GEMM's prologue).  Forced
+    for the whole network (every conv without such a form falls back to the dispatcher's choice): exactly one conv takes it, and eps
+    stays inside the contract (ncsnpp_more.py first / last conv3x3; layers.py:107-113)."""
+    config, sd, net = _net(cfg)
+    net.set_option("conv_shape", form)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = torch.tensor([700, 20, 333][:B]).cuda()
+    a = net(x.cuda(), t, cond=cond.cuda()).clone()
+    took = [k for k in _conv_kernels(net) if k[4] == form]
+    n_out = config.data.channels * config.data.num_frames
+    n_in = config.data.channels * (config.data.num_frames + config.data.num_frames_cond)
+    if (form == 22 and 9 * n_out > 64) or (form == 23 and 9 * n_in > 96):
+        assert not took                                        # (15 output channels = 135 planes; 15 / 21 input channels = 135 / 189 rows: not offered)
+    else:
+        assert len(took) == 1 and took[0][0] == 3, took
+        assert (took[0][3] == n_out) if form == 22 else (took[0][2] == n_in), took
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t.cpu(), cond)
+    assert (a.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("cfg,B", [("smmnist_big5_ngf96", 2), ("smmnist_big5", 3), ("tiny", 3), ("kth64_big_ngf128", 2)])
 def test_attention_with_presplit_kv_is_bit_identical(cfg, B):
     """the fused q|k|v projection writes K and V ALREADY SPLIT into the three bf16 pieces, in the LDS-image order the
