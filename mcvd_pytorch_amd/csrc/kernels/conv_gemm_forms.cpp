@@ -14,62 +14,61 @@
 
 namespace mcvd {
 
-// one thread per (b, k, 4 pixels): K rows of `col` per sample, rows >= 9 * (C0 + C1) are zero
+// one thread per (b, k, 4 pixels): K rows of `col` per sample, rows >= 9 * (C0 + C1) are zero.  blockIdx.y = b * K + k (no 64-bit division per thread)
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x0, int C0, const float* __restrict__ x1, int C1, float* __restrict__ col,
-                                                        int B, int H, int W, int K) {
+                                                        int H, int W, int K) {
     const int W4 = W >> 2, HW = H * W;
-    const long n = (long)B * K * H * W4;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int xq = (int)(i % W4) * 4;
-        const int y = (int)((i / W4) % H);
-        const int k = (int)((i / ((long)W4 * H)) % K);
-        const int b = (int)(i / ((long)W4 * H * K));
+    const int k = blockIdx.y % K, b = blockIdx.y / K;
+    const int c = k / 9, t = k - 9 * c;
+    const bool real = c < C0 + C1;
+    const int dy = t / 3 - 1, dx = t % 3 - 1;
+    const float* plane = !real ? nullptr : (c < C0 ? x0 + ((long)b * C0 + c) * HW : x1 + ((long)b * C1 + (c - C0)) * HW);
+    float* dst = col + ((long)b * K + k) * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W4; i += gridDim.x * 256) {
+        const int y = i / W4, xq = (i - y * W4) * 4;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int c = k / 9, t = k - 9 * c;
-        if (c < C0 + C1) {
-            const int yy = y + t / 3 - 1, dx = t % 3 - 1;
-            if (yy >= 0 && yy < H) {
-                const float* row = (c < C0 ? x0 + ((long)b * C0 + c) * HW : x1 + ((long)b * C1 + (c - C0)) * HW) + (long)yy * W;
-                if (dx == 0) {
-                    o = *reinterpret_cast<const float4*>(row + xq);
-                } else {
-                    const float4 q = *reinterpret_cast<const float4*>(row + xq);
-                    if (dx < 0) o = make_float4(xq > 0 ? row[xq - 1] : 0.0f, q.x, q.y, q.z);
-                    else o = make_float4(q.y, q.z, q.w, xq + 4 < W ? row[xq + 4] : 0.0f);
-                }
-            }
+        const int yy = y + dy;
+        if (real && yy >= 0 && yy < H) {
+            const float* row = plane + yy * W;
+            const float4 q = *reinterpret_cast<const float4*>(row + xq);
+            if (dx == 0) o = q;
+            else if (dx < 0) o = make_float4(xq > 0 ? row[xq - 1] : 0.0f, q.x, q.y, q.z);
+            else o = make_float4(q.y, q.z, q.w, xq + 4 < W ? row[xq + 4] : 0.0f);
         }
-        *reinterpret_cast<float4*>(col + ((long)b * K + k) * HW + (long)y * W + xq) = o;
+        *reinterpret_cast<float4*>(dst + y * W + xq) = o;
     }
 }
 
 int launch_im2col3x3(const float* x0, int C0, const float* x1, int C1, float* col, int B, int H, int W, int K, hipStream_t s) {
-    MCVD_REQUIRE(W % 4 == 0 && K >= 9 * (C0 + C1), "im2col: W=%d K=%d", W, K);
-    const long n = (long)B * K * H * (W / 4);
-    const int blocks = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
-    hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks), dim3(256), 0, s, x0, C0, x1, C1, col, B, H, W, K);
-    MCVD_HIP_CHECK(hipGetLastError());
+    MCVD_REQUIRE(W % 4 == 0 && K >= 9 * (C0 + C1) && K <= 65535, "im2col: W=%d K=%d", W, K);
+    const int per_plane = H * (W / 4), bmax = 65535 / K;
+    const long HW = (long)H * W;
+    for (int b0 = 0; b0 < B; b0 += bmax) {              // (grid.y holds 65535 planes)
+        const int nb = B - b0 < bmax ? B - b0 : bmax;
+        hipLaunchKernelGGL(im2col3x3_kernel, dim3((per_plane + 255) / 256, nb * K), dim3(256), 0, s, x0 + (long)b0 * C0 * HW,
+                           C0, x1 ? x1 + (long)b0 * C1 * HW : nullptr, C1, col + (long)b0 * K * HW, H, W, K);
+        MCVD_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 
-// one thread per (b, co, 4 pixels): nine shifted reads of z (row t * Cout + co of the sample's 9 * Cout rows), summed in tap order behind the bias
+// one thread per (b, co, 4 pixels): nine shifted reads of z (row t * Cout + co of the sample's 9 * Cout rows), summed in tap order behind the
+// bias.  blockIdx.y = b * Cout + co
 __global__ __launch_bounds__(256) void taps_shift_add_kernel(const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ res,
-                                                             float scale, float* __restrict__ y, int B, int Cout, int H, int W) {
+                                                             float scale, float* __restrict__ y, int Cout, int H, int W) {
     const int W4 = W >> 2, HW = H * W;
-    const long n = (long)B * Cout * H * W4;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int xq = (int)(i % W4) * 4;
-        const int yv = (int)((i / W4) % H);
-        const int co = (int)((i / ((long)W4 * H)) % Cout);
-        const int b = (int)(i / ((long)W4 * H * Cout));
-        const float bs = bias[co];
+    const int co = blockIdx.y % Cout, b = blockIdx.y / Cout;
+    const float bs = bias[co];
+    const float* zb = z + ((long)b * 9 * Cout + co) * HW;
+    const long plane = ((long)b * Cout + co) * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W4; i += gridDim.x * 256) {
+        const int yv = i / W4, xq = (i - yv * W4) * 4;
         float acc[4] = {bs, bs, bs, bs};
-        const float* zb = z + (long)b * 9 * Cout * HW;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int yy = yv + t / 3 - 1, dx = t % 3 - 1;
             if (yy < 0 || yy >= H) continue;
-            const float* row = zb + ((long)t * Cout + co) * HW + (long)yy * W;
+            const float* row = zb + (long)t * Cout * HW + yy * W;
             const float4 q = *reinterpret_cast<const float4*>(row + xq);
             float v[4];
             if (dx == 0) { v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
@@ -78,7 +77,7 @@ __global__ __launch_bounds__(256) void taps_shift_add_kernel(const float* __rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] += v[j];
         }
-        const long o = ((long)b * Cout + co) * HW + (long)yv * W + xq;
+        const long o = plane + yv * W + xq;
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (res) r = *reinterpret_cast<const float4*>(res + o);
         *reinterpret_cast<float4*>(y + o) = make_float4((acc[0] + r.x) * scale, (acc[1] + r.y) * scale, (acc[2] + r.z) * scale, (acc[3] + r.w) * scale);
@@ -86,11 +85,15 @@ __global__ __launch_bounds__(256) void taps_shift_add_kernel(const float* __rest
 }
 
 int launch_taps_shift_add(const float* z, const float* bias, const float* res, float scale, float* y, int B, int Cout, int H, int W, hipStream_t s) {
-    MCVD_REQUIRE(W % 4 == 0, "taps_shift_add: W=%d", W);
-    const long n = (long)B * Cout * H * (W / 4);
-    const int blocks = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
-    hipLaunchKernelGGL(taps_shift_add_kernel, dim3(blocks), dim3(256), 0, s, z, bias, res, scale, y, B, Cout, H, W);
-    MCVD_HIP_CHECK(hipGetLastError());
+    MCVD_REQUIRE(W % 4 == 0 && Cout <= 65535, "taps_shift_add: W=%d Cout=%d", W, Cout);
+    const int per_plane = H * (W / 4), bmax = 65535 / Cout;
+    const long HW = (long)H * W;
+    for (int b0 = 0; b0 < B; b0 += bmax) {
+        const int nb = B - b0 < bmax ? B - b0 : bmax;
+        hipLaunchKernelGGL(taps_shift_add_kernel, dim3((per_plane + 255) / 256, nb * Cout), dim3(256), 0, s, z + (long)b0 * 9 * Cout * HW, bias,
+                           res ? res + (long)b0 * Cout * HW : nullptr, scale, y + (long)b0 * Cout * HW, Cout, H, W);
+        MCVD_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 
