@@ -146,6 +146,9 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         (profiles/r03_gn_inline_ab.txt).  "spade_fuse" (0): 1 = the SPADE modulation inside the fp32 Winograd conv loader (gamma | beta by
  *         LDS-DMA; measured 3.5 % slower end to end than the materialising spade_apply kernel).  "side_stream" (0): ResBlock shortcut
  *         convs on a second HIP stream (measured slower; UNSAFE beside the split-operand attention kernel: INTEGRATION.md section 4).
+ *         "gn_producer" (1): the second pass of a K-split Winograd layer over 8 x 8 / 16 x 16 planes also writes the (A, B) table of the
+ *         single-source norm over its output (one workgroup per (sample, group); bit-identical to gn_finalize), that norm's launch is
+ *         skipped; 0 = two launches.
  *         "fir_form" (0): 0 = the x2 FIR resamplers stage a strip of 1024 input elements through the LDS (prologue applied once per
  *         element; power-of-two widths 8..256), 1 = the register-window forms only; bit-identical (up_or_down_sampling.py:196-258).
  *         "spade_norm_fuse" (0): 1 = a SPADE norm in front of a conv is ONE launch -- GroupNorm finalize from the producers' epilogue partials +
@@ -282,7 +285,8 @@ long mcvd_model_gn_inlined(mcvd_model* m);
 /* Launch counters of the fused forms that have no reference counterpart (diagnostics / tests), cumulative over the model's forwards:
  * what = 0: attention blocks whose K and V went from the q|k|v projection to the attention kernel pre-split (option "attn_presplit",
  * layerspp.py:236-245 computes the same products on fp32 rows); 1: SPADE norms finalized inside the modulating kernel (option
- * "spade_norm_fuse", layerspp.py:152-173); 2: convs that took the SPADE modulation inside their loader (shape ids 36 / 40 or "spade_fuse"). */
+ * "spade_norm_fuse", layerspp.py:152-173); 2: convs that took the SPADE modulation inside their loader (shape ids 36 / 40 or "spade_fuse"); 3: norms whose table the producing
+ * conv's K-split reduce pass wrote ("gn_producer"). */
 long mcvd_model_fused_launches(mcvd_model* m, int what);
 
 /* Debug/test aid: copy the output tensor of reference module `module` (index in all_modules, ncsnpp_more.py:249) from the

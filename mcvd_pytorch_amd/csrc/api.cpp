@@ -316,6 +316,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "naive_attn")) ctx->naive_attn = value;
     else if (!strcmp(key, "fir_form")) ctx->fir_form = value;
     else if (!strcmp(key, "dbg_skip_finalize")) ctx->dbg_skip_finalize = value;
+    else if (!strcmp(key, "gn_producer")) ctx->gn_producer = value;
     else if (!strcmp(key, "graph")) ctx->graph = value;
     else if (!strcmp(key, "conv_shape")) ctx->conv_shape = value;
     else if (!strcmp(key, "conv_shape1")) ctx->conv_shape1 = value;
@@ -794,7 +795,7 @@ int mcvd_model_op_kernel(mcvd_model* m, int i) {
 }
 
 long mcvd_model_gn_inlined(mcvd_model* m) { return m ? m->gn_inlined_total : -1; }
-long mcvd_model_fused_launches(mcvd_model* m, int what) { return (m && what >= 0 && what < 3) ? m->fused_launches[what] : -1; }
+long mcvd_model_fused_launches(mcvd_model* m, int what) { return (m && what >= 0 && what < 4) ? m->fused_launches[what] : -1; }
 
 int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst, int64_t capacity, int* C, int* H) {
     MCVD_REQUIRE(m && dst && B > 0 && B <= m->arena_B, "module_output: run a forward at batch >= B first");

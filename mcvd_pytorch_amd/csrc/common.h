@@ -54,6 +54,18 @@ static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 // ------------------------------------------------------------------ conv (implicit GEMM on fp32 MFMA)
 // Packed weight layout: wp[(cin * KK + tap) * CoutP + cout], cin padded to CinP (multiple of the kernel's
 // channel chunk) and cout padded to CoutP (multiple of the cout tile) with zeros.
+// GroupNorm (A, B) table a conv writes for the norm that consumes its output, where its LAST pass sees whole (sample, group) slabs: the
+// second pass of a K-split Winograd layer (gn.cpp: ksplit_reduce_gn_kernel).  coef == NULL: off.  Fields as GnArgs.
+struct GnOut {
+    float* coef;            // [B][Cout][2]
+    int groups;
+    float eps;
+    int mode;
+    const float* p0;
+    const float* p1;
+    int emb_stride, emb_off;
+};
+
 struct ConvArgs {
     const float* x0;
     const float* x1;      // second source of a virtual channel concat (may be null when C1 == 0)
@@ -102,7 +114,14 @@ struct ConvArgs {
     // three-piece bf16 LDS images per (sample, head, key tile) instead of as fp32 rows of y: 3 * kv_C * HW dwords per sample
     float* kv_img;
     int kv_C, kv_D;       // channels of one of q / k / v; head dim
+    // the norm over THIS conv's output (single source), finalized by the K-split reduce pass when the launch has one (8 x 8 / 16 x 16
+    // planes): last_conv_gn_fused() tells whether it happened
+    GnOut gno;
 };
+int last_conv_gn_fused();
+void set_last_conv_gn_fused(int v);
+bool ksplit_reduce_gn_usable(const ConvArgs& a);
+int launch_ksplit_reduce_gn(const ConvArgs& a, hipStream_t s);
 bool conv1x1_h2_kv_supported(const ConvArgs& a, int cot);
 bool conv_takes_gn_inline(const ConvArgs& a, int max_wg);   // the kernel launch_conv_mfma(a) dispatches to reduces the partials itself (and has <= max_wg workgroups)
 void set_last_conv_stats_np(int np);          // (launchers)

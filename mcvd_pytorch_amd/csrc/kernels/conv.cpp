@@ -35,8 +35,14 @@ static thread_local int g_last_stats_np = 0;
 int last_conv_stats_np() { return g_last_stats_np; }
 void set_last_conv_stats_np(int np) { g_last_stats_np = np; }
 
+// 1: the last conv launch of this thread also wrote the (A, B) table of the norm over its output (ConvArgs::gno)
+static thread_local int g_last_gn_fused = 0;
+int last_conv_gn_fused() { return g_last_gn_fused; }
+void set_last_conv_gn_fused(int v) { g_last_gn_fused = v; }
+
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     g_last_stats_np = 0;
+    g_last_gn_fused = 0;
     MCVD_REQUIRE(a.ks == 1 || a.ks == 3, "conv: kernel size %d unsupported", a.ks);
     MCVD_REQUIRE(a.W >= 8 && (a.W & (a.W - 1)) == 0 && a.W <= 256, "conv: W=%d must be a power of two in [8,256]", a.W);
 #ifdef MCVD_DIAG

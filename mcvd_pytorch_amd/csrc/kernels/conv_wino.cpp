@@ -660,6 +660,12 @@ int launch_wino_ksplit_reduce(const ConvArgs& a, hipStream_t s) {
     const int ksp = a.ksplit >= 2 ? a.ksplit : 2;
     const long n = (long)a.B * a.Cout * a.H * a.W, n4 = n / 4;
     const int hw4 = a.H * a.W / 4;
+    if (a.gno.coef && ksplit_reduce_gn_usable(a)) {       // ... and the (A, B) table of the norm over y: one workgroup per (sample, group), gn.cpp
+        if (int rc = launch_ksplit_reduce_gn(a, s)) return rc;
+        set_last_conv_stats_np(1);
+        set_last_conv_gn_fused(1);
+        return 0;
+    }
     if (a.stats && (hw4 == 16 || hw4 == 64)) {     // ... with the GroupNorm partials of the final values (one per plane)
         const int blocks = (int)((n4 + 255) / 256);
         if (hw4 == 16)

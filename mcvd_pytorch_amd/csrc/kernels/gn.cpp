@@ -191,6 +191,107 @@ int launch_gn_finalize(const GnArgs& a, const float* st0, int np0, const float* 
     return 0;
 }
 
+// ---- second pass of a K-split Winograd layer + the GroupNorm finalize of the norm over its output, in ONE launch (round 5).  The reduce
+// pass (conv_wino.cpp: wino_ksplit_reduce_stats_kernel) walks the tensor flat; here a workgroup owns one (sample, group) slab --
+// gs channel planes of 8 x 8 or 16 x 16 pixels -- so it holds every partial the group's statistics need and no workgroup waits for
+// another: y and the per-plane partials exactly as the reduce pass writes them (same expressions, same order: later concat norms read
+// the partials), then gn_finalize_kernel's reduction over the gs planes in wave 0 (same expressions: the table is bit-identical to the
+// two-launch path).  Saves the gn_finalize launch behind 8 x 8 / 16 x 16 layers (4.3 us each inside the graph, r05_tail_launch_bound.txt).
+typedef float gnf32x4 __attribute__((ext_vector_type(4)));
+template <int PL>
+__global__ __launch_bounds__(256) void ksplit_reduce_gn_kernel(const float* part, const float* bias, const float* res, float scale, float* y,
+                                                               long half_stride, int Cout, float* stats, int ksp, GnOut g, int HW) {
+    __shared__ float2 sp[64];
+    const int gs = Cout / g.groups;
+    const int b = blockIdx.x / g.groups, gi = blockIdx.x - b * g.groups;
+    const int c0 = gi * gs;
+    const long base4 = ((long)b * Cout + c0) * PL;
+    const int n4 = gs * PL;
+    for (int j0 = 0; j0 < n4; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        const bool in = j < n4;
+        const long i = base4 + j;
+        gnf32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (in) {
+            gnf32x4 acc = reinterpret_cast<const gnf32x4*>(part)[i];
+            for (int k = 1; k < ksp; ++k) acc = acc + reinterpret_cast<const gnf32x4*>(part + k * half_stride)[i];      // p0 + p1 + ... in this fixed order
+            const float bv = bias[c0 + j / PL];
+            v = acc + bv;
+            if (res) v = v + reinterpret_cast<const gnf32x4*>(res)[i];
+            v = v * scale;
+            reinterpret_cast<gnf32x4*>(y)[i] = v;
+        }
+        float sm = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+        for (int o = PL / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+        const float mu = sm * (1.0f / (4 * PL));
+        const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
+        float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+        for (int o = PL / 2; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+        if (in && (threadIdx.x & (PL - 1)) == 0) {
+            const int plane = j / PL;
+            stats[((long)b * Cout + c0 + plane) * 2] = sm;
+            stats[((long)b * Cout + c0 + plane) * 2 + 1] = m2;
+            sp[plane] = make_float2(sm, m2);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    // gn_finalize_kernel with one source, one partial per channel: P = gs <= 64 partials, partial `lane` in lane `lane`
+    const int lane = threadIdx.x;
+    const int P = gs;
+    float ks0 = 0.0f, km0 = 0.0f, kn0 = 1.0f;
+    if (lane < P) { const float2 q = sp[lane]; ks0 = q.x; km0 = q.y; kn0 = (float)HW; }
+    const int cpar = c0 + min(lane, gs - 1);
+    float par0 = 1.0f, par1 = 0.0f;
+    if (g.mode == 1) {
+        const float* e = g.p0 + (long)b * g.emb_stride + g.emb_off;
+        par0 = 1.0f + e[cpar];
+        par1 = e[Cout + cpar];
+    } else if (g.mode == 2) {
+        par0 = g.p0[cpar];
+        par1 = g.p1[cpar];
+    }
+    float tot = 0.0f;
+    if (lane < P) tot += ks0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    const float N = (float)gs * (float)HW;
+    const float mean = tot / N;
+    float acc = 0.0f;
+    if (lane < P) {
+        const float d = ks0 / kn0 - mean;
+        acc += km0 + kn0 * d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const float var = acc / N;
+    const float rstd = 1.0f / sqrtf(var + g.eps);
+    if (lane < gs) reinterpret_cast<float2*>(g.coef)[(long)b * Cout + cpar] = make_float2(rstd * par0, par1 - mean * rstd * par0);
+}
+
+bool ksplit_reduce_gn_usable(const ConvArgs& a) {
+    const int hw4 = a.H * a.W / 4;
+    return a.gno.coef && a.stats && a.part && (hw4 == 16 || hw4 == 64) && a.gno.groups > 0 && a.Cout % a.gno.groups == 0 &&
+           a.Cout / a.gno.groups <= 64;
+}
+
+int launch_ksplit_reduce_gn(const ConvArgs& a, hipStream_t s) {
+    MCVD_REQUIRE(ksplit_reduce_gn_usable(a), "ksplit_reduce_gn: unsupported (Cout=%d groups=%d HW=%d)", a.Cout, a.gno.groups, a.H * a.W);
+    const int ksp = a.ksplit >= 2 ? a.ksplit : 2;
+    const long n = (long)a.B * a.Cout * a.H * a.W;
+    const int hw4 = a.H * a.W / 4;
+    if (hw4 == 16)
+        hipLaunchKernelGGL(ksplit_reduce_gn_kernel<16>, dim3(a.B * a.gno.groups), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale, a.y, n, a.Cout,
+                           a.stats, ksp, a.gno, a.H * a.W);
+    else
+        hipLaunchKernelGGL(ksplit_reduce_gn_kernel<64>, dim3(a.B * a.gno.groups), dim3(256), 0, s, a.part, a.bias, a.res, a.out_scale, a.y, n, a.Cout,
+                           a.stats, ksp, a.gno, a.H * a.W);
+    MCVD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_gn_coef(const GnArgs& a, hipStream_t s) {
     const int C = a.C0 + a.C1;
     MCVD_REQUIRE(a.groups > 0 && C % a.groups == 0, "gn: %d channels not divisible by %d groups", C, a.groups);

@@ -581,6 +581,12 @@ int mcvd_model::build_plan() {
             }
         }
     }
+    // ... and, for every such conv, the single-source norm over its output that comes first (ConvArgs::gno: the conv's own last pass may
+    // write that norm's table)
+    for (size_t gi = ops.size(); gi-- > 0;) {
+        const Op& g = ops[gi];
+        if (g.kind == OP_GN && g.src1.kind == REF_NONE && g.prod0 >= 0 && g.coef.kind == REF_ARENA) ops[g.prod0].gn_next = (int)gi;
+    }
     // consumers of GroupNorm coefficients: which norm of the plan wrote the table they read (the latest one before them)
     for (size_t ci = 0; ci < ops.size(); ++ci) {
         Op& c = ops[ci];
@@ -667,6 +673,10 @@ int mcvd_model::launch_gn(const Op& op, const float* x, const void* lab, const f
     const int np1 = a.C1 == 0 ? 1 : (op.prod1 >= 0 ? stats_np[op.prod1] : 0);
     if (gn_deferred.size() != ops.size()) gn_deferred.assign(ops.size(), 0);
     gn_deferred[gi] = 0;
+    if (gn_done.size() == ops.size() && gn_done[gi]) {       // the producing conv's K-split reduce pass wrote this table (ConvArgs::gno)
+        gn_done[gi] = 0;
+        return 0;
+    }
     if (ctx->gn_stats && np0 > 0 && np1 > 0) {
         // a SPADE norm (mode 0) in front of a conv: the statistics are finalized INSIDE the kernel that modulates and activates the
         // tensor (spade_norm_apply_kernel, launched by the conv op) -- no gn_finalize launch.  The conv op falls back to ensure_coef
@@ -896,6 +906,28 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             }
             if (ran_kernel.size() != ops.size()) ran_kernel.assign(ops.size(), -1);
             if (kv_live.size() != ops.size()) kv_live.assign(ops.size(), 0);
+            if (gn_done.size() != ops.size()) gn_done.assign(ops.size(), 0);
+            if (op.gn_next >= 0) {
+                // the norm over this conv's output: if the launch ends in a K-split reduce pass over 8 x 8 / 16 x 16 planes, that pass writes
+                // the norm's (A, B) table too (gn.cpp: ksplit_reduce_gn_kernel) and the norm's own launch is skipped
+                gn_done[op.gn_next] = 0;
+                const Op& g = ops[op.gn_next];
+                const bool plain = !ctx->gn_inline && !(ctx->spade_norm_fuse && g.gn_mode == 0);
+                if (ctx->gn_producer && ctx->gn_stats && a.stats && op.ks == 3 && plain && !ctx->dbg_skip_finalize) {
+                    a.gno.coef = resolve(g.coef, x, cond, out, B);
+                    a.gno.groups = g.groups;
+                    a.gno.eps = g.eps;
+                    a.gno.mode = g.gn_mode;
+                    if (g.gn_mode == 1) {
+                        a.gno.p0 = resolve(ops[1].dst, x, cond, out, B);
+                        a.gno.emb_stride = (uniform_labels && !d.cond_emb) ? 0 : NE;
+                        a.gno.emb_off = g.emb_off;
+                    } else if (g.gn_mode == 2) {
+                        a.gno.p0 = blob + g.p0;
+                        a.gno.p1 = blob + g.p1;
+                    }
+                }
+            }
             if (op.attn_op >= 0) {
                 // the q|k|v projection of an attention block: where the launch goes to the three-piece 1x1 GEMM and the attention op will run
                 // the three-piece kernel on a device of its own, K and V leave this kernel pre-split (conv1x1_h2.cpp KV -> attn_h2p_kernel)
@@ -932,6 +964,10 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             const int rc = launch_conv_mfma(a, s);
             stats_np[oi] = a.stats ? last_conv_stats_np() : 0;
             ran_kernel[oi] = last_conv_kernel();
+            if (rc == 0 && a.gno.coef && last_conv_gn_fused()) {
+                gn_done[op.gn_next] = 1;
+                ++fused_launches[3];
+            }
             return rc;
         }
         case OP_FIR: {

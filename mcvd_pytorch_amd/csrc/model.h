@@ -14,6 +14,7 @@ struct mcvd_ctx {
     hipStream_t stream = nullptr;
     int naive_conv = 0;
     int naive_attn = 0;
+    int gn_producer = 1;       // the K-split reduce pass of a conv also finalizes the norm over its output (gn.cpp: ksplit_reduce_gn_kernel); 0: two launches
     int dbg_skip_finalize = 0; // timing-only: no gn_finalize launches inside a captured graph (wrong results)
     int fir_form = 0;          // 0: FIR x2 resamplers through the LDS where the geometry applies; 1: register forms only (A/B)
     int graph = 0;                 // 1: replay each forward as a hipGraph (captured on the second use of the same
@@ -137,6 +138,8 @@ struct Op {
     // GroupNorm op names the plan ops that produce its sources (-1: not a conv of this plan)
     TRef stats;
     int prod0 = -1, prod1 = -1;
+    int gn_next = -1;              // conv: the plan's single-source OP_GN over this conv's output that comes first (its (A, B) table may be written by
+                                   // the conv's own last pass: ConvArgs::gno), else -1
     int gn_src = -1;               // consumers of GroupNorm coefficients (conv, FIR, SPADE apply): the plan's OP_GN that computes `coef`
 };
 
@@ -218,7 +221,9 @@ struct mcvd_model {
     std::vector<signed char> kv_live;       // per OP_ATTN of the forward in flight: 1 = its projection wrote the K / V piece images (set by the conv launch)
     std::vector<signed char> gn_deferred;   // per OP_GN of the forward in flight: 1 = not launched, its consumers reduce the partials
                                       //    themselves (or launch it late, the first that cannot): launch_op / ensure_coef
-    long fused_launches[3] = {0, 0, 0};   // mcvd_model_fused_launches: pre-split attention blocks, fused SPADE norms, convs with the SPADE loader
+    long fused_launches[4] = {0, 0, 0, 0};   // mcvd_model_fused_launches: pre-split attention blocks, fused SPADE norms, convs with the SPADE loader,
+                                             // norms finalized by their producer's K-split reduce pass
+    std::vector<signed char> gn_done;       // per OP_GN of the forward in flight: 1 = its table was written by the producing conv's last pass
     long gn_inlined_total = 0;        // norms that never needed a launch (diagnostics: mcvd_model_stat)
     int launch_gn(const mcvd::Op& op, const float* x, const void* labels, const float* cond, float* out, int B, bool may_defer);
     int ensure_coef(int gn_index, const float* x, const void* labels, const float* cond, float* out, int B);
