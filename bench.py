@@ -318,6 +318,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="smmnist_big5_ngf96", choices=sorted(DEFAULTS))
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the config's per-GPU batch)")
+    ap.add_argument("--global-batch", type=int, default=None, help="total samples of the job, sharded over the ranks by shard_rows (uneven "
+                    "shards when it is not a multiple of --gpus); default: --batch x --gpus")
+    ap.add_argument("--rank-spread-tol", type=float, default=1.10, help="N > 1 with even shards: the line is marked valid: false when the "
+                    "slowest rank's own sampling time exceeds the fastest rank's by more than this factor (a straggler GPU: the whole-node "
+                    "number then measures that GPU, not the design)")
     ap.add_argument("--subsample", type=int, default=None)
     ap.add_argument("--frames-pred", type=int, default=None, help="autoregressive configs: frames to keep (default 28)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MCVD_GRAPH", "1")), help="hipGraph replay of the forwards")
@@ -396,8 +401,10 @@ def main():
         if kv:
             net.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
-    total = B * world
+    total = args.global_batch or B * world
     b0, b1 = shard_rows(total, rank, world)
+    assert b1 > b0, f"rank {rank} of {world} has no rows of a global batch of {total}"
+    B = b1 - b0 if args.global_batch else B          # what this rank runs (the roofline figures of rank 0's line are per its own batch)
     x, cond = synthetic.random_inputs(config, b0, b1 - b0)
     x, cond = x.cuda(), cond.cuda()
 
@@ -414,16 +421,24 @@ def main():
         return ddpm_sampler(x, net, cond=cond, final_only=True, denoise=True, subsample_steps=subsample,
                             clip_before=True, verbose=False, log=False, seed=1000 + i, sample_offset=b0)[0]
 
+    busy = [0.0]                                     # this rank's own sampling time (launch to device idle), without barrier / gather waits
+
+    def timed_local_step(i):
+        t = time.perf_counter()
+        out = local_step(i)
+        torch.cuda.synchronize()                     # (the gather needs the frames anyway)
+        busy[0] += time.perf_counter() - t
+        return out
+
     def one_step(i):
         if serialize:
             out = None
             for r in range(world):
                 if r == rank:
-                    out = local_step(i)
-                    torch.cuda.synchronize()
+                    out = timed_local_step(i)
                 dist.barrier()
         else:
-            out = local_step(i)
+            out = timed_local_step(i)
         return gather_rows(out, total)               # final gather of the generated frames
 
     def fence():
@@ -451,17 +466,20 @@ def main():
                 os.makedirs(args.save_tuning, exist_ok=True)
                 net.save_tuning(os.path.join(args.save_tuning, os.path.basename(table_path(arith_name))), [b1 - b0])
         fence()
+        busy[0] = 0.0
         t0 = time.perf_counter()
         for i in range(steps):
             frames = one_step(seed0 + i)
         fence()
         dt_local = time.perf_counter() - t0
-        dt, per_rank = dt_local, [round(dt_local, 4)]
+        dt, per_rank, per_rank_busy, per_rank_rows = dt_local, [round(dt_local, 4)], [round(busy[0], 4)], [b1 - b0]
         if world > 1:
-            tt = torch.tensor([dt_local], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            tt = torch.tensor([dt_local, busy[0], float(b1 - b0)], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
             allt = [torch.zeros_like(tt) for _ in range(world)]
             dist.all_gather(allt, tt)
-            per_rank = [round(v.item(), 4) for v in allt]
+            per_rank = [round(v[0].item(), 4) for v in allt]
+            per_rank_busy = [round(v[1].item(), 4) for v in allt]
+            per_rank_rows = [int(v[2].item()) for v in allt]
             dt = max(per_rank)
         assert torch.isfinite(frames).all() and frames.shape[0] == total and frames.shape[1] == config.data.channels * nfp
         if args.dump_frames and rank == 0 and arith_name == main_arith:
@@ -487,7 +505,8 @@ def main():
                 if serialize:
                     dist.barrier()
             selfcheck = float((full[:1] - one).abs().max().item())
-        return dict(value=steps * total * nfp / dt, ms_per_step=1e3 * dt / steps, per_rank=per_rank, roofline=roofline, dtype=arith,
+        return dict(value=steps * total * nfp / dt, ms_per_step=1e3 * dt / steps, per_rank=per_rank, per_rank_busy=per_rank_busy,
+                    per_rank_rows=per_rank_rows, roofline=roofline, dtype=arith,
                     kernel_table=pinned or "autotuned in this run (HIP-event timing per distinct layer shape)", selfcheck_max_abs=selfcheck)
 
     main_arith = "f16x2" if args.f16x2 else "bf16x3"
@@ -524,7 +543,12 @@ def main():
                                parallelism=f"sample-sharded x{world} (1 weight broadcast + 1 final all_gather)",
                                kernel_table=main_leg["kernel_table"],
                                hip_graph=dict(enabled=bool(args.graph), captures=cap.value, replays=rep.value)),
-                   per_rank_s=main_leg["per_rank"], roofline=main_leg["roofline"],
+                   per_rank_s=main_leg["per_rank"], per_rank_busy_s=main_leg["per_rank_busy"], per_rank_rows=main_leg["per_rank_rows"],
+                   per_rank_spread=round(max(main_leg["per_rank_busy"]) / max(min(main_leg["per_rank_busy"]), 1e-9), 4),
+                   per_rank_note="per_rank_s: each rank's wall time between the two fences (barrier-bounded: equal by construction); "
+                                 "per_rank_busy_s: its own sampler calls, launch to device idle, without barrier / gather waits; "
+                                 "per_rank_spread = max / min of the busy times",
+                   roofline=main_leg["roofline"],
                    selfcheck_max_abs=main_leg["selfcheck_max_abs"],
                    selfcheck_note="max |row 0 of the last timed call - the same row sampled alone (B = 1, same kernel table, same Philox key)| "
                                   "over the final frames (data range [-1, 1]); computed after the timed region",
@@ -548,6 +572,11 @@ def main():
         if bad:
             res["invalid_reason"] = (f"selfcheck_max_abs {bad[0]:.3e} > {args.selfcheck_tol:.1e}: row 0 of the benchmarked batch differs from the "
                                      "same row sampled alone under the same kernel table (expected 0.0)")
+        even = len(set(main_leg["per_rank_rows"])) == 1
+        if world > 1 and even and not serialize and res["per_rank_spread"] > args.rank_spread_tol:
+            res["valid"] = False
+            res["invalid_reason"] = (res.get("invalid_reason", "") + f" per_rank_spread {res['per_rank_spread']} > {args.rank_spread_tol}: ranks with equal "
+                                     f"shards took {main_leg['per_rank_busy']} s for their own sampler calls -- a straggler GPU").strip()
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(config, sd, subsample, kept_fraction=nfp / (n_blocks * nfr) if autoreg else 1.0)

@@ -300,9 +300,13 @@ int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst_device
  * noise: NULL -> counter-based Philox keyed by (seed, sample_offset + row, step) so results do not depend on how rows are
  * sharded over GPUs; else [n_draws, B, C*nf, S, S] consumed in draw order (t_min draw first, then one per step).
  * MCVD_FLAG_GAMMA: the draws are gamma variates g ~ Gamma(k_cum[i], scale theta_t[i]) standardised as (g - k theta) / sqrt(1 - a_i);
- * an injected `noise` then holds the RAW g (what Gamma(...).sample() returns in the reference). */
+ * an injected `noise` then holds the RAW g (what Gamma(...).sample() returns in the reference).
+ * t_min is a DOUBLE, as the Python float the reference multiplies by the table length (:269): step i is skipped iff
+ * `steps[i] < t_min * L` evaluated as the reference evaluates it -- in float32 when the schedule was subsampled (there `step` is a
+ * 0-dim int64 tensor and torch compares it with a Python scalar in the default dtype), in double otherwise (numpy int64 vs float).
+ * A float parameter would move e.g. t_min = 0.1 to 0.100000001 and skip the step that sits exactly on the threshold. */
 int mcvd_sampler_run(mcvd_model* m, int kind, float* x_inout, const float* cond, const float* noise, uint64_t seed,
-                     uint64_t sample_offset, int subsample_steps, int flags, float t_min, int B);
+                     uint64_t sample_offset, int subsample_steps, int flags, double t_min, int B);
 /* The whole F-PNDM loop on the device (FPNDM_sampler, models/__init__.py:38-99 with models/pndm.py: Runge-Kutta for the first three
  * steps, 4th-order Adams-Bashforth afterwards; deterministic).  flags: MCVD_FLAG_CLIP_BEFORE.  x_inout is overwritten with the last step. */
 int mcvd_fpndm_run(mcvd_model* m, float* x_inout, const float* cond, int subsample_steps, int flags, int B);

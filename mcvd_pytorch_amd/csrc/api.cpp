@@ -333,6 +333,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     }
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
     else if (!strcmp(key, "persist_grid")) ctx->persist_grid = value;
+    else if (!strcmp(key, "q1_stagger")) ctx->q1_stagger = value;
     else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
     else if (!strcmp(key, "gn_inline")) ctx->gn_inline = value;
     else if (!strcmp(key, "gn_inline_max_wg")) ctx->gn_inline_max_wg = value;
@@ -818,7 +819,7 @@ int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst, int64
 
 // ------------------------------------------------------------------------------------------------ sampler
 int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const float* noise, uint64_t seed,
-                     uint64_t sample_offset, int subsample_steps, int flags, float t_min, int B) {
+                     uint64_t sample_offset, int subsample_steps, int flags, double t_min, int B) {
     API_TRY
     MCVD_REQUIRE(m && x && B > 0, "sampler_run: bad arguments");
     MCVD_REQUIRE(kind == MCVD_SAMPLER_DDPM || kind == MCVD_SAMPLER_DDIM, "sampler_run: kind %d", kind);
@@ -828,7 +829,8 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
     // schedule subsampling, models/__init__.py:229-237
     std::vector<int> steps;
     std::vector<float> al, alp, be;
-    if (subsample_steps > 0 && subsample_steps < T) {
+    const bool subsampled = subsample_steps > 0 && subsample_steps < T;
+    if (subsampled) {
         const int skip = T / subsample_steps;
         for (int t = 0; t < T; t += skip) steps.push_back(t);
         const int L = (int)steps.size();
@@ -879,9 +881,12 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
                                   draw, B, per, s);
     };
     for (int i = 0; i < L; ++i) {
-        if ((double)steps[i] < (double)t_min * (double)L) continue;                       // :269-270
+        // :269-270 `step < t_min*len(alphas)`: a 0-dim int64 tensor against a Python float on the subsampled schedule (torch compares in
+        // float32), a numpy int64 against it otherwise (double)
+        const double thr = t_min * (double)L;
+        if (subsampled ? ((float)steps[i] < (float)thr) : ((double)steps[i] < thr)) continue;
         const float a = al[i], ap = alp[i], b = be[i];
-        if (!started && t_min > 0.0f) {                                                   // :272-279
+        if (!started && t_min > 0.0) {                                                    // :272-279
             if (gam) {
                 if (int rc = gamma_draw(i)) return rc;
             }
@@ -1091,7 +1096,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
             if (int rc = launch_pack_wino3_weight(w, ctx->scratch + wfloats + a.CoutP + ufloats, Cout, a.Cin, a.CinP, a.CoutP, ctx->stream)) return rc;
             a.wpb = ctx->scratch + wfloats + a.CoutP + ufloats;
         }
-        if (pfloats) a.part = ctx->scratch + wfloats + a.CoutP + ufloats + hfloats;
+        if (pfloats) { a.part = ctx->scratch + wfloats + a.CoutP + ufloats + hfloats; a.part_floats = pfloats; }
     }
     if (int rc = launch_pack_conv_weight(w, ctx->scratch, Cout, a.Cin, ks, a.CinP, a.CoutP, 0, 0, ctx->stream)) return rc;
     if (np1) {
@@ -1105,6 +1110,7 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     if ((ctx->conv_shape == 5 || ctx->conv_shape == 6 || ctx->conv_shape == 9 || ctx->conv_shape == 14 || ctx->conv_shape == 15) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
     a.wdma = ctx->conv_wdma;
     a.pgrid = ctx->persist_grid;
+    a.stagger = ctx->q1_stagger;
     a.dbg = ctx->dbg;
     a.stats = ctx->naive_conv ? nullptr : ctx->stats_buf;
     if (ctx->spade_gb) {

@@ -92,10 +92,14 @@ struct ConvArgs {
                           // kernel as persistent workgroups (17: with a 2-way K split)
     int ksplit;           // Winograd kernel only: 2 = two workgroups per tile contract half the input channels each into
                           // `part`, a second pass sums the halves; 0/1 = off
-    float* part;          // ksplit == 2: scratch for the two partial results, 2 * B*Cout*H*W floats
+    float* part;          // ksplit >= 2: scratch for the partial results, ksplit * B*Cout*H*W floats
+    size_t part_floats;   // capacity of `part` in floats: a K split that needs more is not usable (the *_usable tests refuse it)
     int wdma;             // 1: stage weight chunks by LDS-DMA (default), 0: through registers
     int pgrid;            // persistent Winograd kernel (conv_wino3p.cpp) only: > 0 = number of workgroups (context option "persist_grid": tests
                           // drive long item ranges and sample changes with a few workgroups); 0 = one per CU
+    int stagger;          // conv1x1_h2 only (context option "q1_stagger"): every other workgroup of the FIRST dispatch round sleeps this many
+                          // kilo-cycles before it starts, so that the workgroups that share a CU (and the chip as a whole) are not all in their
+                          // K loops, then all in their store epilogues, at the same moments; 0 = off
     unsigned long long* dbg;   // optional: per-block phase cycle counters [n_blocks][8] (diagnostics), else null
     // GroupNorm statistics from the producer's epilogue (layerspp.py:518-549 consumes them): when non-null, the kernel writes for
     // every (sample, cout) `np` partial pairs (sum, M2 about the partial's own mean) over disjoint pixel sets of HW / np pixels
@@ -120,6 +124,10 @@ struct ConvArgs {
 };
 int last_conv_gn_fused();
 void set_last_conv_gn_fused(int v);
+// the K-split partials of this launch fit the scratch the caller handed over
+inline bool conv_part_fits(const ConvArgs& a) {
+    return a.part != nullptr && (size_t)(a.ksplit < 2 ? 2 : a.ksplit) * a.B * a.Cout * a.H * a.W <= a.part_floats;
+}
 bool ksplit_reduce_gn_usable(const ConvArgs& a);
 int launch_ksplit_reduce_gn(const ConvArgs& a, hipStream_t s);
 bool conv1x1_h2_kv_supported(const ConvArgs& a, int cot);

@@ -754,7 +754,7 @@ bool conv_wino_usable(const ConvArgs& a) {
            (a.C1 == 0 || a.C0 % WR_CK == 0) &&                                       // a chunk never straddles the concat seam
            (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) &&      // 32-bit byte offsets of the patch loads
            wino_lds_bytes(a.Cin, a.H == 8 && a.W == 8, a.gb != nullptr) <= 160 * 1024 &&
-           (a.ksplit != 2 || ((a.CinP / WR_CK) % 2 == 0 && a.CinP / WR_CK >= 4 && a.part != nullptr));
+           (a.ksplit != 2 || ((a.CinP / WR_CK) % 2 == 0 && a.CinP / WR_CK >= 4 && conv_part_fits(a)));
 }
 
 // a.wpw must hold the operand-major layout (launch_pack_wino_weight) packed for conv_wino_cout_tile(Cout).

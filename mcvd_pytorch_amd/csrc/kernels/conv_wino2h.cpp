@@ -708,7 +708,7 @@ bool conv_wino2h_usable(const ConvArgs& a) {
     return a.ks == 3 && ((a.H % 8 == 0 && a.W % 16 == 0 && a.H >= 8 && a.W >= 16) || g8) && a.wph && !a.gb && a.Cin <= 1024 &&
            a.CinP % H2_CK == 0 && (a.C1 == 0 || a.C0 % H2_CK == 0) && a.H * a.W <= 16384 &&
            (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) && wino2h_lds_bytes(a.Cin, g8) <= 160 * 1024 &&
-           (a.ksplit != 2 || ((a.CinP / H2_CK) % 2 == 0 && a.CinP / H2_CK >= 4 && a.part != nullptr));
+           (a.ksplit != 2 || ((a.CinP / H2_CK) % 2 == 0 && a.CinP / H2_CK >= 4 && conv_part_fits(a)));
 }
 
 // a.wph: the layout of launch_pack_wino2h_weight, packed for conv_wino_cout_tile(Cout).

@@ -788,7 +788,7 @@ bool conv_wino3_usable(const ConvArgs& a) {
            a.CinP % W3_CK == 0 && (a.C1 == 0 || a.C0 % W3_CK == 0) && a.H * a.W <= 16384 &&
            (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) && wino3_lds_bytes(a.Cin, g8) <= 160 * 1024 &&
            (a.ksplit < 2 || ((a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && (a.CinP / W3_CK) % a.ksplit == 0 &&
-                             a.CinP / W3_CK >= 2 * a.ksplit && a.part != nullptr));        // every part at least two chunks
+                             a.CinP / W3_CK >= 2 * a.ksplit && conv_part_fits(a)));        // every part at least two chunks
 }
 
 // a.wpb: the layout of launch_pack_wino3_weight, packed for conv_wino_cout_tile(Cout).

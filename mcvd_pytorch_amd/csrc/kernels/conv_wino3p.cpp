@@ -671,7 +671,7 @@ bool conv_wino3p_usable(const ConvArgs& a) {
            (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) && wino3p_lds_bytes(a.Cin) <= 160 * 1024 &&
            (long)a.B * (a.H / 8) * (a.W / 16) * (a.CoutP / 32) * 8 < (1L << 31) &&
            (a.ksplit >= 2 ? ((a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && nchunks % a.ksplit == 0 && nchunks / a.ksplit >= WP_MINCH &&
-                             a.part != nullptr)
+                             conv_part_fits(a))
                           : nchunks >= WP_MINCH);
 }
 

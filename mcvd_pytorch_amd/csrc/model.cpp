@@ -810,7 +810,9 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.shape_hint = (op.ks == 1 && ctx->conv_shape1 >= 0) ? ctx->conv_shape1 : ctx->conv_shape;
             a.wdma = ctx->conv_wdma;
             a.pgrid = ctx->persist_grid;
+            a.stagger = ctx->q1_stagger;
             a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
+            a.part_floats = a.part ? ksplit_floats : 0;
             const size_t oi = (size_t)(&op - ops.data());
             if (a.shape_hint == 14 || a.shape_hint == 15) {      // forced split-operand 1x1 GEMM (tests): a cout tile that kernel serves
                 const int np = a.shape_hint == 14 ? 2 : 3;
@@ -1096,7 +1098,9 @@ int mcvd_model::autotune(int B) {
             a.B = B; a.Cin = cin; a.CinP = op.CinP; a.Cout = op.Cout; a.CoutP = op.CoutP; a.H = op.H; a.W = op.W; a.ks = op.ks;
             a.wdma = ctx->conv_wdma;
             a.pgrid = ctx->persist_grid;
+            a.stagger = ctx->q1_stagger;
             a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
+            a.part_floats = a.part ? ksplit_floats : 0;
             const bool spade_fused = op.gb.kind != REF_NONE && ctx->spade_fuse && ctx->winograd;
             if (spade_fused) {
                 a.gb = resolve(op.gb, scratch_io, scratch_io, scratch_io, B);
@@ -1369,12 +1373,15 @@ int mcvd_model::ensure_ksplit(int B) {
 
 int mcvd_model::prepare_B(int B) {
     if (int rc = ensure_workspace(B)) return rc;
+    // BEFORE the K-split buffer is sized: a table tuned (or imported) under other options is dropped here, and ensure_ksplit must see
+    // the cache as the lookup below will -- sized from a stale shallow table it would be too small for the 4 / 8-part candidates
+    // autotune() then times (the launches carry the capacity as well, ConvArgs::part_floats)
+    sync_tuning_options();
     if (int rc = ensure_ksplit(B)) return rc;
     // (a forced two-piece kernel family -- the tests' conv_shape 12 / 13 / 14 -- needs the pieces as well as the option does)
     const bool forced_h = (ctx->conv_shape >= 12 && ctx->conv_shape <= 14) || ctx->conv_shape1 == 14;
     if (ctx->f16x2 || forced_h)
         if (int rc = ensure_f16x2_weights()) return rc;
-    sync_tuning_options();
     if (!ctx->naive_conv && tuned_B != B) {
         auto it = tuned_cache.find(B);
         if (it != tuned_cache.end() && it->second.first.size() == ops.size()) {     // tuned (or imported) before: no timing launches

@@ -47,6 +47,15 @@ def _subsample(net, subsample_steps):
     return steps, alphas, alphas_prev, betas
 
 
+def _skipped(step, t_min, n, subsampled):
+    """`step < t_min*len(alphas)` (models/__init__.py:269) as the reference evaluates it: on a subsampled schedule `step` is a 0-dim
+    int64 tensor and torch compares it with the Python float in float32; otherwise it is a numpy int64 and the comparison is in double."""
+    thr = t_min * n
+    if subsampled:
+        return bool(np.float32(step) < np.float32(thr))
+    return step < thr
+
+
 def _draw_seed():
     """A 63-bit seed from torch's default CPU generator, so torch.manual_seed() controls the device stream."""
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
@@ -97,9 +106,13 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
     step_list = list(range(0, d.num_classes, skip_all))
     if frac_steps is not None and kind == _lib.SAMPLER_DDPM:
         step_list = step_list[int((1 - frac_steps) * len(step_list)):]
-    n_exec = sum(1 for st in step_list if not (st < t_min * len(step_list)))
+    subsampled = subsample_steps is not None and subsample_steps < d.num_classes
+    n_exec = sum(1 for st in step_list if not _skipped(st, t_min, len(step_list), subsampled))
     if noise is not None:
-        need = (max(n_exec - 1, 0) if kind == _lib.SAMPLER_DDPM else 0) + (1 if (t_min > 0 and n_exec > 0) else 0)
+        # draws of the call: one per executed DDPM step but the last -- none with same_noise, where every step adds noise_val (:316-317) --
+        # plus the t_min re-noise of the first executed step, which always draws (:272-279)
+        step_draws = max(n_exec - 1, 0) if (kind == _lib.SAMPLER_DDPM and not same_noise) else 0
+        need = step_draws + (1 if (t_min > 0 and n_exec > 0) else 0)
         if noise.dim() != 5 or tuple(noise.shape[1:]) != tuple(x.shape) or noise.shape[0] < need:
             raise RuntimeError(f"injected noise has shape {tuple(noise.shape)}; need at least [{need}, {', '.join(map(str, x.shape))}]")
     if noise_val is not None and tuple(noise_val.shape) != tuple(x.shape):

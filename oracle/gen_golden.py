@@ -498,6 +498,142 @@ def gen_init_moments():
     print("wrote init_moments.pt")
 
 
+SURFACE_CASES = [
+    # key, kind, kwargs of the reference call (final_only=True, denoise=True, clip_before=True unless stated), pre-drawn noise tensors
+    ("ddpm_full1000", "ddpm", dict(subsample_steps=1000), 1000),          # `subsample_steps < len(alphas)` false (:229-230): tables as they are
+    ("ddpm_fullNone", "ddpm", dict(subsample_steps=None), 1000),          # :228 `subsample_steps is not None` false
+    ("ddim_full1000", "ddim", dict(subsample_steps=1000), 1),
+    ("ddim_fullNone_tmin0.9", "ddim", dict(subsample_steps=None, t_min=0.9), 2),                       # DDIM, tables as they are, 100 steps + re-noise
+    ("ddpm_full1000_tmin0.9_just_beta", "ddpm", dict(subsample_steps=1000, t_min=0.9, just_beta=True), 101),   # table betas + sqrt(beta) noise
+    ("ddpm_fullNone_tmin0.95", "ddpm", dict(subsample_steps=None, t_min=0.95), 51),
+    ("ddpm_10_just_beta", "ddpm", dict(subsample_steps=10, just_beta=True), 11),                       # :325-326
+    ("ddpm_tail_just_beta", "ddpm", dict(subsample_steps=1000, frac_steps=0.05, just_beta=True), 60),  # frac_steps + just_beta (host loop)
+    ("ddpm_10_same_noise", "ddpm", dict(subsample_steps=10, same_noise=True), 1),                      # :259-260, :316-317 (noise_val = x_mod copy)
+    ("ddpm_10_same_noise_val", "ddpm", dict(subsample_steps=10, same_noise=True, noise_val="NOISE_VAL"), 1),
+    ("ddpm_10_noise_val_ignored", "ddpm", dict(subsample_steps=10, same_noise=False, noise_val="NOISE_VAL"), 11),   # noise_val without same_noise: unused
+    ("ddpm_10_same_noise_tmin", "ddpm", dict(subsample_steps=10, same_noise=True, t_min=0.35), 2),     # the re-noise still DRAWS (:278)
+    ("ddpm_frac0.2", "ddpm", dict(subsample_steps=None, frac_steps=0.2), 200),                         # :250-254: the last 200 of 1000 steps
+    ("ddpm_frac0.1_tmin0.5", "ddpm", dict(subsample_steps=1000, frac_steps=0.1, t_min=0.5), 101),      # t_min test against the CUT length + re-noise
+    ("ddpm_10_nodenoise", "ddpm", dict(subsample_steps=10, denoise=False), 11),                        # :331
+    ("ddim_10_nodenoise", "ddim", dict(subsample_steps=10, denoise=False), 1),
+    ("ddpm_10_noclip", "ddpm", dict(subsample_steps=10, clip_before=False), 11),                       # :288
+    ("ddim_10_noclip", "ddim", dict(subsample_steps=10, clip_before=False), 1),
+    ("ddpm_10_images", "ddpm", dict(subsample_steps=10, final_only=False), 11),                        # :292-293, :334-335, :340 (CPU aliasing, see below)
+    ("ddim_10_images", "ddim", dict(subsample_steps=10, final_only=False), 1),
+    ("ddpm_10_images_nodenoise", "ddpm", dict(subsample_steps=10, final_only=False, denoise=False), 11),
+    # the t_min test `step < t_min*len(alphas)` (:269) exactly ON a step: 0.1 * 100 == 10.0 -> step 10 runs (a C float 0.1f * 100 =
+    # 10.0000001 would skip it); 0.3 * 100 = 30.000000000000004 in double but the subsampled schedule compares in float32 (0-dim int64
+    # tensor vs Python scalar) -> step 30 runs; 0.998 * 1000 == 998.0 on the full schedule (numpy int64: double comparison) -> 998 runs
+    ("ddpm_100_tmin0.1", "ddpm", dict(subsample_steps=100, t_min=0.1), 100),
+    ("ddim_100_tmin0.3", "ddim", dict(subsample_steps=100, t_min=0.3), 2),
+    ("ddpm_full1000_tmin0.998", "ddpm", dict(subsample_steps=1000, t_min=0.998), 3),
+]
+
+
+def surface_kwargs(kw, config, batch):
+    """The fixture stores kwargs with a placeholder for the explicit same-noise tensor; this builds the call's kwargs."""
+    out = dict(final_only=True, denoise=True, clip_before=True)
+    out.update(kw)
+    if out.get("noise_val", None) == "NOISE_VAL":
+        out["noise_val"] = synth.make_noise(config, batch, 1, seed=7)[0]
+    return out
+
+
+def gen_sampler_surface(name="tiny", batch=2, only_missing=False):
+    """Round 6: the parts of the kept `ddpm_sampler` / `ddim_sampler` surface that had no reference fixture.
+    The REAL samplers (models/__init__.py:102-340) on the synthetic tiny net with the injected noise sequence:
+      * the un-subsampled schedule (`subsample_steps` 1000 and None: schedule buffers used as they are, betas from the table and not
+        1 - a / a_prev, :228-237) -- the branch BASELINE config 4 (`subsample=1000`) runs;
+      * just_beta (:325-326), same_noise with and without an explicit noise_val (:259-260, :316-317), frac_steps (:250-254),
+        denoise=False (:331), clip_before=False (:288), final_only=False (:292-293, :334-335, :340).
+    `final_only=False` on a CPU run: `x_mod.to('cpu')` IS x_mod, so the later in-place `x_mod += c * noise` (:326-328) shows through in
+    the list -- image i < L - 1 of a DDPM fixture is the POST-noise state.  On an accelerator the list holds pre-noise copies.  The
+    fixture records what the CPU run returned; the tests add the step noise to the accelerator-semantics images before comparing."""
+    import models as ref_models
+    from oracle import sampler_ref
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    sd = synth.make_state_dict(config, seed=123)
+    net.load_state_dict(sd, strict=False)
+    x, cond = synth.make_inputs(config, batch, seed=0)
+    out = dict(config_name=name, batch=batch, cases={})
+    path = os.path.join(OUT, f"{name}_b{batch}_surface.pt")
+    if only_missing and os.path.exists(path):       # `surface_add`: keep the cases already in the file, run the new ones
+        out = torch.load(path, weights_only=False)
+    for key, kind, kw, n_noise in SURFACE_CASES:
+        if key in out["cases"]:
+            continue
+        noise = synth.make_noise(config, batch, n_noise, seed=2)
+        kwargs = surface_kwargs(kw, config, batch)
+        inj = NoiseInjector(noise)
+        orig = torch.randn_like
+        torch.randn_like = inj
+        try:
+            res = dict(ddpm=ref_models.ddpm_sampler, ddim=ref_models.ddim_sampler)[kind](
+                x.clone(), net, cond=cond, verbose=False, log=False, **kwargs)
+        finally:
+            torch.randn_like = orig
+        # the same call in float64 on the restatement: the noise floor a tolerance on this case stands on
+        k = [0]
+
+        def fn(i, like, noise=noise, k=k):
+            k[0] += 1
+            return noise[k[0] - 1].to(like.dtype)
+        kw64 = dict(kwargs)
+        if kw64.get("noise_val", None) is not None:
+            kw64["noise_val"] = kw64["noise_val"].double()
+        net64 = unet_ref.OracleScoreNet(config, sd, dtype=torch.float64)
+        res64 = sampler_ref.sample(x.double().clone(), net64, cond=cond.double(), kind=kind, noise_fn=fn, **kw64)
+        assert k[0] == inj.k, (key, k[0], inj.k)
+        cmp32 = res if kwargs["final_only"] else res[-1:]
+        drift = float((cmp32.double() - (res64 if kwargs["final_only"] else res64[-1:])).abs().max())
+        out["cases"][key] = dict(kind=kind, kwargs=dict(kw), n_noise=inj.k, n_predrawn=n_noise, result=res.clone(),
+                                 ref32_vs_ref64_max_abs=drift)
+        print(f"  {name}: {key}: draws {inj.k}, shape {tuple(res.shape)}, range [{res.min():.4f}, {res.max():.4f}], fp32 vs fp64 {drift:.3e}",
+              flush=True)
+    torch.save(out, path)
+    print(f"wrote {name}_b{batch}_surface.pt")
+
+
+def gen_full_schedule_wide(name="bair_big_spade", batch=1):
+    """Round 6: BASELINE config 4 as the bench runs it -- the REAL `ddpm_sampler` over the FULL 1000-step schedule (`subsample=1000`,
+    configs/bair_big_spade.yml; 1001 forwards of the SPADE net at full width), injected noise, final frames; plus the fp32-vs-fp64
+    distance of the same call on the restatement."""
+    import time
+    import models as ref_models
+    from oracle import sampler_ref
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    sd = synth.make_state_dict(config, seed=123)
+    net.load_state_dict(sd, strict=False)
+    x, cond = synth.make_inputs(config, batch, seed=0)
+    noise = synth.make_noise(config, batch, 1000, seed=2)
+    inj = NoiseInjector(noise)
+    orig = torch.randn_like
+    torch.randn_like = inj
+    t0 = time.time()
+    try:
+        res = ref_models.ddpm_sampler(x.clone(), net, cond=cond, final_only=True, denoise=True, subsample_steps=1000, clip_before=True,
+                                      verbose=False, log=False)
+    finally:
+        torch.randn_like = orig
+    print(f"  reference: {time.time() - t0:.0f} s, draws {inj.k}, range [{res.min():.4f}, {res.max():.4f}]", flush=True)
+    k = [0]
+
+    def fn(i, like):
+        k[0] += 1
+        return noise[k[0] - 1].to(like.dtype)
+    t0 = time.time()
+    net64 = unet_ref.OracleScoreNet(config, sd, dtype=torch.float64)
+    res64 = sampler_ref.sample(x.double().clone(), net64, cond=cond.double(), kind="ddpm", final_only=True, denoise=True,
+                               subsample_steps=1000, clip_before=True, noise_fn=fn)
+    drift = float((res.double() - res64).abs().max())
+    print(f"  fp64 restatement: {time.time() - t0:.0f} s; reference fp32 vs fp64 {drift:.3e}", flush=True)
+    torch.save(dict(config_name=name, batch=batch, subsample=1000, kind="ddpm", result=res.clone(), n_noise=inj.k,
+                    ref32_vs_ref64_max_abs=drift), os.path.join(OUT, f"{name}_b{batch}_ddpm1000.pt"))
+    print(f"wrote {name}_b{batch}_ddpm1000.pt")
+
+
 def main_round2():
     """Fixtures added in round 2 (VERDICT r01 'next round' item 1): the headline config end-to-end, configs 3 / 4 full samplers,
     the autoregressive driver at config 5 width, the BASELINE.json ch_mult variant, the cosine schedule."""
@@ -527,6 +663,12 @@ def main_round2():
         gen_init_moments()
     if "tiny" in which:           # round 5: regenerate the tiny fixtures with the DDIM drift recorded inside them
         gen_model_case("tiny", 3, [("ddpm", 10, {}), ("ddim", 10, {}), ("ddpm", 10, dict(t_min=0.35))])
+    if "surface" in which:        # round 6: the un-subsampled schedule and the untested kwargs of the kept sampler surface
+        gen_sampler_surface("tiny", 2)
+    if "surface_add" in which:
+        gen_sampler_surface("tiny", 2, only_missing=True)
+    if "cfg4full" in which:       # round 6: BASELINE config 4 over its full 1000-step schedule
+        gen_full_schedule_wide("bair_big_spade", 1)
     if "cs_spade" in which:
         gen_forward_only("cityscapes_big_spade", 1)          # shipped config with 192-channel heads (VERDICT r01 missing item 5)
 

@@ -31,11 +31,17 @@ def subsampled_schedule(alphas, alphas_prev, betas, subsample_steps):
 
 @torch.no_grad()
 def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=False, denoise=True,
-           subsample_steps=None, clip_before=True, t_min=-1, noise_fn=None, frac_steps=None, gamma=False):
+           subsample_steps=None, clip_before=True, t_min=-1, noise_fn=None, frac_steps=None, gamma=False,
+           same_noise=False, noise_val=None):
     """kind='ddpm': models/__init__.py:266-333.  kind='ddim': :142-198.
     noise_fn(i, like) -> tensor shaped like `like` (i = -1 for the t_min re-noise draw).
     gamma=True (:224-225, :238-240, :273-276, :319-322): noise_fn returns the RAW draw g ~ Gamma(k_cum[i], rate 1/theta[i]) and the
-    loop standardises it, z = (g - k theta) / sqrt(1 - alpha_i), as the reference does."""
+    loop standardises it, z = (g - k theta) / sqrt(1 - alpha_i), as the reference does.
+    same_noise / noise_val (:259-260, :316-317): every step adds the SAME tensor -- `noise_val`, or a copy of the incoming x_mod when
+    none is given -- and nothing is drawn for the steps (the t_min re-noise still draws).
+    `images` holds what the reference's list holds on an accelerator, where `x_mod.to('cpu')` (:293) is a copy taken BEFORE the step
+    noise is added in place (:326-328); on a CPU run of the reference `.to('cpu')` is the tensor itself and the in-place `+=` shows
+    through (tests that compare against a CPU-generated `final_only=False` fixture add the step noise back)."""
     assert kind in ("ddpm", "ddim")
     if noise_fn is None:
         noise_fn = lambda i, like: torch.randn_like(like)
@@ -51,6 +57,9 @@ def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=
         alphas, alphas_prev, betas = alphas[steps], alphas_prev[steps], betas[steps]
         if gamma:
             ks_cum, thetas = ks_cum[steps], thetas[steps]
+
+    if same_noise and noise_val is None:                              # :259-260
+        noise_val = x_mod.detach().clone()
 
     def std(g, i):
         return (g - ks_cum[i] * thetas[i]) / (1 - alphas[i]).sqrt() if gamma else g
@@ -83,7 +92,7 @@ def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=
             images.append(x_mod.clone())
 
         if kind == "ddpm" and i + 1 != L:                             # :311-328
-            noise = std(noise_fn(i, x_mod), i)
+            noise = noise_val if same_noise else std(noise_fn(i, x_mod), i)   # :316-322
             if just_beta:
                 x_mod = x_mod + c_beta.sqrt() * noise
             else:

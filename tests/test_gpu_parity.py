@@ -2048,7 +2048,7 @@ def test_direct_rccl_weight_broadcast_two_ranks(tmp_path):
     assert torch.equal(a, b)
 
 
-def _bench_job(tmp_path, tag, gpus, batch, backend=None, tune_cache=None, save_tuning=None):
+def _bench_job(tmp_path, tag, gpus, batch, backend=None, tune_cache=None, save_tuning=None, global_batch=None):
     """One bench.py job (self-launching for gpus > 1): returns (JSON line, frames of the last timed step)."""
     import json
     import subprocess
@@ -2070,6 +2070,8 @@ def _bench_job(tmp_path, tag, gpus, batch, backend=None, tune_cache=None, save_t
         cmd += ["--tune-cache", tune_cache]
     if save_tuning:
         cmd += ["--save-tuning", save_tuning]
+    if global_batch:
+        cmd += ["--global-batch", str(global_batch)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1]), torch.load(dump)
@@ -2101,6 +2103,27 @@ def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path):
     test's first form found out why they must be -- kernels of the two processes that share a SIMD corrupt each other
     (profiles/r04_two_process_corruption.txt; not a property of the multi-rank plumbing under test here)."""
     _two_rank_job_matches_single_rank(tmp_path, "gloo")
+
+
+def test_bench_four_ranks_uneven_shards_on_one_gpu_match_single_rank(tmp_path):
+    """VERDICT r5 item 9 (8-GPU readiness without an 8-GPU box): FOUR serialised ranks on device 0 with UNEVEN shards -- a global batch of
+    10 rows, shards 3 + 3 + 2 + 2 (dist.shard_rows) -- against the single-rank job of the same 10 rows, bit for bit: every rank's
+    sample_offset keys its Philox rows by the GLOBAL row, the padded all_gather trims each shard to its own length, the line lists four
+    distinct ranks and each rank's own row count and busy time."""
+    import json
+    d1, f1 = _bench_job(tmp_path, "n1", 1, 10, save_tuning=str(tmp_path))
+    table = json.load(open(os.path.join(str(tmp_path), "tune_smmnist_big5_ngf96_B10_bf16x3.json")))["10"]
+    cache = os.path.join(str(tmp_path), "table_all.json")
+    json.dump({"10": table, "3": table, "2": table}, open(cache, "w"))
+    d1, f1 = _bench_job(tmp_path, "n1", 1, 10, tune_cache=cache)
+    d4, f4 = _bench_job(tmp_path, "n4", 4, 3, backend="gloo", tune_cache=cache, global_batch=10)
+    assert d4["n_gpus"] == 4 and d4["config"]["global_batch"] == 10 and d4["config"]["frames_per_step"] == 50
+    assert d4["rccl_ranks_seen"]["world_size"] == 4 and sorted(d4["rccl_ranks_seen"]["ranks"]) == [0, 1, 2, 3]
+    assert d4["per_rank_rows"] == [3, 3, 2, 2] and len(d4["per_rank_busy_s"]) == 4 and all(t > 0 for t in d4["per_rank_busy_s"])
+    assert d4["per_rank_spread"] >= 1.0 and d4["valid"] is True            # uneven shards: the straggler rule does not apply
+    assert d1["selfcheck_max_abs"] == 0.0 and d4["selfcheck_max_abs"] == 0.0
+    assert f1.shape == f4.shape == (10, 5, 64, 64)
+    assert torch.equal(f1, f4), f"N=4 (3+3+2+2 rows) frames differ from N=1: max {float((f1 - f4).abs().max()):.3e}"
 
 
 def test_bench_two_gpus(tmp_path):

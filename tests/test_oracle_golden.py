@@ -295,3 +295,82 @@ def test_topology_counts(name, n_mod, n_param):
     assert len(unet_ref.module_plan(c)) == n_mod
     if n_param is not None:
         assert len(unet_ref.param_shapes(c)) == n_param
+
+
+# ------------------------------------------------------------------ round 6: the rest of the kept sampler surface (tiny_b2_surface.pt)
+SURFACE_KEYS = [
+    "ddpm_full1000", "ddpm_fullNone", "ddim_full1000", "ddim_fullNone_tmin0.9", "ddpm_full1000_tmin0.9_just_beta",
+    "ddpm_fullNone_tmin0.95", "ddpm_10_just_beta", "ddpm_tail_just_beta", "ddpm_10_same_noise", "ddpm_10_same_noise_val",
+    "ddpm_10_noise_val_ignored", "ddpm_10_same_noise_tmin", "ddpm_frac0.2", "ddpm_frac0.1_tmin0.5", "ddpm_10_nodenoise",
+    "ddim_10_nodenoise", "ddpm_10_noclip", "ddim_10_noclip", "ddpm_10_images", "ddim_10_images", "ddpm_10_images_nodenoise",
+    "ddpm_100_tmin0.1", "ddim_100_tmin0.3", "ddpm_full1000_tmin0.998",
+]
+
+
+def surface_case(golden_dir, key):
+    """(config, batch, x, cond, noise, case dict, call kwargs, tolerance) of one case of tiny_b2_surface.pt.  Tolerance: 1e-4 on frames
+    in [-1, 1], 3e-4 for the deterministic DDIM (no step noise washes rounding out), relative 1e-5 where clip_before=False
+    lets |x| grow to ~1e3; each stands at least 3x above the reference's own fp32-vs-fp64 distance recorded in the fixture."""
+    g = load(golden_dir, "tiny_b2_surface.pt")
+    c = g["cases"][key]
+    config = synth.make_config(g["config_name"])
+    B = g["batch"]
+    x, cond = synth.make_inputs(config, B, seed=0)
+    noise = synth.make_noise(config, B, c["n_predrawn"], seed=2)
+    kw = dict(final_only=True, denoise=True, clip_before=True)
+    kw.update(c["kwargs"])
+    if kw.get("noise_val", None) == "NOISE_VAL":
+        kw["noise_val"] = synth.make_noise(config, B, 1, seed=7)[0]
+    ref = c["result"]
+    tol = 3e-4 if c["kind"] == "ddim" else 1e-4
+    if not kw["clip_before"]:
+        tol = 1e-5 * ref.abs().max().item()
+    assert 0.0 < c["ref32_vs_ref64_max_abs"] and 3.0 * c["ref32_vs_ref64_max_abs"] <= tol, (key, c["ref32_vs_ref64_max_abs"], tol)
+    return config, B, x, cond, noise, c, kw, tol
+
+
+def add_back_step_noise(images, kind, kw, noise, alphas_full, alphas_prev_full, betas_full):
+    """`final_only=False` images with accelerator semantics (pre-noise copies) -> what a CPU run of the reference returns, where
+    `x_mod.to('cpu')` aliases x_mod and the in-place `x_mod += c * noise` (models/__init__.py:326-328) shows through: image i of a DDPM
+    run gains the step's noise term for every step but the last (DDIM adds no noise; the denoise image is a new tensor)."""
+    if kind != "ddpm":
+        return images
+    steps, al, alp, be = sampler_ref.subsampled_schedule(alphas_full, alphas_prev_full, betas_full, kw["subsample_steps"])
+    out = images.clone()
+    L = len(steps)
+    for i in range(L - 1):
+        cn = be[i].sqrt() if kw.get("just_beta", False) else ((1 - alp[i]) / (1 - al[i]) * be[i]).sqrt()
+        out[i] = out[i] + cn * noise[i]
+    return out
+
+
+@pytest.mark.parametrize("key", SURFACE_KEYS)
+def test_sampler_surface_matches_reference(golden_dir, key):
+    """The un-subsampled schedule (subsample_steps 1000 / None: tables as they are, models/__init__.py:228-237 not taken) and the kwargs
+    just_beta / same_noise / noise_val / frac_steps / denoise=False / clip_before=False / final_only=False of the REAL samplers."""
+    config, B, x, cond, noise, c, kw, tol = surface_case(golden_dir, key)
+    net = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123))
+    fn, k = _injector(noise)
+    out = sampler_ref.sample(x.clone(), net, cond=cond, kind=c["kind"], noise_fn=fn, **kw)
+    assert k[0] == c["n_noise"], (key, k[0], c["n_noise"])
+    if not kw["final_only"]:
+        out = add_back_step_noise(out, c["kind"], kw, noise, net.alphas, net.alphas_prev, net.betas)
+    ref = c["result"]
+    assert out.shape == ref.shape
+    err = (out - ref).abs().max().item()
+    assert err <= tol, f"{key}: {err:.3e} > {tol:.1e}"
+
+
+def test_full_schedule_uses_the_table_betas(golden_dir):
+    """What separates the un-subsampled branch from a subsampling with skip 1: betas are the TABLE's (linspace), not 1 - a / a_prev
+    recomputed in fp32 (models/__init__.py:236 'for some reason we lose a bit of precision here') -- the two differ in the last bits,
+    and the oracle must take the table."""
+    config = synth.make_config("tiny")
+    net = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123))
+    for sub in (1000, None, 2000):
+        steps, al, alp, be = sampler_ref.subsampled_schedule(net.alphas, net.alphas_prev, net.betas, sub)
+        assert len(steps) == 1000 and torch.equal(be, net.betas) and torch.equal(al, net.alphas) and torch.equal(alp, net.alphas_prev)
+    recomputed = 1.0 - net.alphas / net.alphas_prev
+    assert not torch.equal(recomputed, net.betas)
+    steps, al, alp, be = sampler_ref.subsampled_schedule(net.alphas, net.alphas_prev, net.betas, 999)   # skip 1, but the branch IS taken
+    assert len(steps) == 1000 and torch.equal(be, recomputed)
