@@ -119,7 +119,7 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         bit-identical to 10 / 11; 17: K split), 18 / 19 the three-piece bf16 Winograd kernel with the input channels in 4 / 8 parts and
  *         20 the persistent kernel with 4 parts (small batches: 8x8 / 16x16 layers with fewer (region, cout tile) pairs than CUs; the
  *         parts are summed in index order by the reduce pass -- deterministic; a layer without the chunks for the depth takes the next
- *         shallower split); 21 the fp32 VALU direct kernel for at most 16 output channels; 22 / 23 (models only, not mcvd_op_conv2d) a 3x3
+ *         shallower split); 22 / 23 (models only, not mcvd_op_conv2d) a 3x3
  *         conv with a handful of channels on one side as a 1x1 GEMM on the three-piece bf16 kernel: 23 = im2col of at most 10 input
  *         channels + GEMM (the stem), 22 = GEMM to 9 * Cout planes (Cout <= 7) + shift-and-add (the last conv); kernels/conv_gemm_forms.cpp.
  *         A family that does not serve a launch falls back.  "persist_grid" (0 = one workgroup

@@ -333,7 +333,6 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     }
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
     else if (!strcmp(key, "persist_grid")) ctx->persist_grid = value;
-    else if (!strcmp(key, "q1_stagger")) ctx->q1_stagger = value;
     else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
     else if (!strcmp(key, "gn_inline")) ctx->gn_inline = value;
     else if (!strcmp(key, "gn_inline_max_wg")) ctx->gn_inline_max_wg = value;
@@ -1110,7 +1109,6 @@ int mcvd_op_conv2d(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int 
     if ((ctx->conv_shape == 5 || ctx->conv_shape == 6 || ctx->conv_shape == 9 || ctx->conv_shape == 14 || ctx->conv_shape == 15) && ctx->conv_cot > 0) a.cot = ctx->conv_cot;
     a.wdma = ctx->conv_wdma;
     a.pgrid = ctx->persist_grid;
-    a.stagger = ctx->q1_stagger;
     a.dbg = ctx->dbg;
     a.stats = ctx->naive_conv ? nullptr : ctx->stats_buf;
     if (ctx->spade_gb) {

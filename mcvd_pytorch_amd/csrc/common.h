@@ -97,9 +97,6 @@ struct ConvArgs {
     int wdma;             // 1: stage weight chunks by LDS-DMA (default), 0: through registers
     int pgrid;            // persistent Winograd kernel (conv_wino3p.cpp) only: > 0 = number of workgroups (context option "persist_grid": tests
                           // drive long item ranges and sample changes with a few workgroups); 0 = one per CU
-    int stagger;          // conv1x1_h2 only (context option "q1_stagger"): every other workgroup of the FIRST dispatch round sleeps this many
-                          // kilo-cycles before it starts, so that the workgroups that share a CU (and the chip as a whole) are not all in their
-                          // K loops, then all in their store epilogues, at the same moments; 0 = off
     unsigned long long* dbg;   // optional: per-block phase cycle counters [n_blocks][8] (diagnostics), else null
     // GroupNorm statistics from the producer's epilogue (layerspp.py:518-549 consumes them): when non-null, the kernel writes for
     // every (sample, cout) `np` partial pairs (sum, M2 about the partial's own mean) over disjoint pixel sets of HW / np pixels
@@ -139,13 +136,10 @@ int conv_chunk(int ks);                       // input-channel chunk the MFMA ke
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 int launch_conv_naive(const ConvArgs& a, hipStream_t s);
 int last_conv_kernel();                       // kernel family of this thread's last launch_conv_mfma (see conv.cpp)
-// fp32 VALU direct conv for layers with at most 16 output channels (the network's last conv; conv_small_cout.cpp): tile shape id 21
-bool conv_small_cout_usable(const ConvArgs& a);
 // 3x3 convs with a handful of channels on one side as 1x1 GEMMs (conv_gemm_forms.cpp): shape ids 22 (taps as outputs + shift-and-add) / 23 (im2col)
 int launch_im2col3x3(const float* x0, int C0, const float* x1, int C1, float* col, int B, int H, int W, int K, hipStream_t s);
 int launch_taps_shift_add(const float* z, const float* bias, const float* res, float scale, float* y, int B, int Cout, int H, int W, hipStream_t s);
 int launch_pack_conv_gemm_form(const float* w, float* wp, int Cout, int Cin, int form, int CoutP, hipStream_t s);
-int launch_conv_small_cout(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2,3x3) kernel (conv_wino.cpp): tile shape id 4 of the dispatcher
 bool conv_wino_supported(int ks, int H, int W);      // geometry only (decides whether transformed weights are packed at all)
 int conv_wino_cout_tile(int Cout);

@@ -57,7 +57,6 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     auto blocks = [&](int bpx) { return ((px + bpx - 1) / bpx) * ntc; };
     auto fits = [&](int bpx) { return bpx % a.W == 0 && (bpx / a.W <= a.H ? a.H % (bpx / a.W) == 0 : (bpx / a.W) % a.H == 0); };
     int shape;
-    if (a.shape_hint == 21 && conv_small_cout_usable(a)) { g_last_conv_kernel = 21; return launch_conv_small_cout(a, s); }   // <= 16 couts: fp32 VALU direct conv
     // hints 4 / 5 select the specialised kernels where they apply and fall back to the tile heuristic elsewhere
     if (a.shape_hint == 13) {                                       // f16x2 Winograd with a 2-way K split
         ConvArgs b = a;

@@ -68,12 +68,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int ptile = (slot / nct) * 8 + xcd, ctile = slot - (slot / nct) * nct;
     if (ptile >= ptiles) return;
-    if (a.stagger > 0 && blockIdx.x < 512 && ((slot + (slot >> 5)) & 1)) {
-        // phase stagger: the first dispatch round (two workgroups on each of 256 CUs) starts in lockstep and -- every workgroup taking the
-        // same time -- stays there: all K loops (matrix pipe busy, HBM idle), then all store epilogues (HBM write burst, matrix pipe idle).
-        // Half of that round starts late; the dispatcher keeps the offset for the rounds that follow (a workgroup starts when one ends).
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);          // 16 x 64 cycles
-    }
     const int co0 = ctile * BCO;
     const int HW = a.H * a.W, Cin = a.Cin;
     const long NPX = (long)a.B * HW;

@@ -810,7 +810,6 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             a.shape_hint = (op.ks == 1 && ctx->conv_shape1 >= 0) ? ctx->conv_shape1 : ctx->conv_shape;
             a.wdma = ctx->conv_wdma;
             a.pgrid = ctx->persist_grid;
-            a.stagger = ctx->q1_stagger;
             a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
             a.part_floats = a.part ? ksplit_floats : 0;
             const size_t oi = (size_t)(&op - ops.data());
@@ -1098,7 +1097,6 @@ int mcvd_model::autotune(int B) {
             a.B = B; a.Cin = cin; a.CinP = op.CinP; a.Cout = op.Cout; a.CoutP = op.CoutP; a.H = op.H; a.W = op.W; a.ks = op.ks;
             a.wdma = ctx->conv_wdma;
             a.pgrid = ctx->persist_grid;
-            a.stagger = ctx->q1_stagger;
             a.part = (op.ks == 3 && op.H * op.W <= 256) ? ksplit_buf : nullptr;
             a.part_floats = a.part ? ksplit_floats : 0;
             const bool spade_fused = op.gb.kind != REF_NONE && ctx->spade_fuse && ctx->winograd;
@@ -1138,8 +1136,6 @@ int mcvd_model::autotune(int B) {
                 }
             }
             a.cot = op.cot;
-            if (op.ks == 3 && op.Cout <= 16 && !spade_fused && conv_small_cout_usable(a))      // 21 = fp32 VALU direct conv for the last layer's handful of couts
-                if (int rc = time_candidate(21, op.cot)) return rc;
             if (op.alt_kind && !spade_fused && op.gb.kind == REF_NONE) {         // 22 / 23 = the conv as a 1x1 GEMM on the three-piece kernel + its copy / shift pass
                 ConvArgs t = a;
                 t.shape_hint = op.alt_kind;

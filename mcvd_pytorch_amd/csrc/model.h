@@ -27,7 +27,6 @@ struct mcvd_ctx {
                                    //    every 3x3 conv AND every 1x1 conv of a model on chosen kernels at once
     int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
     int persist_grid = 0;          // > 0: workgroups of the persistent Winograd kernel (tests); 0 = one per CU
-    int q1_stagger = 0;            // conv1x1_h2: start delay (kilo-cycles) of every other workgroup of the first dispatch round (ConvArgs::stagger)
     int wino_selftest = 0;         // 0 not run yet, 1 passed, -1 FAILED: the hand-scheduled bf16 Winograd kernels disagree with the fp32-MFMA Winograd
                                    //    kernel on this device / driver (mcvd_ctx_selftest); bf16x3 was switched off for this context
     int conv_cot = 0;              // > 0 with conv_shape 5: cout tile (32-channel units) mcvd_op_conv2d requests (tests)

@@ -499,7 +499,6 @@ def w2htl(f):
     between two workgroups (dispatch gap)."""
     from tests.hiputil import Ctx, P
     ctx = Ctx()
-    ctx.opt("q1_stagger", int(os.environ.get("MCVD_Q1_STAGGER", "0")))
     B = 64
     cases = [(96, 96, 64, 3, 12, 0), (480, 192, 32, 3, 12, 0), (192, 576, 32, 1, 14, 2), (192, 576, 32, 1, 14, 3), (288, 96, 64, 1, 14, 3), (384, 1152, 8, 1, 14, 3)]
     if os.environ.get("MCVD_TL_B3", "1") != "0":          # the three-piece bf16 kernels (default) instead of the two-piece fp16 ones
@@ -514,7 +513,7 @@ def w2htl(f):
         coef = torch.ones(B, cin, 2, device="cuda")
         ctx.opt("conv_shape", shp)
         ctx.opt("conv_cot", cot)
-        f.write(f"--- {ks}x{ks} shape {shp} cot {cot} exp {os.environ.get('MCVD_Q1_EXP', '0')} stagger {os.environ.get('MCVD_Q1_STAGGER', '0')}: ")
+        f.write(f"--- {ks}x{ks} shape {shp} cot {cot} exp {os.environ.get('MCVD_Q1_EXP', '0')}: ")
         os.environ["MCVD_DBG_WAVE"] = "0"
         for _ in range(3):
             ctx.conv2d(x, w, b, coef=coef, act=act_tl, scale=0.7)

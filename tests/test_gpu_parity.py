@@ -203,45 +203,6 @@ def test_conv2d(ctx, case, naive):
     _close(got, want, what=f"conv {case}")
 
 
-@pytest.mark.parametrize("B,C0,C1,Cout,H,use_coef,act,use_res", [
-    (2, 96, 0, 5, 64, True, 1, False),      # the headline net's last layer: GroupNorm + SiLU -> conv3x3(96 -> 5)
-    (3, 128, 0, 15, 64, True, 1, False),    # 15 = 3 channels x 5 frames (BASELINE configs 4 / 5), odd batch
-    (2, 42, 25, 8, 64, True, 0, True),      # concat input with the seam inside a chunk, affine without SiLU, residual + scale, ragged last chunk (67 channels)
-    (1, 20, 0, 3, 128, False, 0, False),    # raw input, ragged chunk (20 channels), 128 x 128
-])
-def test_conv_small_cout_direct_kernel(ctx, B, C0, C1, Cout, H, use_coef, act, use_res):
-    """Shape id 21 (conv_small_cout.cpp): the fp32 VALU direct conv for layers with at most 16 output channels -- the network's last conv,
-    which the matrix-pipe kernels serve on a 32-cout tile that is 27 / 32 zeros.  Exact fp32 FMA chains; against
-    F.conv2d at the per-op tolerance and against an fp64 convolution (layers.py:107-113)."""
-    from mcvd_pytorch_amd import _lib
-    g = _g(37)
-    Cin = C0 + C1
-    x0 = torch.randn(B, C0, H, H, generator=g)
-    x1 = torch.randn(B, C1, H, H, generator=g) if C1 else None
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
-    bias = 0.1 * torch.randn(Cout, generator=g)
-    coef = torch.stack([1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], dim=-1) if use_coef else None
-    res = torch.randn(B, Cout, H, H, generator=g) if use_res else None
-    scale = 0.70710678 if use_res else 1.0
-    xin = torch.cat([x0, x1], 1) if C1 else x0
-    if use_coef:
-        xin = xin * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]
-    if act:
-        xin = unet_ref.silu(xin)
-    want64 = F.conv2d(xin.double(), w.double(), bias.double(), padding=1)
-    if use_res:
-        want64 = want64 + res.double()
-    want64 = want64 * scale
-    dev = lambda t: t.cuda().contiguous() if t is not None else None
-    ctx.opt("conv_shape", 21)
-    got = ctx.conv2d(dev(x0), dev(w), dev(bias), x1=dev(x1), coef=dev(coef), act=act, res=dev(res), scale=scale)
-    assert _lib.lib.mcvd_last_conv_kernel() == 21
-    ctx.opt("conv_shape", -1)
-    _close(got, want64.float(), what="small-cout conv")
-    err = ((got.cpu().double() - want64).abs().max() / want64.abs().max()).item()
-    assert err < 3e-6, err
-
-
 def _structured(kind, B, Cin, H, g):
     """Inputs on which operand-representation errors do NOT average out: constant planes, one dominant channel, sums that
     cancel (channel pairs carry the same plane; the test pairs the weights w, -w), and plain Gaussian data."""
