@@ -138,12 +138,9 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         mcvd_sampler_run presents the same set on every step.  Any option change, re-tune, workspace growth or mcvd_model_finalize
  *         drops the captured graph.  Also MCVD_GRAPH=1 in the environment at mcvd_ctx_create.
  *     "gn_stats" (1): GroupNorm statistics come out of the producing conv's epilogue where the kernel supports it (0: always one pass
- *         over the normalised tensor).  "gn_inline" (0): 1 = where every source of a norm has at most 8 partial statistics per channel (32x32 and
- *         smaller layers) AND the consuming conv launch has at most "gn_inline_max_wg" workgroups (default: two per CU) the conv reduces them
- *         in its own prologue and no finalize kernel is launched for that norm (kernels/gn_inline.h, mcvd_model_gn_inlined).  Off by
- *         default: the finalize launches it spares (2.4 % of the GPU time by their durations) overlap with their neighbours inside the
- *         graph, the redundant reduction in every workgroup does not -- measured 0.3-1 % slower on every config
- *         (profiles/r03_gn_inline_ab.txt).  "spade_fuse" (0): 1 = the SPADE modulation inside the fp32 Winograd conv loader (gamma | beta by
+ *         over the normalised tensor).
+ *         (The consumer-side reduction of those statistics, option "gn_inline" of rounds 3-5, measured 0.3-1 % slower on every config and was
+ *         removed in round 6: profiles/r03_gn_inline_ab.txt.)  "spade_fuse" (0): 1 = the SPADE modulation inside the fp32 Winograd conv loader (gamma | beta by
  *         LDS-DMA; measured 3.5 % slower end to end than the materialising spade_apply kernel).  "side_stream" (0): ResBlock shortcut
  *         convs on a second HIP stream (measured slower; UNSAFE beside the split-operand attention kernel: INTEGRATION.md section 4).
  *         "gn_producer" (1): the second pass of a K-split Winograd layer over 8 x 8 / 16 x 16 planes also writes the (A, B) table of the
@@ -151,15 +148,13 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         skipped; 0 = two launches.
  *         "fir_form" (0): 0 = the x2 FIR resamplers stage a strip of 1024 input elements through the LDS (prologue applied once per
  *         element; power-of-two widths 8..256), 1 = the register-window forms only; bit-identical (up_or_down_sampling.py:196-258).
- *         "spade_norm_fuse" (0): 1 = a SPADE norm in front of a conv is ONE launch -- GroupNorm finalize from the producers' epilogue partials +
- *         (1 + gamma) / beta modulation + temb pair + SiLU (spade_norm_apply_kernel; layerspp.py:152-173, :530-535) -- instead of
- *         gn_finalize + spade_apply; bit-identical; measured -1 ... +0.7 % end to end on config 4 (profiles/r05_spade_fusion_ab.txt): off.  "spade_fuse_auto" (1): the autotuner also times, per SPADE-normed 3x3 layer,
- *         [gn_finalize + conv with the modulation in its fp32 Winograd loader] against [spade_norm_apply + the best plain conv] and marks the
- *         layers where the fused loader wins with shape ids 36 / 40 (= 32 + 4 / 8).  "attn_presplit" (1): the fused q|k|v projection
+ *         (Rounds 5's "spade_norm_fuse" -- finalize + modulation in one launch, -1 ... +0.7 % -- and "spade_fuse_auto" -- the fused loader
+ *         offered per layer as shape ids 36 / 40, chosen for 0 of 57 layers -- were removed in round 6: profiles/r05_spade_fusion_ab.txt.)
+ *         "attn_presplit" (1): the fused q|k|v projection
  *         writes K and V already split into the three bf16 pieces, in the LDS-image order of the attention kernel, which then stages its
  *         tiles by LDS-DMA (head dims 32 / 64 / 96, default arithmetic, a device of its own); bit-identical to 0 (the attention kernel splits
  *         K / V itself, once per query tile).  "profile" (0/1): see mcvd_model_profile_read.
- * Environment variables read ONCE at mcvd_ctx_create set the same options: MCVD_AUTOTUNE, MCVD_SIDE_STREAM, MCVD_WINOGRAD, MCVD_CONV_DMA1, MCVD_GN_INLINE,
+ * Environment variables read ONCE at mcvd_ctx_create set the same options: MCVD_AUTOTUNE, MCVD_SIDE_STREAM, MCVD_WINOGRAD, MCVD_CONV_DMA1,
  * MCVD_BF16X3, MCVD_F16X2, MCVD_GRAPH, MCVD_GN_STATS, MCVD_SPADE_FUSE, MCVD_NAIVE; MCVD_ALLOW_SHARED_DEVICE (see mcvd_ctx_create) is read there
  * too.  Nothing else in the production library reads the
  * environment (the diagnostics build, csrc/build.py --diag, adds timing-only ablation hooks). */
@@ -277,15 +272,10 @@ int mcvd_model_op_info(mcvd_model* m, int i, int info[8]);
  * use it to assert that a forced or imported kernel table is what executed (a graph replay re-runs what its capture recorded). */
 int mcvd_model_op_kernel(mcvd_model* m, int i);
 
-/* How many GroupNorm finalize launches this model has NOT made so far because the consuming conv reduced the producers' partial
- * statistics in its own prologue (ctx option "gn_inline", default 0; csrc/kernels/gn_inline.h): a running total over the eager
- * forwards and graph captures of the model (a graph replay re-runs what its capture recorded).  Tests use it to assert that the
- * fused path really ran; -1 for a NULL model. */
-long mcvd_model_gn_inlined(mcvd_model* m);
 /* Launch counters of the fused forms that have no reference counterpart (diagnostics / tests), cumulative over the model's forwards:
  * what = 0: attention blocks whose K and V went from the q|k|v projection to the attention kernel pre-split (option "attn_presplit",
- * layerspp.py:236-245 computes the same products on fp32 rows); 1: SPADE norms finalized inside the modulating kernel (option
- * "spade_norm_fuse", layerspp.py:152-173); 2: convs that took the SPADE modulation inside their loader (shape ids 36 / 40 or "spade_fuse"); 3: norms whose table the producing
+ * layerspp.py:236-245 computes the same products on fp32 rows); 1: unused (always 0);
+ * 2: convs that took the SPADE modulation inside their loader (option "spade_fuse"); 3: norms whose table the producing
  * conv's K-split reduce pass wrote ("gn_producer"). */
 long mcvd_model_fused_launches(mcvd_model* m, int what);
 

@@ -74,7 +74,6 @@ _PROTOS = {
     "mcvd_model_profile_read": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "mcvd_model_op_info": (_i, [_vp, _i, C.POINTER(_i)]),
     "mcvd_model_op_kernel": (_i, [_vp, _i]),
-    "mcvd_model_gn_inlined": (C.c_long, [_vp]),
     "mcvd_model_fused_launches": (C.c_long, [_vp, _i]),
     "mcvd_model_module_output": (_i, [_vp, _i, _i, _vp, _i64, C.POINTER(_i), C.POINTER(_i)]),
     "mcvd_sampler_run": (_i, [_vp, _i, _vp, _vp, _vp, _u64, _u64, _i, _i, C.c_double, _i]),

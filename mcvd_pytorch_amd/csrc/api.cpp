@@ -142,7 +142,6 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     c->device = device;
     c->shared_device = taken == 1 ? 1 : 0;
     c->stream = (hipStream_t)hip_stream;
-    c->gn_inline_max_wg = 2 * prop.multiProcessorCount;
     if (const char* t = getenv("MCVD_AUTOTUNE")) c->autotune = atoi(t);
     if (const char* t = getenv("MCVD_SIDE_STREAM")) c->side_stream = atoi(t);
     if (const char* t = getenv("MCVD_WINOGRAD")) c->winograd = atoi(t);
@@ -151,7 +150,6 @@ int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out) {
     if (const char* t = getenv("MCVD_F16X2")) c->f16x2 = atoi(t);
     if (const char* t = getenv("MCVD_GRAPH")) c->graph = atoi(t);
     if (const char* t = getenv("MCVD_GN_STATS")) c->gn_stats = atoi(t);
-    if (const char* t = getenv("MCVD_GN_INLINE")) c->gn_inline = atoi(t);
     if (const char* t = getenv("MCVD_SPADE_FUSE")) c->spade_fuse = atoi(t);
     const char* e = getenv("MCVD_NAIVE");
     if (e) {
@@ -334,12 +332,8 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
     else if (!strcmp(key, "persist_grid")) ctx->persist_grid = value;
     else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
-    else if (!strcmp(key, "gn_inline")) ctx->gn_inline = value;
-    else if (!strcmp(key, "gn_inline_max_wg")) ctx->gn_inline_max_wg = value;
     else if (!strcmp(key, "spade_fuse")) ctx->spade_fuse = value;
-    else if (!strcmp(key, "spade_norm_fuse")) ctx->spade_norm_fuse = value;
     else if (!strcmp(key, "attn_presplit")) ctx->attn_presplit = value;
-    else if (!strcmp(key, "spade_fuse_auto")) ctx->spade_fuse_auto = value;
     else {
         set_error("unknown option '%s'", key);
         return MCVD_EINVAL;
@@ -794,7 +788,6 @@ int mcvd_model_op_kernel(mcvd_model* m, int i) {
     return m->ran_kernel[i];
 }
 
-long mcvd_model_gn_inlined(mcvd_model* m) { return m ? m->gn_inlined_total : -1; }
 long mcvd_model_fused_launches(mcvd_model* m, int what) { return (m && what >= 0 && what < 4) ? m->fused_launches[what] : -1; }
 
 int mcvd_model_module_output(mcvd_model* m, int module, int B, float* dst, int64_t capacity, int* C, int* H) {

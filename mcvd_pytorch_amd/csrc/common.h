@@ -5,7 +5,6 @@
 #include <atomic>
 #include <string>
 
-#include "kernels/gn_inline.h"
 
 namespace mcvd {
 
@@ -107,10 +106,6 @@ struct ConvArgs {
     // (1 + scale, shift) [B][Cin][2] (may be null); requires coef (plain GroupNorm coefficients) and act
     const float* gb;
     const float* coef2;
-    // GroupNorm coefficients computed by this conv from the producers' partial statistics (kernels/gn_inline.h): gni.st0 != NULL
-    // replaces `coef` (which must still be non-null: it selects the affine prologue).  Only the launches conv_takes_gn_inline()
-    // accepts (the three-piece bf16 Winograd and 1x1 kernels) may carry it.
-    GnInline gni;
     // q|k|v projection of an attention block (conv1x1_h2.cpp, KV): when non-null the K and V thirds of the output are written HERE as
     // three-piece bf16 LDS images per (sample, head, key tile) instead of as fp32 rows of y: 3 * kv_C * HW dwords per sample
     float* kv_img;
@@ -128,7 +123,6 @@ inline bool conv_part_fits(const ConvArgs& a) {
 bool ksplit_reduce_gn_usable(const ConvArgs& a);
 int launch_ksplit_reduce_gn(const ConvArgs& a, hipStream_t s);
 bool conv1x1_h2_kv_supported(const ConvArgs& a, int cot);
-bool conv_takes_gn_inline(const ConvArgs& a, int max_wg);   // the kernel launch_conv_mfma(a) dispatches to reduces the partials itself (and has <= max_wg workgroups)
 void set_last_conv_stats_np(int np);          // (launchers)
 int last_conv_stats_np();                     // partials per (sample, channel) the thread's last conv launch wrote to a.stats; 0 = none
 int conv_cout_tile(int Cout);                 // 32-channel units per block along Cout
@@ -223,12 +217,6 @@ int launch_upfirdn2d(const float* in, const float* kernel_dev, int kh, int kw, i
                      float* out, int NC, int H, int W, int oh, int ow, hipStream_t s);
 int launch_spade_apply(const float* x0, int C0, const float* x1, int C1, const float* coef, const float* gb,
                        const float* coef2, float* y, int B, int HW, hipStream_t s);
-// GroupNorm finalize (from the producers' epilogue partials) + SPADE modulation + temb pair + SiLU in ONE launch: what gn_finalize +
-// spade_apply compute, bit for bit; coef_out (may be null) also receives the plain (A, B) table
-bool spade_norm_apply_supported(int C, int groups, int HW);
-int launch_spade_norm_apply(const float* x0, int C0, const float* x1, int C1, int groups, float eps, const float* st0, int np0,
-                            const float* st1, int np1, const float* gb, const float* coef2, float* y, float* coef_out, int B, int HW,
-                            hipStream_t s);
 int launch_coef2(const float* emb, int emb_stride, int emb_off, float* coef2, int B, int C, hipStream_t s);
 // all tables of a forward at once: desc_dev[3 t] = {arena offset per sample, emb_off, C} (device, int64); coef2 table t = arena + off * B
 int launch_coef2_all(const float* emb, int emb_stride, const long long* desc_dev, int ntab, int cmax, float* arena, int B, hipStream_t s);

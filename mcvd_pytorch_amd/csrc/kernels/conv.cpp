@@ -141,31 +141,6 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     return (a.ks == 3 ? tab3 : tab1)[a.cot - 1](a, shape, s);
 }
 
-// Mirrors the dispatch above for the kernels that can compute their GroupNorm coefficients themselves (GnInline): shape ids 10 / 11
-// (conv_wino3.cpp) and 15 (conv1x1_h2.cpp with three bf16 pieces), where the launch really goes there, the table fits the per-thread
-// register budget of gn_inline_coef (wino3: 4 x 512 entries, 1x1: 6 x 256) and the launch has at most max_wg workgroups (every
-// workgroup repeats the reduction; profiles/r03_gn_inline_ab.txt).
-bool conv_takes_gn_inline(const ConvArgs& a, int max_wg) {
-    const int HW = a.H * a.W;
-    if (a.shape_hint == 10 || a.shape_hint == 11) {
-        ConvArgs b = a;
-        b.ksplit = a.shape_hint == 11 ? 2 : 0;
-        bool ok = conv_wino3_usable(b);
-        if (!ok && b.ksplit == 2) { b.ksplit = 0; ok = conv_wino3_usable(b); }
-        const bool g8 = a.H == 8 && a.W == 8;
-        const int nsamp = g8 ? 2 : 1;
-        const long regions = g8 ? (a.B + 1) / 2 : (long)a.B * (a.H / 8) * (a.W / 16);
-        const long wg = regions * (a.CoutP / (32 * conv_wino_cout_tile(a.Cout))) * (b.ksplit == 2 ? 2 : 1);
-        return ok && nsamp * a.Cin <= 4 * 512 && wg <= max_wg;
-    }
-    if (a.shape_hint == 15 && conv1x1_h2_supported(a, a.cot, 3)) {
-        const int nimg = HW >= 128 ? 1 : 128 / HW;
-        const long wg = (((long)a.B * HW + 127) / 128) * (a.CoutP / (32 * a.cot));
-        return nimg * a.Cin <= 6 * 256 && wg <= max_wg;
-    }
-    return false;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Naive direct convolution: one thread per output element, fp32 FMA chain in (ci, tap) order.
 __global__ void conv_naive_kernel(ConvArgs a) {

@@ -100,8 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     // through registers and waited for it before the first chunk was requested: one exposed memory latency per workgroup.)
     const int b_first = (int)(gp0 / HW);
     const int nimg = HW >= PT ? 1 : PT / HW;
-    const bool gn_inline = PRO != 0 && a.gni.st0 != nullptr;      // the table is computed below from the producers' partials (gn_inline.h)
-    if (PRO != 0 && !gn_inline) {
+    if (PRO != 0) {
         const int ppi = Cin >> 1;                                  // 16-byte pieces per image (Cin % 16 == 0)
         for (int q0 = 0; q0 < nimg * ppi; q0 += 256) {
             const int q = q0 + tid;
@@ -166,11 +165,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     Q1_DMA(0);
     if (nchunks > 1) Q1_DMA(1);
     if (nchunks > 2) Q1_DMA(2);
-    if (gn_inline) {
-        // behind the first chunks' DMA requests (the compiler counts its own loads behind them: by the time the partials have landed so
-        // have the chunks); the barrier of the first stage makes the table visible
-        gn_inline_coef<256, 6>(a.gni, b_first, nimg, a.B, a.C0, a.C1, HW, sC, tid);
-    }
     if (rec) tk1 = __builtin_amdgcn_s_memtime();
     /* chunk k becomes visible, chunk k + 3 is requested, the LDS reads of chunk k are issued: 8 pixel values, their coefficients, the
        NP * COT A operands */

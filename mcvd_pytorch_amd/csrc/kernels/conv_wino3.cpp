@@ -149,8 +149,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
         co_src[k] = a.coef + ((long)b * Cin + min(tid + k * NT, Cin - 1)) * 2;
         if (G8) co_src[2 + k] = a.coef + ((long)min(b + 1, a.B - 1) * Cin + min(tid + k * NT, Cin - 1)) * 2;
     }
-    const bool gn_inline = PRO && a.gni.st0 != nullptr;        // the coefficients are computed HERE from the producers' partials (gn_inline.h)
-    if (PRO && !gn_inline) {               // unconditional (clamped) loads into the registers of the third patch (requested later); the
+    if (PRO) {                             // unconditional (clamped) loads into the registers of the third patch (requested later); the
                                            // oldest VMEM operations of the wave: their latency passes under the index arithmetic below
         asm volatile("global_load_dwordx2 v[172:173], %0, off\n\tglobal_load_dwordx2 v[174:175], %1, off"
                      :: "v"(co_src[0]), "v"(co_src[1]) : "memory");
@@ -462,16 +461,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(86))) void conv
         W3_LOAD_PR(c_begin + 1, nodep, ofs, "v[194:197]", "v[198:201]", "v202")
         if (G8)                            // the halo of both patch buffers is zero padding for the whole kernel
             for (int i = tid; i < 2 * PBUF; i += NT) sP[i] = 0.0f;
-        if (gn_inline) {
-            // behind the patch requests: the partials' latency passes together with theirs (the compiler's own waits for these loads are
-            // in order behind the asm loads: conservative, never early).  The reduction's scratch and result are the table itself.
-            gn_inline_coef<NT, 4>(a.gni, b, G8 ? 2 : 1, a.B, a.C0, a.C1, HW, sCo, tid);
-        }
         if (rec) sp[0] = __builtin_amdgcn_s_memtime() - tk0;      // loads issued
         W3_WAIT(0)                         // the coefficients and the two patches have landed
         if (rec) sp[1] = __builtin_amdgcn_s_memtime() - tk0;      // first patches landed
         float cdep = 0.0f;
-        if (PRO && !gn_inline) {
+        if (PRO) {
             f32x2 cpre[G8 ? 4 : 2];
             asm volatile("v_mov_b32 %0, v172\n\tv_mov_b32 %1, v173\n\tv_mov_b32 %2, v174\n\tv_mov_b32 %3, v175"
                          : "=v"(cpre[0].x), "=v"(cpre[0].y), "=v"(cpre[1].x), "=v"(cpre[1].y) : "s"(vtok));

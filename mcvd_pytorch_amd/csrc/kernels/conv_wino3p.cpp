@@ -666,7 +666,7 @@ static int wino3p_launch1(const ConvArgs& a, hipStream_t s) {
 // GroupNorm reduction, pre-split packed weights present, at least WP_MINCH chunks per item (17: per K half, and an even chunk count).
 bool conv_wino3p_usable(const ConvArgs& a) {
     const int nchunks = a.CinP / WP_CK;
-    return a.ks == 3 && a.H % 8 == 0 && a.W % 16 == 0 && a.H >= 8 && a.W >= 16 && a.wpb && !a.gb && !a.gni.st0 && a.Cin <= 1024 &&
+    return a.ks == 3 && a.H % 8 == 0 && a.W % 16 == 0 && a.H >= 8 && a.W >= 16 && a.wpb && !a.gb && a.Cin <= 1024 &&
            a.CinP % WP_CK == 0 && (a.C1 == 0 || a.C0 % WP_CK == 0) && a.H * a.W <= 16384 &&
            (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * a.H * a.W < (1L << 29) && wino3p_lds_bytes(a.Cin) <= 160 * 1024 &&
            (long)a.B * (a.H / 8) * (a.W / 16) * (a.CoutP / 32) * 8 < (1L << 31) &&

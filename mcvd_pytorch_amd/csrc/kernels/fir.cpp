@@ -521,157 +521,6 @@ int launch_spade_apply(const float* x0, int C0, const float* x1, int C1, const f
     return 0;
 }
 
-// ---- SPADE modulation fused into the normalisation itself (north_star: "SPADE gamma/beta fused into the normalization epilogue";
-// layerspp.py:152-173 MySPADE.forward + :530-535 + :543-547).  Until round 5 a SPADE norm was THREE launches: gn_finalize (GroupNorm
-// statistics of the producers' epilogue partials -> (A, B) per channel), spade_apply (modulate, activate, materialise) and the conv.
-// Here the first two are one: a workgroup owns one (sample, group, pixel part); its first wave reduces the group's partial statistics
-// EXACTLY as gn_finalize_kernel does (same partial order, same two passes, same shuffles: the coefficients are bit-identical to that
-// kernel's), parks the group's (A, B) in LDS, and all waves stream the group's channels:
-//     y = silu( ((A x + B) (1 + gamma) + beta) s1 + b2 )          (s1, b2) = the temb pair (1 + scale, shift), absent for the final norm
-// with the same expression as spade_apply_kernel (bit-identical output).  The reduction is repeated by the `parts` workgroups of a
-// group: a few hundred bytes of L2-resident partials each.  Groups of more than 64 channels keep the two-launch path (not a shape of
-// the reference's configs).
-struct SpadeNormArgs {
-    const float* x0; const float* x1; int C0, C1; int groups; float eps;
-    const float* st0; int np0; const float* st1; int np1;
-    const float* gb; const float* coef2; float* y; float* coef_out; int B, HW, parts;
-};
-constexpr int SN_KEEP = 8;
-constexpr int SN_PRE = 4;        // items per thread whose loads are issued in front of the reduction
-__global__ __launch_bounds__(256) void spade_norm_apply_kernel(SpadeNormArgs a) {
-    __shared__ float sAB[2 * 64];
-    const int C = a.C0 + a.C1;
-    const int gs = C / a.groups;
-    const int part_id = blockIdx.x % a.parts;
-    const int bg = blockIdx.x / a.parts;
-    const int b = bg / a.groups, g = bg - b * a.groups;
-    const int c0 = g * gs;
-    const int tid = threadIdx.x, lane = tid & 63;
-    // the thread's first SN_PRE items (x, gamma, beta: 16 bytes each) are requested BEFORE the statistics are reduced: their latency
-    // passes under the reduction's two dependent round trips instead of behind them (most workgroups have 2-4 items per thread)
-    const int HW4 = a.HW >> 2;
-    const int per = (HW4 + a.parts - 1) / a.parts;                 // float4 columns of this part, for every channel of the group
-    const int p_lo = part_id * per, p_hi = min(HW4, p_lo + per);
-    const int span = p_hi - p_lo;
-    const int nitems = gs * span;
-    float4 pv[SN_PRE], pg[SN_PRE], pb[SN_PRE];
-#pragma unroll
-    for (int k = 0; k < SN_PRE; ++k) {
-        const int i = min(tid + 256 * k, nitems - 1);
-        const int cl = i / span, p4 = p_lo + (i - cl * span);
-        const int c = c0 + cl;
-        const float* src = (c < a.C0) ? a.x0 + ((long)b * a.C0 + c) * a.HW : a.x1 + ((long)b * a.C1 + (c - a.C0)) * a.HW;
-        pv[k] = reinterpret_cast<const float4*>(src)[p4];
-        pg[k] = reinterpret_cast<const float4*>(a.gb + ((long)b * 2 * C + c) * a.HW)[p4];
-        pb[k] = reinterpret_cast<const float4*>(a.gb + ((long)b * 2 * C + C + c) * a.HW)[p4];
-    }
-    if (tid < 64) {                       // ---- gn_finalize_kernel's reduction, instruction for instruction (mode 0: no affine)
-        const int n_in0 = max(0, min(c0 + gs, a.C0) - c0), n_in1 = gs - n_in0;
-        const int P0 = n_in0 * a.np0, P = P0 + n_in1 * a.np1;
-        const float n0 = (float)(a.HW / max(a.np0, 1)), n1 = (float)(a.HW / max(a.np1, 1));
-        auto part = [&](int i, float& sum, float& m2, float& n) {
-            if (i < P0) {
-                const int cl = i / a.np0, p = i - cl * a.np0;
-                const float2 q = *reinterpret_cast<const float2*>(a.st0 + (((long)b * a.C0 + c0 + cl) * a.np0 + p) * 2);
-                sum = q.x; m2 = q.y; n = n0;
-            } else {
-                const int j = i - P0;
-                const int cl = j / a.np1, p = j - cl * a.np1;
-                const int c1 = max(c0, a.C0) - a.C0 + cl;
-                const float2 q = *reinterpret_cast<const float2*>(a.st1 + (((long)b * a.C1 + c1) * a.np1 + p) * 2);
-                sum = q.x; m2 = q.y; n = n1;
-            }
-        };
-        float ks[SN_KEEP], km[SN_KEEP], kn[SN_KEEP];
-#pragma unroll
-        for (int k = 0; k < SN_KEEP; ++k) {
-            ks[k] = 0.0f; km[k] = 0.0f; kn[k] = 1.0f;
-            if (lane + 64 * k < P) part(lane + 64 * k, ks[k], km[k], kn[k]);
-        }
-        float tot = 0.0f;
-#pragma unroll
-        for (int k = 0; k < SN_KEEP; ++k)
-            if (lane + 64 * k < P) tot += ks[k];
-        for (int i = lane + 64 * SN_KEEP; i < P; i += 64) {
-            float sm, m2, n;
-            part(i, sm, m2, n);
-            tot += sm;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-        const float N = (float)gs * (float)a.HW;
-        const float mean = tot / N;
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < SN_KEEP; ++k)
-            if (lane + 64 * k < P) {
-                const float d = ks[k] / kn[k] - mean;
-                acc += km[k] + kn[k] * d * d;
-            }
-        for (int i = lane + 64 * SN_KEEP; i < P; i += 64) {
-            float sm, m2, n;
-            part(i, sm, m2, n);
-            const float d = sm / n - mean;
-            acc += m2 + n * d * d;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        const float var = acc / N;
-        const float rstd = 1.0f / sqrtf(var + a.eps);
-        if (lane < gs) {
-            const float A = rstd * 1.0f, Bc = 0.0f - mean * rstd * 1.0f;           // gn_finalize: rstd * par0, par1 - mean * rstd * par0 with (1, 0)
-            sAB[2 * lane] = A;
-            sAB[2 * lane + 1] = Bc;
-            if (a.coef_out && part_id == 0) reinterpret_cast<float2*>(a.coef_out)[(long)b * C + c0 + lane] = make_float2(A, Bc);
-        }
-    }
-    __syncthreads();
-    for (int i = tid, k = 0; i < nitems; i += 256, ++k) {
-        const int cl = i / span, p4 = p_lo + (i - cl * span);
-        const int c = c0 + cl;
-        const long bc = (long)b * C + c;
-        float4 v, gm, be;
-        if (k < SN_PRE) {
-#pragma unroll
-            for (int q = 0; q < SN_PRE; ++q)
-                if (q == k) { v = pv[q]; gm = pg[q]; be = pb[q]; }
-        } else {
-            const float* src = (c < a.C0) ? a.x0 + ((long)b * a.C0 + c) * a.HW : a.x1 + ((long)b * a.C1 + (c - a.C0)) * a.HW;
-            v = reinterpret_cast<const float4*>(src)[p4];
-            gm = reinterpret_cast<const float4*>(a.gb + ((long)b * 2 * C + c) * a.HW)[p4];
-            be = reinterpret_cast<const float4*>(a.gb + ((long)b * 2 * C + C + c) * a.HW)[p4];
-        }
-        const float cA = sAB[2 * cl], cB = sAB[2 * cl + 1];
-        float sA = 1.f, sB = 0.f;
-        if (a.coef2) { sA = a.coef2[bc * 2]; sB = a.coef2[bc * 2 + 1]; }
-        float4 o;
-        o.x = silu1(((v.x * cA + cB) * (1.0f + gm.x) + be.x) * sA + sB);
-        o.y = silu1(((v.y * cA + cB) * (1.0f + gm.y) + be.y) * sA + sB);
-        o.z = silu1(((v.z * cA + cB) * (1.0f + gm.z) + be.z) * sA + sB);
-        o.w = silu1(((v.w * cA + cB) * (1.0f + gm.w) + be.w) * sA + sB);
-        reinterpret_cast<float4*>(a.y + bc * a.HW)[p4] = o;
-    }
-}
-
-bool spade_norm_apply_supported(int C, int groups, int HW) { return groups > 0 && C % groups == 0 && C / groups <= 64 && HW % 4 == 0; }
-
-int launch_spade_norm_apply(const float* x0, int C0, const float* x1, int C1, int groups, float eps, const float* st0, int np0,
-                            const float* st1, int np1, const float* gb, const float* coef2, float* y, float* coef_out, int B, int HW,
-                            hipStream_t s) {
-    const int C = C0 + (x1 ? C1 : 0);
-    MCVD_REQUIRE(spade_norm_apply_supported(C, groups, HW), "spade_norm_apply: C=%d groups=%d HW=%d", C, groups, HW);
-    MCVD_REQUIRE(st0 && np0 > 0 && HW % np0 == 0 && (!x1 || C1 == 0 || (st1 && np1 > 0 && HW % np1 == 0)),
-                 "spade_norm_apply: bad partial statistics (np0=%d np1=%d HW=%d)", np0, np1, HW);
-    // enough workgroups to fill the chip: (sample, group) pairs x pixel parts, a part no smaller than 256 float4 columns per channel
-    const int gs = C / groups;
-    int parts = 1;
-    while ((long)B * groups * parts < 1024 && (HW / 4) / (parts * 2) * gs >= 256 && (HW / 4) % (parts * 2) == 0) parts *= 2;
-    SpadeNormArgs a{x0, x1, C0, x1 ? C1 : 0, groups, eps, st0, np0, st1, (x1 && C1) ? np1 : 1, gb, coef2, y, coef_out, B, HW, parts};
-    hipLaunchKernelGGL(spade_norm_apply_kernel, dim3((unsigned)(B * groups * parts)), dim3(256), 0, s, a);
-    MCVD_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
 // coef2[b][c] = (1 + scale, shift) from the fused Dense_0 output (layerspp.py:523,535)
 __global__ void coef2_kernel(const float* emb, int emb_stride, int emb_off, float* coef2, int B, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

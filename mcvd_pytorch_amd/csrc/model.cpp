@@ -596,7 +596,6 @@ int mcvd_model::build_plan() {
     }
     arena_per_sample = bld.arena;
     stats_np.assign(ops.size(), 0);
-    gn_deferred.assign(ops.size(), 0);
     if (c.noise_in_cond) {            // gamma/beta depend on the noised conditioning frames: nothing can be hoisted out of the step
         for (Op& op : ops) op.prep = false;
         has_prep = false;
@@ -644,10 +643,8 @@ float* mcvd_model::resolve(const TRef& r, const float* x, const float* cond, flo
 }
 
 // GroupNorm -> (A, B).  Statistics already computed by the producers' epilogues (every source must have them) are finalized by a
-// small kernel -- or not launched at all (may_defer): where every source has at most GN_INLINE_MAX_NP partials per channel the
-// consumers reduce them in their own prologue (conv_takes_gn_inline); a consumer that cannot calls ensure_coef, which launches the
-// kernel late.  Without producer statistics: one pass over the tensor.
-int mcvd_model::launch_gn(const Op& op, const float* x, const void* lab, const float* cond, float* out, int B, bool may_defer) {
+// small kernel (or were, by the producing conv's own K-split reduce pass: gn_done).  Without producer statistics: one pass over the tensor.
+int mcvd_model::launch_gn(const Op& op, const float* x, const void* lab, const float* cond, float* out, int B) {
     hipStream_t s = op_stream ? op_stream : ctx->stream;
     const size_t gi = (size_t)(&op - ops.data());
     GnArgs a{};
@@ -671,35 +668,11 @@ int mcvd_model::launch_gn(const Op& op, const float* x, const void* lab, const f
     a.HW = op.H * op.W;
     const int np0 = op.prod0 >= 0 ? stats_np[op.prod0] : 0;
     const int np1 = a.C1 == 0 ? 1 : (op.prod1 >= 0 ? stats_np[op.prod1] : 0);
-    if (gn_deferred.size() != ops.size()) gn_deferred.assign(ops.size(), 0);
-    gn_deferred[gi] = 0;
     if (gn_done.size() == ops.size() && gn_done[gi]) {       // the producing conv's K-split reduce pass wrote this table (ConvArgs::gno)
         gn_done[gi] = 0;
         return 0;
     }
     if (ctx->gn_stats && np0 > 0 && np1 > 0) {
-        // a SPADE norm (mode 0) in front of a conv: the statistics are finalized INSIDE the kernel that modulates and activates the
-        // tensor (spade_norm_apply_kernel, launched by the conv op) -- no gn_finalize launch.  The conv op falls back to ensure_coef
-        // if it ends up on the fused Winograd loader, which reads the table.
-        if (may_defer && ctx->spade_norm_fuse && op.gn_mode == 0 && spade_norm_apply_supported(a.C0 + a.C1, op.groups, a.HW)) {
-            for (size_t ci = gi + 1; ci < ops.size(); ++ci)
-                if (ops[ci].gn_src == (int)gi) {
-                    if (ops[ci].kind == OP_CONV && ops[ci].gb.kind != REF_NONE) {
-                        gn_deferred[gi] = 2;
-                        return 0;
-                    }
-                    break;
-                }
-        }
-        if (may_defer && ctx->gn_inline && np0 <= GN_INLINE_MAX_NP && np1 <= GN_INLINE_MAX_NP) {
-            bool has_consumer = false;
-            for (size_t ci = gi + 1; ci < ops.size() && !has_consumer; ++ci) has_consumer = ops[ci].gn_src == (int)gi;
-            if (has_consumer) {
-                gn_deferred[gi] = 1;
-                ++gn_inlined_total;
-                return 0;
-            }
-        }
         // timing-only ablation (option "dbg_skip_finalize", WRONG results after the first step): the captured graph carries no finalize
         // launch -- the table keeps the values of the eager first forward.  The upper bound of what ANY scheme that removes these launches
         // (producer-side last arriver, consumer-side reduction) can gain (profiles/r05_tail_launch_bound.txt).
@@ -710,15 +683,9 @@ int mcvd_model::launch_gn(const Op& op, const float* x, const void* lab, const f
     return launch_gn_coef(a, s);
 }
 
-int mcvd_model::ensure_coef(int gn_index, const float* x, const void* lab, const float* cond, float* out, int B) {
-    if (gn_index < 0 || (size_t)gn_index >= gn_deferred.size() || !gn_deferred[gn_index]) return 0;
-    if (gn_deferred[gn_index] == 1) --gn_inlined_total;
-    return launch_gn(ops[gn_index], x, lab, cond, out, B, false);       // (clears the flag)
-}
-
 // ---- the GEMM forms of a 3x3 conv (kernels/conv_gemm_forms.cpp; shape ids 22 / 23).  `a` = the conv's arguments as launch_op built them.
 bool mcvd_model::gemm_form_usable(const Op& op, const ConvArgs& a) const {
-    if (!op.alt_kind || a.shape_hint != op.alt_kind || !ctx->bf16x3 || a.gb || a.gni.st0 || a.ks != 3) return false;
+    if (!op.alt_kind || a.shape_hint != op.alt_kind || !ctx->bf16x3 || a.gb || a.ks != 3) return false;
     if (op.alt_kind == 22 && (a.stats || a.C1 != 0)) return false;        // (the shift-and-add pass emits no GroupNorm partials; one source)
     if (op.alt_kind == 23 && (a.coef || a.act)) return false;             // (im2col copies raw values)
     ConvArgs g = gemm_form_args(op, a, nullptr);
@@ -780,7 +747,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             return launch_dense_all(resolve(op.src0, x, cond, out, B), packed + dense_wt, packed + dense_bias,
                                     resolve(op.dst, x, cond, out, B), (uniform_labels && !d.cond_emb) ? 1 : B, T, NE, s);
         case OP_GN:
-            return launch_gn(op, x, lab, cond, out, B, true);
+            return launch_gn(op, x, lab, cond, out, B);
         case OP_CONV: {
             ConvArgs a{};
             a.x0 = resolve(op.src0, x, cond, out, B);
@@ -841,70 +808,25 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                 // spade_apply materialises silu(((A x + B)(1 + gamma) + beta) s1 + b2) and the conv reads it plainly
                 a.gb = resolve(op.gb, x, cond, out, B);
                 a.coef2 = op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, x, cond, out, B);
-                // shape ids 36 / 40 (= 32 + 4 / 8; tables only): THIS layer takes the SPADE modulation inside the fp32 Winograd loader -- the
-                // autotuner measured [gn_finalize + fused conv] against [spade_norm_apply + the best plain conv] and the fused form won
-                const bool table_fused = a.shape_hint == 36 || a.shape_hint == 40;
-                if (table_fused) a.shape_hint -= 32;
-                const bool want_fused = (ctx->spade_fuse || table_fused) && !ctx->naive_conv && ctx->winograd;
+                if (a.shape_hint == 36 || a.shape_hint == 40) a.shape_hint = -1;      // (ids of a round-5 table: the per-layer fused loader is gone)
+                const bool want_fused = ctx->spade_fuse && !ctx->naive_conv && ctx->winograd;
                 ConvArgs t = a;
                 t.shape_hint = (a.shape_hint == 8) ? 8 : 4;
                 t.ksplit = t.shape_hint == 8 ? 2 : 0;
                 bool fused = want_fused && conv_wino_usable(t);
                 if (!fused && t.ksplit == 2) { t.ksplit = 0; t.shape_hint = 4; fused = want_fused && conv_wino_usable(t); }
-                if (table_fused && !fused) a.shape_hint = -1;        // (a table of another build: the dispatcher's own choice)
                 if (fused) {
-                    if (op.gn_src >= 0)                         // the fused loader reads the (A, B) table
-                        if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
                     a.shape_hint = t.shape_hint;
                     ++fused_launches[2];
                 } else {
                     float* tmp = resolve(op.tmp, x, cond, out, B);
-                    if (op.gn_src >= 0 && gn_deferred[op.gn_src] == 2) {
-                        // normalisation statistics + SPADE modulation + temb pair + SiLU in one launch (kernels/fir.cpp)
-                        const Op& g = ops[op.gn_src];
-                        gn_deferred[op.gn_src] = 0;
-                        ++fused_launches[1];
-                        const int np0 = stats_np[g.prod0], np1 = a.C1 ? stats_np[g.prod1] : 1;
-                        if (int rc = launch_spade_norm_apply(a.x0, a.C0, a.x1, a.C1, g.groups, g.eps, resolve(ops[g.prod0].stats, x, cond, out, B), np0,
-                                                             a.C1 ? resolve(ops[g.prod1].stats, x, cond, out, B) : nullptr, np1, a.gb, a.coef2, tmp,
-                                                             nullptr, B, op.H * op.W, s))
-                            return rc;
-                    } else {
-                        if (op.gn_src >= 0)
-                            if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
-                        if (int rc = launch_spade_apply(a.x0, a.C0, a.x1, a.C1, a.coef, a.gb, a.coef2, tmp, B, op.H * op.W, s)) return rc;
-                    }
+                    if (int rc = launch_spade_apply(a.x0, a.C0, a.x1, a.C1, a.coef, a.gb, a.coef2, tmp, B, op.H * op.W, s)) return rc;
                     a.x0 = tmp; a.x1 = nullptr; a.C0 = a.Cin; a.C1 = 0; a.coef = nullptr; a.act = 0; a.gb = nullptr; a.coef2 = nullptr;
                 }
             }
             // (the split-operand 1x1 GEMM emits them cheaply from its transposed epilogue: shape ids 14 / 15)
             a.stats = (ctx->gn_stats && op.stats.kind != REF_NONE && !ctx->naive_conv && (op.ks == 3 || ctx->gn_stats >= 2 || a.shape_hint == 14 || a.shape_hint == 15))
                           ? resolve(op.stats, x, cond, out, B) : nullptr;
-            if (op.gn_src >= 0 && gn_deferred[op.gn_src]) {
-                // the norm in front of this conv was not launched: this kernel reduces the producers' partials itself -- or, if the
-                // launch goes to a kernel that cannot, the table is written now
-                const Op& g = ops[op.gn_src];
-                ConvArgs t = a;
-                if (!ctx->naive_conv && a.gb == nullptr && conv_takes_gn_inline(t, ctx->gn_inline_max_wg)) {
-                    a.gni.st0 = resolve(ops[g.prod0].stats, x, cond, out, B);
-                    a.gni.np0 = stats_np[g.prod0];
-                    a.gni.st1 = a.C1 ? resolve(ops[g.prod1].stats, x, cond, out, B) : nullptr;
-                    a.gni.np1 = a.C1 ? stats_np[g.prod1] : 1;
-                    a.gni.groups = g.groups;
-                    a.gni.eps = g.eps;
-                    a.gni.mode = g.gn_mode;
-                    if (g.gn_mode == 1) {
-                        a.gni.p0 = resolve(ops[1].dst, x, cond, out, B);
-                        a.gni.emb_stride = (uniform_labels && !d.cond_emb) ? 0 : NE;
-                        a.gni.emb_off = g.emb_off;
-                    } else if (g.gn_mode == 2) {
-                        a.gni.p0 = blob + g.p0;
-                        a.gni.p1 = blob + g.p1;
-                    }
-                } else if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) {
-                    return rc;
-                }
-            }
             if (ran_kernel.size() != ops.size()) ran_kernel.assign(ops.size(), -1);
             if (kv_live.size() != ops.size()) kv_live.assign(ops.size(), 0);
             if (gn_done.size() != ops.size()) gn_done.assign(ops.size(), 0);
@@ -913,8 +835,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                 // the norm's (A, B) table too (gn.cpp: ksplit_reduce_gn_kernel) and the norm's own launch is skipped
                 gn_done[op.gn_next] = 0;
                 const Op& g = ops[op.gn_next];
-                const bool plain = !ctx->gn_inline && !(ctx->spade_norm_fuse && g.gn_mode == 0);
-                if (ctx->gn_producer && ctx->gn_stats && a.stats && op.ks == 3 && plain && !ctx->dbg_skip_finalize) {
+                if (ctx->gn_producer && ctx->gn_stats && a.stats && op.ks == 3 && !ctx->dbg_skip_finalize) {
                     a.gno.coef = resolve(g.coef, x, cond, out, B);
                     a.gno.groups = g.groups;
                     a.gno.eps = g.eps;
@@ -972,8 +893,6 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
             return rc;
         }
         case OP_FIR: {
-            if (op.gn_src >= 0)
-                if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
             const float* gb = op.gb.kind == REF_NONE ? nullptr : resolve(op.gb, x, cond, out, B);
             return launch_fir2(resolve(op.src0, x, cond, out, B),
                                op.coef.kind == REF_NONE ? nullptr : resolve(op.coef, x, cond, out, B), op.act, op.up,
@@ -1028,8 +947,6 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                                 resolve(op.dst, x, cond, out, B), B, op.Cout, s);
         }
         case OP_APPLY:
-            if (op.gn_src >= 0)
-                if (int rc = ensure_coef(op.gn_src, x, lab, cond, out, B)) return rc;
             return launch_spade_apply(resolve(op.src0, x, cond, out, B), op.src0.C, resolve(op.src1, x, cond, out, B),
                                       op.src1.kind == REF_NONE ? 0 : op.src1.C, resolve(op.coef, x, cond, out, B),
                                       resolve(op.gb, x, cond, out, B),
@@ -1233,61 +1150,6 @@ int mcvd_model::autotune(int B) {
                         if (int rc = time_candidate(9, 2)) return rc;
                 }
             }
-            // SPADE norm in front of this conv: the modulation inside the fp32 Winograd loader (gamma | beta by LDS-DMA, conv_wino.cpp PRO 3)
-            // against the materialising path, measured as what each really costs per norm:
-            //     fused:   gn_finalize  +  conv_wino_kernel<PRO 3> (fp32 MFMA)          plain:  spade_norm_apply  +  the best plain conv (bf16x3 ...)
-            // Shape ids 36 / 40 (32 + 4 / 8) mark the layers where the fused form wins.  Offered by default (option "spade_fuse_auto").
-            if (op.gb.kind != REF_NONE && !spade_fused && ctx->spade_fuse_auto && ctx->winograd && op.ks == 3 && op.gn_src >= 0 && choice.first >= 0 &&
-                ops[op.gn_src].prod0 >= 0 && (op.src1.kind == REF_NONE || ops[op.gn_src].prod1 >= 0)) {
-                const Op& g = ops[op.gn_src];
-                ConvArgs f = a;                                   // the conv as the fused loader sees it: raw sources + tables + maps
-                f.x0 = resolve(op.src0, scratch_io, scratch_io, scratch_io, B);
-                f.x1 = resolve(op.src1, scratch_io, scratch_io, scratch_io, B);
-                f.C0 = op.src0.C; f.C1 = op.src1.kind == REF_NONE ? 0 : op.src1.C;
-                f.coef = resolve(op.coef, scratch_io, scratch_io, scratch_io, B);
-                f.act = op.act;
-                f.gb = resolve(op.gb, scratch_io, scratch_io, scratch_io, B);
-                f.coef2 = op.coef2.kind == REF_NONE ? nullptr : resolve(op.coef2, scratch_io, scratch_io, scratch_io, B);
-                f.cot = op.cot;
-                GnArgs ga{};
-                ga.C0 = f.C0; ga.C1 = f.C1; ga.groups = g.groups; ga.eps = g.eps; ga.mode = 0; ga.coef = const_cast<float*>(f.coef); ga.B = B; ga.HW = op.H * op.W;
-                const int HW = op.H * op.W;
-                const int np = std::max(1, HW / 128);             // what the Winograd producers emit (one partial per 8 x 16 region)
-                const float* st0 = resolve(ops[g.prod0].stats, scratch_io, scratch_io, scratch_io, B);
-                const float* st1 = f.C1 ? resolve(ops[g.prod1].stats, scratch_io, scratch_io, scratch_io, B) : nullptr;
-                float* tmp = resolve(op.tmp, scratch_io, scratch_io, scratch_io, B);
-                auto time_seq = [&](auto&& fn, float* ms_out) -> int {
-                    if (int rc = fn()) return rc;                                  // warm-up
-                    MCVD_HIP_CHECK(hipEventRecord(e0, s));
-                    for (int r = 0; r < 3; ++r)
-                        if (int rc = fn()) return rc;
-                    MCVD_HIP_CHECK(hipEventRecord(e1, s));
-                    MCVD_HIP_CHECK(hipEventSynchronize(e1));
-                    MCVD_HIP_CHECK(hipEventElapsedTime(ms_out, e0, e1));
-                    return 0;
-                };
-                if (spade_norm_apply_supported(cin, g.groups, HW)) {
-                    ConvArgs pa = a;                              // the plain winner
-                    pa.shape_hint = choice.first; pa.cot = choice.second;
-                    float ms_plain = 1e30f;
-                    if (int rc = time_seq([&]() -> int {
-                            if (int r2 = launch_spade_norm_apply(f.x0, f.C0, f.x1, f.C1, g.groups, g.eps, st0, np, st1, np, f.gb, f.coef2, tmp, nullptr, B, HW, s)) return r2;
-                            return launch_conv_mfma(pa, s);
-                        }, &ms_plain)) return rc;
-                    for (int shape : {4, 8}) {
-                        ConvArgs t = f;
-                        t.shape_hint = shape; t.ksplit = shape == 8 ? 2 : 0;
-                        if (!conv_wino_usable(t)) continue;
-                        float ms_fused = 1e30f;
-                        if (int rc = time_seq([&]() -> int {
-                                if (int r2 = launch_gn_finalize(ga, st0, np, st1, np, s)) return r2;
-                                ConvArgs u = f; u.shape_hint = shape;
-                                return launch_conv_mfma(u, s);
-                            }, &ms_fused)) return rc;
-                        if (ms_fused < ms_plain) { ms_plain = ms_fused; choice = {32 + shape, op.cot}; }
-                    }
-                }
-            }
             it = best.emplace(k, choice).first;
         }
         tuned_shape[i] = it->second.first;
@@ -1305,7 +1167,7 @@ int mcvd_model::autotune(int B) {
 // (mcvd_model_set_tuning stamps its table with the options in force at the import).
 void mcvd_model::sync_tuning_options() {
     const int sig = (ctx->winograd ? 1 : 0) | (ctx->conv_dma1 ? 2 : 0) | (ctx->bf16x3 ? 4 : 0) | (ctx->f16x2 ? 8 : 0) |
-                    (ctx->spade_fuse ? 16 : 0) | (ctx->conv_wdma ? 32 : 0) | (ctx->spade_fuse_auto ? 64 : 0);
+                    (ctx->spade_fuse ? 16 : 0) | (ctx->conv_wdma ? 32 : 0);
     if (sig != tuned_sig) {
         if (tuned_sig >= 0) { tuned_cache.clear(); tuned_B = 0; }
         tuned_sig = sig;

@@ -45,17 +45,7 @@ struct mcvd_ctx {
     int attn_presplit = 1;         // the q|k|v projection writes K and V pre-split (three bf16 pieces, LDS-image order) and the attention kernel
                                    //    stages them by LDS-DMA (attn_h2p_kernel; head dims 32 / 64 / 96, default arithmetic only); 0: attn_h2_kernel
                                    //    splits them itself, once per query tile.  Bit-identical results either way.
-    int spade_fuse_auto = 1;       // offer the fused SPADE loader to the autotuner PER LAYER (shape ids 36 / 40): it takes the layers where
-                                   //    [gn_finalize + fused fp32 Winograd conv] beats [spade_norm_apply + the best plain conv] in its own timing
-    int spade_norm_fuse = 0;       // 1: SPADE norms in front of a conv: GroupNorm finalize + modulation + temb pair + SiLU in ONE launch
-                                   //    (spade_norm_apply_kernel) instead of gn_finalize + spade_apply (bit-identical results).  Off by default:
-                                   //    measured 0.7 % faster, then 1 % SLOWER end to end on config 4 (profiles/r05_spade_fusion_ab.txt) -- every
-                                   //    workgroup pays the reduction's two dependent round trips in front of its stream
     int gn_stats = 1;              // GroupNorm statistics from the producing conv's epilogue (0: always one pass over the tensor)
-    int gn_inline = 0;             // 1: a conv whose kernel can (conv_takes_gn_inline) reduces those partial statistics itself where a channel has
-                                   //    at most GN_INLINE_MAX_NP of them: no gn_finalize launch for that norm (kernels/gn_inline.h).  Off by default:
-                                   //    measured 0.3-1 % SLOWER end to end on every config (profiles/r03_gn_inline_ab.txt)
-    int gn_inline_max_wg = 0;      // ... and the conv launch has at most this many workgroups (mcvd_ctx_create: two rounds of the device's CUs)
     int autotune = 1;              // time the conv tile candidates per distinct layer shape on first use of a batch size
     int profile = 0;               // record HIP events around every op of the first forward of each sampler call
     unsigned long long* dbg = nullptr;   // conv phase-timing buffer for mcvd_op_conv2d (diagnostics)
@@ -219,14 +209,10 @@ struct mcvd_model {
     // conv tile choice per op for the batch size it was tuned at: (shape, cot); filled by autotune()
     std::vector<int> stats_np;        // per op: partials per (sample, channel) its last launch wrote (0: none)
     std::vector<signed char> kv_live;       // per OP_ATTN of the forward in flight: 1 = its projection wrote the K / V piece images (set by the conv launch)
-    std::vector<signed char> gn_deferred;   // per OP_GN of the forward in flight: 1 = not launched, its consumers reduce the partials
-                                      //    themselves (or launch it late, the first that cannot): launch_op / ensure_coef
     long fused_launches[4] = {0, 0, 0, 0};   // mcvd_model_fused_launches: pre-split attention blocks, fused SPADE norms, convs with the SPADE loader,
                                              // norms finalized by their producer's K-split reduce pass
     std::vector<signed char> gn_done;       // per OP_GN of the forward in flight: 1 = its table was written by the producing conv's last pass
-    long gn_inlined_total = 0;        // norms that never needed a launch (diagnostics: mcvd_model_stat)
-    int launch_gn(const mcvd::Op& op, const float* x, const void* labels, const float* cond, float* out, int B, bool may_defer);
-    int ensure_coef(int gn_index, const float* x, const void* labels, const float* cond, float* out, int B);
+    int launch_gn(const mcvd::Op& op, const float* x, const void* labels, const float* cond, float* out, int B);
     std::vector<int> ran_kernel;      // per conv op: the kernel family its last launch REALLY ran (last_conv_kernel(); -2 the naive kernel,
                                       //    -1 never launched): what mcvd_model_op_kernel reports
     std::vector<int> tuned_shape, tuned_cot;
