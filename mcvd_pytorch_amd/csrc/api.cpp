@@ -1,8 +1,11 @@
 // extern "C" surface of libmcvd_hip.so (see include/mcvd_hip.h).  Nothing here throws.
 #include <dlfcn.h>
+#include <errno.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <math.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -56,19 +59,29 @@ int device_lock_acquire(int device) {
     if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) snprintf(bus, sizeof(bus), "dev%d", device);
     for (char* c = bus; *c; ++c)
         if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
+    // The lock file has a predictable name in a world-writable directory: never follow a symlink planted there (O_NOFOLLOW), accept a
+    // regular file only (fstat), and open it read-only when it belongs to another user (flock needs no write access) so that the
+    // one-process-per-GPU rule holds across users too.  The guard stays ADVISORY: a local user can hold the lock and deny the device
+    // (MCVD_EBUSY is loud, never wrong results), and a sharer that could not take LOCK_SH while the first process holds LOCK_EX holds
+    // nothing once that process exits.
     const char* dirs[2] = {"/dev/shm", "/tmp"};
     int fd = -1;
     for (int i = 0; i < 2 && fd < 0; ++i) {
         char path[256];
         snprintf(path, sizeof(path), "%s/mcvd_hip_gpu_%s.lock", dirs[i], bus);
-        fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+        fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC | O_NOFOLLOW, 0666);
+        if (fd < 0 && (errno == EACCES || errno == EPERM)) fd = open(path, O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
+        if (fd >= 0) {
+            struct stat sb;
+            if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); fd = -1; }
+        }
     }
-    if (fd < 0) return 0;                                   // no lock directory: nothing to enforce with
+    if (fd < 0) return 0;                                   // no usable lock file: nothing to enforce with
     L.fd = fd;
     L.refs = 1;
     if (flock(fd, LOCK_EX | LOCK_NB) == 0) { L.exclusive = true; return 0; }
     L.exclusive = false;
-    (void)flock(fd, LOCK_SH | LOCK_NB);                     // a sharer: later arrivals still see the device as taken
+    (void)flock(fd, LOCK_SH | LOCK_NB);                     // a sharer: later arrivals still see the device as taken (best effort, see above)
     return 1;
 }
 
@@ -81,6 +94,16 @@ void device_lock_release(int device) {
         L = DevLock{};
     }
 }
+// a fork()ed child inherits the table but not the parent's claim on the device: it starts with no lock and takes its own on its first context
+void device_lock_atfork_child() {
+    for (DevLock& L : g_dev_lock) {
+        if (L.fd >= 0) close(L.fd);                         // (closing the child's copy of the descriptor does not release the parent's flock)
+        L = DevLock{};
+    }
+    for (auto& v : g_live_ctx) v.clear();
+}
+struct AtForkOnce { AtForkOnce() { pthread_atfork(nullptr, nullptr, device_lock_atfork_child); } } g_atfork_once;
+
 void ctx_register(mcvd_ctx* c) {
     std::lock_guard<std::mutex> g(g_dev_mu);
     if (c->device < 0 || c->device >= 64) return;
@@ -104,6 +127,7 @@ void ctx_unregister(mcvd_ctx* c) {
 bool mcvd_ctx_shares_device(const mcvd_ctx* c) {
     if (!c) return false;
     if (c->shared_device) return true;
+    if (c->side_stream) return true;              // the context's own second stream (option "side_stream") overlaps kernels just as a foreign one does
     std::lock_guard<std::mutex> g(g_dev_mu);
     if (c->device < 0 || c->device >= 64) return false;
     for (const mcvd_ctx* o : g_live_ctx[c->device])

@@ -406,6 +406,10 @@ static bool fir_strip_geometry(int up, int nl, long planes, int H, int W, bool r
     }
     if (R & (R - 1)) return false;                    // (whole planes of a non-power-of-two height: the register forms)
     if (!up && R < 2) return false;
+    // the halo rows of a strip (2 per plane, W / 4 float4 each) are filled by ONE pass of the 256 threads (fir_strip_fill: tid < 2 P W/4):
+    // geometries with more halo float4s than threads (e.g. H = 2 planes of a power-of-two width under the 2048-element strip) would leave
+    // part of the halo unwritten -- the register forms take those
+    if (2L * P * (W / 4) > 256) return false;
     const long n = P > 1 ? planes / P : planes * (H / R);
     if (n >= (1L << 31) || planes >= (1L << 31)) return false;
     auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };

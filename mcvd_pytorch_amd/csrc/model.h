@@ -1,5 +1,6 @@
 // Host-side executor: config -> static op plan, parameter blob, weight packing, forward, sampler loop.
 #pragma once
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -21,7 +22,7 @@ struct mcvd_ctx {
                                    //    (x, labels, cond, out, B) pointer set; the sampler loop reuses one set for all steps)
     hipStream_t cap = nullptr;     // private capture stream (the caller's stream may be the legacy default stream, which
                                    //    cannot be captured)
-    unsigned epoch = 0;            // bumped by every option change: invalidates captured graphs
+    std::atomic<unsigned> epoch{0};   // bumped by every option change (and by ctx_register from another thread): invalidates captured graphs
     int conv_shape = -1;           // -1 auto, else force a conv tile shape / kernel family (tests)
     int conv_shape1 = -1;          // >= 0: the shape forced for the 1x1 convs only (they follow conv_shape otherwise): lets a test put
                                    //    every 3x3 conv AND every 1x1 conv of a model on chosen kernels at once

@@ -763,6 +763,27 @@ def test_fir2_lds_strip_form_is_bit_identical(ctx, up, B, C, H):
         _close(got, want, rtol=1e-5, atol=2e-6, what="fir2")
 
 
+@pytest.mark.parametrize("up", [0, 1])
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 2, 64), (2, 16, 2, 128), (1, 32, 2, 32), (2, 8, 4, 256)])
+def test_fir2_flat_planes_with_more_halo_than_threads(ctx, up, B, C, H, W):
+    """planes of height 2 (and wide, flat planes generally) put more halo float4s into a strip than the 256 threads fill in
+    their one pass (2 * P * W / 4 > 256): the strip geometry must refuse those and leave them to the register forms.  Not a shape of
+    the reference's configs, but `mcvd_op_fir2` accepts it: held to the oracle and to the register form, bit for bit."""
+    g = _g(14)
+    x = torch.randn(B, C, H, W, generator=g)
+    coef = torch.stack([1 + 0.3 * torch.randn(B, C, generator=g), 0.3 * torch.randn(B, C, generator=g)], dim=-1)
+    for pro in (0, 1):
+        xin = unet_ref.silu(x * coef[..., 0][:, :, None, None] + coef[..., 1][:, :, None, None]) if pro else x
+        want = unet_ref.fir_up2(xin) if up else unet_ref.fir_down2(xin)
+        ctx.opt("fir_form", 0)
+        got = ctx.fir2(x.cuda(), up, coef=coef.cuda() if pro else None, act=pro)
+        ctx.opt("fir_form", 1)
+        old = ctx.fir2(x.cuda(), up, coef=coef.cuda() if pro else None, act=pro)
+        ctx.opt("fir_form", 0)
+        assert torch.equal(got, old), f"{float((got - old).abs().max()):.3e}"
+        _close(got, want, rtol=1e-5, atol=2e-6, what="fir2 flat plane")
+
+
 @pytest.mark.parametrize("cfg,B", [("tiny", 3), ("tiny_spade", 2), ("smmnist_big5_ngf96", 2)])
 def test_fir2_lds_strip_form_in_the_network(cfg, B):
     """The same A/B through a whole forward: the down blocks take the two-output form (FIR(act(norm(x))) and FIR(x) from one read), SPADE
