@@ -122,7 +122,9 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         shallower split); 22 / 23 (models only, not mcvd_op_conv2d) a 3x3
  *         conv with a handful of channels on one side as a 1x1 GEMM on the three-piece bf16 kernel: 23 = im2col of at most 10 input
  *         channels + GEMM (the stem), 22 = GEMM to 9 * Cout planes (Cout <= 7) + shift-and-add (the last conv); kernels/conv_gemm_forms.cpp.
- *         A family that does not serve a launch falls back.  "persist_grid" (0 = one workgroup
+ *         A family that does not serve a launch falls back.  "im2col_lds" (1): shape id 23 stages its im2col in LDS inside the GEMM kernel
+ *         (conv1x1_h2.cpp IM: raw patch of the pixel tile + offset table; no HBM `col` tensor) where its geometry applies (W <= 128, whole
+ *         image rows per 128-pixel tile); 0 = im2col3x3_kernel materialises it first (bit-identical).  "persist_grid" (0 = one workgroup
  *         per CU): number of workgroups of the persistent kernel (tests: long item ranges on small tensors).
  *     "conv_shape1" (-1): the same for the 1x1 convs only (they follow "conv_shape" otherwise), so that a test can put every 3x3 AND
  *         every 1x1 conv of a model on chosen kernels at once.  "conv_cot": cout tile (32-channel units) mcvd_op_conv2d requests with

@@ -355,6 +355,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     }
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
     else if (!strcmp(key, "persist_grid")) ctx->persist_grid = value;
+    else if (!strcmp(key, "im2col_lds")) ctx->im2col_lds = value;
     else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
     else if (!strcmp(key, "spade_fuse")) ctx->spade_fuse = value;
     else if (!strcmp(key, "attn_presplit")) ctx->attn_presplit = value;

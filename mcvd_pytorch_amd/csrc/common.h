@@ -110,6 +110,10 @@ struct ConvArgs {
     // three-piece bf16 LDS images per (sample, head, key tile) instead of as fp32 rows of y: 3 * kv_C * HW dwords per sample
     float* kv_img;
     int kv_C, kv_D;       // channels of one of q / k / v; head dim
+    // conv1x1_h2.cpp only (shape id 23, the stem as a GEMM): 1 = x0 / x1 are the RAW sources of a 3x3 conv (C0 + C1 channels, H x W) and
+    // the GEMM's B operand is their im2col, staged in LDS by the kernel itself: K row k = c * 9 + t <-> x[c][y + t / 3 - 1][x + t % 3 - 1]
+    // (zero outside the image), rows 9 (C0 + C1) .. Cin - 1 zero; Cin = CinP = the padded row count.  No HBM `col` tensor.
+    int im2col;
     // the norm over THIS conv's output (single source), finalized by the K-split reduce pass when the launch has one (8 x 8 / 16 x 16
     // planes): last_conv_gn_fused() tells whether it happened
     GnOut gno;

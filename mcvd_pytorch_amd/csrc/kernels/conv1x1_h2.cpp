@@ -46,7 +46,12 @@ constexpr int Q1_MAXIMG = 4;     // images a pixel tile may span (HW >= 32)
 //     head, key tile of 32 pixels) [K image: step][piece][dword j][64 lanes] [V image: sub-tile][step s2][piece][64 lanes][4 dwords] --
 //     instead of as fp32 rows (which nothing reads any more); the Q third is stored as before.  The attention kernel split every K / V
 //     element once per QUERY TILE (8 times at 32 x 32) and spent a third of its VALU instructions on it.
-template <int NP, int COT, int PRO, int EXP = 0, bool KV = false>
+// IM (NP = 3, PRO = 0; ConvArgs::im2col; north_star: "LDS-staged im2col"): the B operand of a 3x3 conv run as a GEMM (the stem: 10 input channels,
+//     90 K rows) is gathered from a patch of the RAW input the workgroup stages once -- [C0 + C1 + 1 planes][PT / W + 2 rows][W + 2], zero outside
+//     the image (W + 8 columns in the kernel: 16-byte aligned rows), the extra plane all zeros for the padding rows of K -- through a table of patch offsets per K row; no pixel DMA, no pixel
+//     ring buffers, no `col` tensor in HBM (round 5 wrote and re-read 100 MB of it per forward).  Same K order, same MFMA order: bit-identical
+//     to the GEMM over the materialised im2col.
+template <int NP, int COT, int PRO, int EXP = 0, bool KV = false, bool IM = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptiles, int nct) {
     typedef Pieces<NP> PX;
     constexpr int PT = Q1_PT, CK = Q1_CK, NB = Q1_NB, BCO = 32 * COT;
@@ -57,12 +62,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     constexpr int WPC = WDW / 4;              // its 16-byte pieces (COT * NP * 64)
     constexpr int MAXX = XSZ / 4 / 256;       // x DMA rounds per chunk (2)
     constexpr int MAXW = (WPC + 255) / 256;   // weight DMA rounds per chunk; a partial round re-fetches pieces from the start (same data, same place)
-    constexpr int G = MAXX + MAXW;            // DMA instructions per wave and chunk: the unit of the vmcnt bookkeeping below
+    constexpr int G = (IM ? 0 : MAXX) + MAXW; // DMA instructions per wave and chunk: the unit of the vmcnt bookkeeping below
     static_assert(MAXX * 256 * 4 == XSZ && WPC % 64 == 0, "DMA rounds");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned* sW = reinterpret_cast<unsigned*>(smem);      // [NB][WDW]
-    float* sX = smem + NB * WDW;              // [NB][CK][PT]
-    float* sC = sX + NB * XSZ;                // [nimg][Cin][2] prologue coefficients of the images this pixel tile spans (PRO only)
+    float* sX = smem + NB * WDW;              // [NB][CK][PT]   (IM: no pixel ring -- the patch and the offset table live here)
+    float* sC = sX + (IM ? 0 : NB * XSZ);     // [nimg][Cin][2] prologue coefficients of the images this pixel tile spans (PRO only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -124,14 +129,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
             __builtin_amdgcn_global_load_lds(                                                                   \
                 (const __attribute__((address_space(1))) void*)(wsrc + w_goff[s]),                              \
                 (__attribute__((address_space(3))) void*)(wdst + w_lds[s]), 16, 0, 0);                          \
-        const bool second = cb >= a.C0;                                                                         \
-        const float* xsrc = second ? a.x1 + (long)(cb - a.C0) * HW : a.x0 + (long)cb * HW;                      \
-        const int voff = second ? voff1 : voff0;                                                                \
-        float* xdst = sX + ((ch) & (NB - 1)) * XSZ;                                                             \
-        _Pragma("unroll") for (int s = 0; s < MAXX; ++s)                                                        \
-            __builtin_amdgcn_global_load_lds(                                                                   \
-                (const __attribute__((address_space(1))) void*)(xsrc + (long)s * RPS * HW + voff),              \
-                (__attribute__((address_space(3))) void*)(xdst + (s * 256 + wave * 64) * 4), 16, 0, 0);         \
+        if constexpr (!IM) {                                                                                    \
+            const bool second = cb >= a.C0;                                                                     \
+            const float* xsrc = second ? a.x1 + (long)(cb - a.C0) * HW : a.x0 + (long)cb * HW;                  \
+            const int voff = second ? voff1 : voff0;                                                            \
+            float* xdst = sX + ((ch) & (NB - 1)) * XSZ;                                                         \
+            _Pragma("unroll") for (int s = 0; s < MAXX; ++s)                                                    \
+                __builtin_amdgcn_global_load_lds(                                                               \
+                    (const __attribute__((address_space(1))) void*)(xsrc + (long)s * RPS * HW + voff),          \
+                    (__attribute__((address_space(3))) void*)(xdst + (s * 256 + wave * 64) * 4), 16, 0, 0);     \
+        }                                                                                                       \
     }
 
     f32x16 acc[COT];
@@ -162,6 +169,51 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     // register sets with the reads behind the barrier (+5 %: the scheduler chains the MFMAs per accumulator), s_setprio around the MFMAs
     // (+3 %), three instead of two workgroups per CU (round 3: no gain).
     const int nchunks = Cin / CK;          // Cin % CK == 0 (launch check): the zero rows that pad the weights are never staged
+    // IM: the raw patch of this pixel tile and the K-row -> patch-offset table, through registers, IN FRONT of the weight DMAs (the compiler
+    // waits for these loads before it parks them; whatever it makes of the DMAs behind them is conservative).  The barrier of the first
+    // stage makes both visible.
+    // Patch layout [Cc + 1 planes][PR = PT / W + 2 rows][PITCH = W + 8]: the W interior pixels of a row at columns 4 .. W + 3 (16-byte aligned:
+    // float4 in, ds_write_b128 out), zero blocks at 0 .. 3 and W + 4 .. W + 7 -- a pixel tile is whole image rows, so the columns left and
+    // right of the interior are ALWAYS outside the image; only the first / last patch row can be.  Plane Cc is all zeros (padding K rows).
+    float* sPatch = sX;
+    const int im_W = a.W, im_PR = PT / (IM ? a.W : PT) + 2, im_PITCH = a.W + 8, im_Cc = a.C0 + a.C1;
+    const int im_plane = im_PR * im_PITCH;
+    int* sTab = reinterpret_cast<int*>(sPatch + (im_Cc + 1) * im_plane);       // [chunk][half][8]: K row 16 k + 2 e + h at [k][h][e]
+    int im_base = 0;
+    if constexpr (IM) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int y0 = (int)((gp0 - (long)b_first * HW) / im_W);   // first image row of the tile (HW % PT == 0, PT % W == 0: whole rows of one image)
+        const int w4 = im_W >> 2, lw4 = 31 - __builtin_clz(w4);    // W / 4 is a power of two (launch check)
+        const int rows = (im_Cc + 1) * im_PR;
+        for (int u0 = 0; u0 < rows * w4; u0 += 2 * 256) {          // interior: one float4 per unit, two units per thread in flight
+            f4 v[2];
+            int dst[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int u = u0 + j * 256 + tid;
+                const int row = u >> lw4, q = u & (w4 - 1);
+                const int c = row / im_PR, ry = row - c * im_PR;
+                const int yy = y0 - 1 + ry;
+                v[j] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+                dst[j] = u < rows * w4 ? row * im_PITCH + 4 + 4 * q : -1;
+                if (dst[j] >= 0 && c < im_Cc && yy >= 0 && yy < a.H)
+                    v[j] = *reinterpret_cast<const f4*>(c < a.C0 ? a.x0 + (((long)b_first * a.C0 + c) * a.H + yy) * im_W + 4 * q
+                                                                 : a.x1 + (((long)b_first * a.C1 + (c - a.C0)) * a.H + yy) * im_W + 4 * q);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (dst[j] >= 0) *reinterpret_cast<f4*>(sPatch + dst[j]) = v[j];
+        }
+        for (int u = tid; u < 2 * rows; u += 256)                   // the two zero blocks of every row
+            *reinterpret_cast<f4*>(sPatch + (u >> 1) * im_PITCH + (u & 1) * (im_W + 4)) = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int kk = tid; kk < Cin; kk += 256) {
+            const int c = kk / 9, t = kk - 9 * c;
+            const int off = c < im_Cc ? c * im_plane + (t / 3) * im_PITCH + (t % 3) + 3 : im_Cc * im_plane + 4;
+            sTab[(kk >> 4) * 16 + (kk & 1) * 8 + ((kk & 15) >> 1)] = off;
+        }
+        const int p = wave * 32 + l31;                              // the lane's pixel of the tile
+        im_base = (p / im_W) * im_PITCH + (p % im_W);
+    }
     Q1_DMA(0);
     if (nchunks > 1) Q1_DMA(1);
     if (nchunks > 2) Q1_DMA(2);
@@ -183,9 +235,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
         if ((k) + 3 < nchunks && !(EXP & 1)) Q1_DMA((k) + 3);                                                   \
         const float* sXc = sX + ((k) & (NB - 1)) * XSZ + x_lane;       /* (the lane's half is in the base: the eight reads differ by immediates) */ \
         const float* sCb = sC + ((long)my_img * Cin + (k) * CK) * 2 + half * 2;                                 \
+        if constexpr (IM) {     /* K rows 16 k + 2 e + h of lane (n, h): their patch offsets from the table, then the gather */ \
+            const u32x4* tp = reinterpret_cast<const u32x4*>(sTab + (k) * 16 + half * 8);                       \
+            const u32x4 t0 = tp[0], t1 = tp[1];                                                                 \
+            const float* pb = sPatch + im_base;                                                                 \
+            BV[0] = pb[t0[0]]; BV[1] = pb[t0[1]]; BV[2] = pb[t0[2]]; BV[3] = pb[t0[3]];                         \
+            BV[4] = pb[t1[0]]; BV[5] = pb[t1[1]]; BV[6] = pb[t1[2]]; BV[7] = pb[t1[3]];                         \
+        } else {                                                                                                \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {         /* element e of lane (n, h) = channel 2e + h of the chunk */ \
             BV[e] = sXc[2 * e * PT];                                                                            \
             if (PRO != 0) CF[e] = *reinterpret_cast<const f32x2*>(sCb + 4 * e);                                 \
+        }                                                                                                       \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     }
@@ -426,9 +486,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     }
 }
 
-static size_t q1_lds_bytes(int np, int cot, int Cin, int HW) {
+// im_cc > 0: the im2col form (ConvArgs::im2col) -- no pixel ring; the raw patch [im_cc + 1][PT / W + 2][W + 8] and the offset table [Cin] instead
+static size_t q1_lds_bytes(int np, int cot, int Cin, int HW, int im_cc = 0, int W = 0) {
     const int nimg = HW >= Q1_PT ? 1 : Q1_PT / HW;
-    const size_t loop = (size_t)(Q1_NB * (cot * np * 256) + Q1_NB * Q1_CK * Q1_PT + nimg * Cin * 2) * sizeof(float);
+    const size_t pix = im_cc > 0 ? (size_t)((im_cc + 1) * (Q1_PT / W + 2) * (W + 8) + Cin) : (size_t)Q1_NB * Q1_CK * Q1_PT + (size_t)nimg * Cin * 2;
+    const size_t loop = ((size_t)Q1_NB * (cot * np * 256) + pix) * sizeof(float);
     const size_t epi = (size_t)(32 * cot) * (Q1_PT + 4) * sizeof(float);      // the transposed output tile (row pitch PT + 4) overlays the chunk buffers
     return loop > epi ? loop : epi;
 }
@@ -438,6 +500,11 @@ bool conv1x1_h2_supported(const ConvArgs& a, int cot, int np) {
     const int HW = a.H * a.W;
     if (np != 2 && np != 3) return false;
     if (a.ks != 1 || !(np == 2 ? a.wph : a.wpb) || HW % 32 != 0 || cot < 1 || cot > 4 || (a.CoutP / 32) % cot != 0) return false;
+    if (a.im2col) {          // the stem as a GEMM over an im2col the kernel stages itself: whole image rows per pixel tile, raw input, three pieces
+        return np == 3 && !a.coef && !a.act && !a.kv_img && a.W >= 8 && a.W <= Q1_PT && (a.W & (a.W - 1)) == 0 && HW % Q1_PT == 0 && a.Cin % Q1_CK == 0 &&
+               a.Cin == a.CinP && a.Cin >= 9 * (a.C0 + a.C1) && (long)a.B * (a.C0 > a.C1 ? a.C0 : a.C1) * HW < (1L << 31) &&
+               q1_lds_bytes(np, cot, a.Cin, HW, a.C0 + a.C1, a.W) <= 80 * 1024;
+    }
     if (!(HW % Q1_PT == 0 || (HW < Q1_PT && Q1_PT % HW == 0 && Q1_PT / HW <= Q1_MAXIMG))) return false;
     if (a.Cin % Q1_CK != 0 || a.CinP % Q1_CK != 0) return false;            // no partial chunk: every staged row is real data
     if (a.C1 > 0 && a.C0 % Q1_CK != 0) return false;                        // a chunk never straddles the concat seam
@@ -452,8 +519,20 @@ static int q1_launch(const ConvArgs& a, hipStream_t s) {
     const long NPX = (long)a.B * HW;
     const int ptiles = (int)((NPX + Q1_PT - 1) / Q1_PT);
     const int nct = a.CoutP / (32 * COT);
-    const size_t lds = q1_lds_bytes(NP, COT, a.Cin, HW);
+    const size_t lds = q1_lds_bytes(NP, COT, a.Cin, HW, a.im2col ? a.C0 + a.C1 : 0, a.W);
     const dim3 grid(((ptiles + 7) / 8) * 8 * nct);
+    if constexpr (NP == 3) {
+        if (a.im2col) {
+            static PerDeviceOnce raised_im;
+            if (lds > 48 * 1024 && raised_im.first_use()) {
+                MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<3, COT, 0, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                raised_im.done();
+            }
+            hipLaunchKernelGGL((conv1x1_h2_kernel<3, COT, 0, 0, false, true>), grid, dim3(256), lds, s, a, ptiles, nct);
+            MCVD_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     static PerDeviceOnce raised;
     if (lds > 48 * 1024 && raised.first_use()) {
         MCVD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_h2_kernel<NP, COT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

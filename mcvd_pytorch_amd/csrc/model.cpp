@@ -711,8 +711,18 @@ ConvArgs mcvd_model::gemm_form_args(const Op& op, const ConvArgs& a, float* buf)
         g.res = nullptr; g.out_scale = 1.0f; g.stats = nullptr;
         g.y = buf;
     } else {                                 // the im2col rows -> Cout; the epilogue is the conv's
-        g.x0 = buf; g.x1 = nullptr;
-        g.C0 = g.Cin = op.alt_CinP; g.C1 = 0;
+        g.Cin = op.alt_CinP;
+        g.im2col = 1;                        // staged in LDS by the GEMM itself (g.x0 / x1 / C0 / C1 stay the conv's raw sources) ...
+        bool lds_form = ctx->im2col_lds != 0;
+        if (lds_form) {
+            lds_form = false;
+            for (int c = 4; c >= 1 && !lds_form; --c) lds_form = conv1x1_h2_supported(g, c, 3);
+        }
+        if (!lds_form) {                     // ... or materialised in `buf` first, where that form's geometry does not apply (or option im2col_lds = 0)
+            g.im2col = 0;
+            g.x0 = buf; g.x1 = nullptr;
+            g.C0 = op.alt_CinP; g.C1 = 0;
+        }
     }
     int cot = a.cot;
     if (cot < 1 || cot > 4 || !conv1x1_h2_supported(g, cot, 3))
@@ -723,7 +733,7 @@ ConvArgs mcvd_model::gemm_form_args(const Op& op, const ConvArgs& a, float* buf)
 
 int mcvd_model::launch_gemm_form(const Op& op, const ConvArgs& a, float* buf, hipStream_t s) {
     const ConvArgs g = gemm_form_args(op, a, buf);
-    if (op.alt_kind == 23)
+    if (op.alt_kind == 23 && !g.im2col)
         if (int rc = launch_im2col3x3(a.x0, a.C0, a.x1, a.C1, buf, a.B, a.H, a.W, op.alt_CinP, s)) return rc;
     if (int rc = launch_conv_mfma(g, s)) return rc;
     if (op.alt_kind == 22) return launch_taps_shift_add(buf, a.bias, a.res, a.out_scale, a.y, a.B, a.Cout, a.H, a.W, s);

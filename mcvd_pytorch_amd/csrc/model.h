@@ -28,6 +28,8 @@ struct mcvd_ctx {
                                    //    every 3x3 conv AND every 1x1 conv of a model on chosen kernels at once
     int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
     int persist_grid = 0;          // > 0: workgroups of the persistent Winograd kernel (tests); 0 = one per CU
+    int im2col_lds = 1;            // shape id 23 (the stem as a GEMM): the im2col is staged in LDS by the GEMM kernel itself (conv1x1_h2.cpp IM) where its
+                                   //    geometry applies; 0 = materialised in HBM by im2col3x3_kernel first (round 5's form; bit-identical results)
     int wino_selftest = 0;         // 0 not run yet, 1 passed, -1 FAILED: the hand-scheduled bf16 Winograd kernels disagree with the fp32-MFMA Winograd
                                    //    kernel on this device / driver (mcvd_ctx_selftest); bf16x3 was switched off for this context
     int conv_cot = 0;              // > 0 with conv_shape 5: cout tile (32-channel units) mcvd_op_conv2d requests (tests)

@@ -619,6 +619,33 @@ def test_conv3x3_as_gemm_forms(cfg, B, form):
     assert (a.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("cfg,B", [("smmnist_big5_ngf96", 2), ("smmnist_big5", 3), ("tiny", 3), ("tiny", 1)])
+def test_stem_im2col_staged_in_lds_is_bit_identical(cfg, B):
+    """north_star: "LDS-staged im2col".  Shape id 23 (the stem, 3x3 conv over 4 ... 10 frame channels, as a GEMM on the three-piece bf16 kernel):
+    the GEMM kernel stages the raw input patch of its pixel tile in LDS and gathers its B operand from it through a table of patch offsets
+    (conv1x1_h2.cpp IM, option im2col_lds = 1, the default) instead of reading a `col` tensor that im2col3x3_kernel wrote to HBM first
+    (option im2col_lds = 0: round 5's form).  Same K rows in the same order through the same MFMAs: eps must be BIT-IDENTICAL, at 64 x 64
+    (two image rows per pixel tile) and 32 x 32 (four), virtual-concat input [x, cond]; the norm behind the stem reads the GEMM epilogue's
+    partial statistics either way (ncsnpp_more.py:188, :288-290; layers.py:107-113)."""
+    config, sd, net = _net(cfg)
+    net.set_option("conv_shape", 23)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    t = torch.tensor([700, 20, 333][:B]).cuda()
+    a = net(x.cuda(), t, cond=cond.cuda()).clone()
+    took = [k for k in _conv_kernels(net) if k[4] == 23]
+    assert len(took) == 1 and took[0][0] == 3, took
+    net.set_option("im2col_lds", 0)
+    b = net(x.cuda(), t, cond=cond.cuda()).clone()
+    assert [k for k in _conv_kernels(net) if k[4] == 23] == took
+    net.set_option("im2col_lds", 1)
+    c = net(x.cuda(), t, cond=cond.cuda()).clone()
+    assert torch.equal(a, b), f"LDS-staged im2col differs from the materialised one: {float((a - b).abs().max()):.3e}"
+    assert torch.equal(a, c)
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, config, x, t.cpu(), cond)
+    assert (a.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("cfg,B", [("smmnist_big5_ngf96", 2), ("smmnist_big5", 3), ("tiny", 3), ("kth64_big_ngf128", 2)])
 def test_attention_with_presplit_kv_is_bit_identical(cfg, B):
     """the fused q|k|v projection writes K and V ALREADY SPLIT into the three bf16 pieces, in the LDS-image order the
