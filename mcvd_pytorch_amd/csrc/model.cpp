@@ -187,7 +187,9 @@ struct Builder {
                 p.alt_kind = 22;
                 p.alt_CinP = round_up(Cin, 16);
                 p.alt_CoutP = round_up(9 * Cout, 32);
-            } else if (9 * Cin <= 96) {                  // im2col: 9 * Cin -> Cout
+            } else if (9 * Cin <= 256) {                 // im2col: 9 * Cin -> Cout.  Up to 10 input channels (96 rows) either staged in LDS by the GEMM
+                                                         // (conv1x1_h2.cpp IM) or materialised in HBM (im2col3x3_kernel; needs the `col` buffer); up to 28
+                                                         // channels (kth / bair: 15, cityscapes: 21) in the LDS form only
                 p.alt_kind = 23;
                 p.alt_CinP = round_up(9 * Cin, 16);
                 p.alt_CoutP = p.CoutP;
@@ -202,7 +204,8 @@ struct Builder {
                 op.alt_CinP = p.alt_CinP;
                 op.alt_CoutP = p.alt_CoutP;
                 op.alt_bias = p.alt_kind == 22 ? alloc_packed(p.alt_CoutP) : -1;           // (the packed blob is zero-filled: a zero bias)
-                op.alt_buf = p.alt_kind == 22 ? alloc(9 * Cout, op.H) : alloc(p.alt_CinP, op.H);
+                if (p.alt_kind == 22) op.alt_buf = alloc(9 * Cout, op.H);
+                else if (9 * Cin <= 96) op.alt_buf = alloc(p.alt_CinP, op.H);                   // (wider stems: no `col` buffer, the LDS form or nothing)
             }
         }
         op.wpw = p.wpw;
@@ -689,6 +692,7 @@ bool mcvd_model::gemm_form_usable(const Op& op, const ConvArgs& a) const {
     if (op.alt_kind == 22 && (a.stats || a.C1 != 0)) return false;        // (the shift-and-add pass emits no GroupNorm partials; one source)
     if (op.alt_kind == 23 && (a.coef || a.act)) return false;             // (im2col copies raw values)
     ConvArgs g = gemm_form_args(op, a, nullptr);
+    if (op.alt_kind == 23 && !g.im2col && op.alt_buf.kind == REF_NONE) return false;      // (a wide stem whose geometry the LDS form does not take)
     for (int c = 4; c >= 1; --c)
         if (conv1x1_h2_supported(g, c, 3)) return true;
     return false;
