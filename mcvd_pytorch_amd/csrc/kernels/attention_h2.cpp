@@ -94,8 +94,16 @@ constexpr float AH_LAZY = 40.0f;
 #define AH_QS(scale_s) ((scale_s) * AH_LOG2E)
 #endif
 
+// (tools/repro_coresident.cpp compiles this kernel stand-alone with other launch bounds / function attributes: the co-residency report of
+// DESIGN.md section 7.  The product build leaves both macros at their defaults.)
+#ifndef MCVD_AH_LB
+#define MCVD_AH_LB __launch_bounds__(256, 2)
+#endif
+#ifndef MCVD_AH_ATTR
+#define MCVD_AH_ATTR
+#endif
 template <int NP, int DT>   // head dim D = 32*DT
-__global__ __launch_bounds__(256, 2) void attn_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int heads, int S,
+__global__ MCVD_AH_LB MCVD_AH_ATTR void attn_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int heads, int S,
                                                           float scale_s, int nbh, int nqt) {
     typedef Pieces<NP> PX;
     constexpr int D = 32 * DT, NST = D / 16;

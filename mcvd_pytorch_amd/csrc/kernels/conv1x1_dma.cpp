@@ -109,8 +109,12 @@ __global__ __launch_bounds__(256, COT * PXW <= 3 ? 4 : (COT * PXW <= 4 ? 3 : 1))
             for (int r = 0; r < 16; ++r) acc[j][ct][r] = 0.0f;
 
     const int nchunks = Cin / CK;          // Cin % CK == 0 (launch check): the zero rows that pad wp to CinP are never staged
+    // (An LDS-DMA is a load without a destination register: the compiler makes nobody wait for it in front of a barrier.  The wave that
+    // issued it waits for it explicitly before the barrier that publishes the chunk -- conv_mfma.h has the story; with a prologue the wait
+    // for the coefficient load, which is younger than the DMAs, used to cover them by accident, with a raw input nothing did.)
     G1_DMA(0);
     G1_WRITE_C(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -140,7 +144,8 @@ __global__ __launch_bounds__(256, COT * PXW <= 3 ? 4 : (COT * PXW <= 4 ? 3 : 1))
             }
         }
         if (more) G1_WRITE_C(ch + 1);
-        __syncthreads();                       // chunk ch consumed by every wave; the DMA of chunk ch+1 has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's part of chunk ch + 1 has landed ...
+        __syncthreads();                       // ... chunk ch consumed by every wave, chunk ch + 1 published
     }
 #undef G1_DMA
 #undef G1_WRITE_C

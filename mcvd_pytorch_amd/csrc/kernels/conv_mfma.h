@@ -289,10 +289,21 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
         tprev = tn;                                                     \
     }
 
+    // LDS-DMA and barriers.  A weight chunk that arrives by global_load_lds is written to LDS ASYNCHRONOUSLY, tracked by the issuing wave's
+    // vmcnt only.  To the compiler the instruction is a load without a destination register: nothing makes it wait for it in front of an
+    // s_barrier (a release fence does not wait for loads), and a wait it inserts later, in front of the wave's own LDS reads, covers that
+    // wave's part of the chunk but not the parts the other waves fetched.  So the wave that issued a DMA waits for it EXPLICITLY before the
+    // barrier that publishes the chunk.  Round 6 found the single-buffered path (WDMA && !WDB) without any such wait -- the generated code
+    // had s_waitcnt lgkmcnt(0); s_barrier behind the DMA -- i.e. a timing-dependent read of a weight chunk that has not landed: correct when
+    // the kernel runs alone (the activation patch takes longer to write than the DMA takes to land), wrong in half of the launches beside a
+    // memory-hungry kernel on another stream (tools/repro_coresident.cpp, profiles/r06_coresident_repro.txt).
+#define MCVD_DMA_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
     const int nchunks = a.CinP / CK;
     MCVD_LOAD_CHUNK(0);
+    if (WDB) MCVD_DMA_LANDED();
     __syncthreads();              // zero fill done
     MCVD_WRITE_CHUNK(0);
+    if (WDMA && !WDB) MCVD_DMA_LANDED();
     __syncthreads();
     MCVD_STAMP(0)
 
@@ -320,11 +331,13 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
             }
         }
         MCVD_STAMP(1)
+        if (WDB) MCVD_DMA_LANDED();          // chunk ch + 1's weights (requested above, into the idle buffer) are published by this barrier
         __syncthreads();
         MCVD_STAMP(2)
         if (ch + 1 < nchunks) {
             MCVD_WRITE_CHUNK(ch + 1);
             MCVD_STAMP(3)
+            if (WDMA && !WDB) MCVD_DMA_LANDED();   // single buffer: the DMA was issued inside MCVD_WRITE_CHUNK
             __syncthreads();
             MCVD_STAMP(4)
         }

@@ -39,7 +39,11 @@ def main():
     torch.cuda.synchronize()
 
     def op(kind, c):
-        if kind == "fir":                       # fir_up2_kernel: the victim of the two-process report
+        if kind == "fir":                       # the x2 FIR upsampler as the library launches it today (LDS strip form)
+            c.opt("fir_form", 0)
+            return c.fir2(xf, 1, coef=coeff, act=1)
+        if kind == "fir1":                      # fir_up2_kernel, the register form: the victim of the round-4 / round-5 reports
+            c.opt("fir_form", 1)
             return c.fir2(xf, 1, coef=coeff, act=1)
         if kind == "attn96":                    # attn_h2_kernel<3,3>: the aggressor of the two-process report
             c.opt("naive_attn", 4)
@@ -94,7 +98,9 @@ def main():
         return bad
 
     total = 0
-    for victim, aggressor in (("fir", None), ("fir", "attn96"), ("c3", "attn96"), ("attn96", "fir"), ("fir", "attn96f32"), ("attn96", "attn96")):
+    plan = (("fir", None), ("fir", "attn96"), ("fir1", None), ("fir1", "attn96"), ("c3", None), ("c3", "attn96"), ("attn96", "fir"), ("fir", "attn96f32"), ("c3", "attn96f32"),
+            ("attn96", "attn96"))
+    for victim, aggressor in plan:
         total += phase(victim, aggressor)
     print("TOTAL corrupted launches across streams of one process:", total, flush=True)
 
