@@ -25,6 +25,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdarg.h>
+#include <string.h>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -57,6 +58,17 @@ __global__ __launch_bounds__(256) void victim_kernel(const f32x2* __restrict__ x
         }
         y[i] = v;
     }
+}
+
+// AGGR=lds: not the attention kernel but a kernel that only FILLS its LDS (and a few hundred registers) with a recognisable value and exits --
+// does a victim pick up what a previous tenant of the CU left behind (LDS or registers it reads before it has written them)?
+__global__ __launch_bounds__(256) void polluter_kernel(float* sink, unsigned pattern, int spin) {
+    extern __shared__ unsigned pl[];
+    for (int i = threadIdx.x; i < 15 * 1024; i += 256) pl[i] = pattern;
+    __syncthreads();
+    unsigned acc = 0;
+    for (int k = 0; k < spin; ++k) acc += pl[(threadIdx.x * 17 + k * 256) % (15 * 1024)];
+    if (acc == 12345u) sink[0] = 1.0f;
 }
 
 __global__ void compare_kernel(const unsigned* y, const unsigned* ref, long n, unsigned* bad, unsigned* first) {
@@ -126,7 +138,11 @@ int main(int argc, char** argv) {
         CK(hipMemset(cb, 0, 96 * 4)); CK(hipMemcpy(cco, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
     }
     int aggr_kind = 0;                           // 0 the stand-alone build of the aggressor, 1 the library's
+    const bool pollute = getenv("AGGR") && !strcmp(getenv("AGGR"), "lds");
+    const unsigned pattern = getenv("PATTERN") ? (unsigned)strtoul(getenv("PATTERN"), nullptr, 16) : 0x7f800000u;      // +Inf
+    if (pollute) printf("# aggressor: polluter_kernel (60 KB of LDS filled with 0x%08x), NOT the attention kernel\n", pattern);
     auto aggressor_once = [&]() {
+        if (pollute) { hipLaunchKernelGGL(polluter_kernel, dim3(2048), dim3(256), 60 * 1024, sa, out, pattern, 64); return 0; }
         if (aggr_kind == 1) return lib_attn(ctx_a, qkv, out, B, C, heads, HW);
         return mcvd::launch_attention_h2(qkv, out, B, C, heads, HW, sa, 3);
     };
