@@ -122,7 +122,9 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         shallower split); 22 / 23 (models only, not mcvd_op_conv2d) a 3x3
  *         conv with a handful of channels on one side as a 1x1 GEMM on the three-piece bf16 kernel: 23 = im2col of at most 10 input
  *         channels + GEMM (the stem), 22 = GEMM to 9 * Cout planes (Cout <= 7) + shift-and-add (the last conv); kernels/conv_gemm_forms.cpp.
- *         A family that does not serve a launch falls back.  "im2col_lds" (1): shape id 23 stages its im2col in LDS inside the GEMM kernel
+ *         A family that does not serve a launch falls back.  "temb_table" (1): the device-loop samplers (mcvd_sampler_run) run the time MLP and all
+ *         Dense_0 projections ONCE per call for the labels of all its forwards and every forward starts with a device copy of its row instead of
+ *         those two launches (bit-identical; 0 = per forward, as mcvd_unet_forward always does).  "im2col_lds" (1): shape id 23 stages its im2col in LDS inside the GEMM kernel
  *         (conv1x1_h2.cpp IM: raw patch of the pixel tile + offset table; no HBM `col` tensor) where its geometry applies (W <= 128, whole
  *         image rows per 128-pixel tile); 0 = im2col3x3_kernel materialises it first (bit-identical).  "persist_grid" (0 = one workgroup
  *         per CU): number of workgroups of the persistent kernel (tests: long item ranges on small tensors).

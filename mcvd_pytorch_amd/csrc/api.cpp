@@ -355,6 +355,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     }
     else if (!strcmp(key, "conv_cot")) ctx->conv_cot = value;
     else if (!strcmp(key, "persist_grid")) ctx->persist_grid = value;
+    else if (!strcmp(key, "temb_table")) ctx->temb_table = value;
     else if (!strcmp(key, "im2col_lds")) ctx->im2col_lds = value;
     else if (!strcmp(key, "gn_stats")) ctx->gn_stats = value;
     else if (!strcmp(key, "spade_fuse")) ctx->spade_fuse = value;
@@ -443,6 +444,9 @@ void mcvd_model_destroy(mcvd_model* m) {
     if (m->eps_buf) (void)hipFree(m->eps_buf);
     if (m->ksplit_buf) (void)hipFree(m->ksplit_buf);
     if (m->labels_f) (void)hipFree(m->labels_f);
+    if (m->temb_tab) (void)hipFree(m->temb_tab);
+    if (m->temb_tmp) (void)hipFree(m->temb_tmp);
+    if (m->temb_lab) (void)hipFree(m->temb_lab);
     if (m->fp_buf) (void)hipFree(m->fp_buf);
     if (m->alphas_dev) (void)hipFree(m->alphas_dev);
     if (m->cond_z) (void)hipFree(m->cond_z);
@@ -879,8 +883,21 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
         m->cond_noise_offset = sample_offset;
         m->cond_noise_draw = 0;
     }
-    struct CondGammaGuard { mcvd_model* m; ~CondGammaGuard() { m->cond_gamma_k = 0.f; m->uniform_labels = 0; } } cg_guard{m};
+    struct CondGammaGuard { mcvd_model* m; ~CondGammaGuard() { m->cond_gamma_k = 0.f; m->uniform_labels = 0; m->temb_row_live = 0; } } cg_guard{m};
     m->uniform_labels = 1;            // every forward of the loop labels all rows alike (:283, :332)
+    // the labels of every forward of this call, in order: the executed steps (:269-270, :283), then L - 1 for the denoise pass (:332)
+    int fwd_no = 0;
+    if (m->ctx->temb_table && !m->d.cond_emb) {
+        std::vector<int> fl;
+        for (int i = 0; i < L; ++i) {
+            const double thr = t_min * (double)L;
+            if (subsampled ? ((float)steps[i] < (float)thr) : ((double)steps[i] < thr)) continue;
+            fl.push_back(steps[i]);
+        }
+        if (flags & MCVD_FLAG_DENOISE) fl.push_back(L - 1);
+        if (!fl.empty())
+            if (int rc = m->prepare_temb_table(fl)) return rc;
+    }
     auto set_cond_gamma = [&](int label) {         // ncsnpp_more.py:761-765: k_cum[labels], theta_t[labels], alphas[labels]
         if (!(gam && m->d.noise_in_cond)) return;
         m->cond_gamma_k = m->k_cum[label];
@@ -915,6 +932,8 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
         started = true;
         if (int rc = launch_fill_labels(m->labels, steps[i], B, s)) return rc;           // :283
         set_cond_gamma(steps[i]);
+        if (m->temb_row_live)
+            if (int rc = m->use_temb_row(fwd_no++, B)) return rc;
         if (int rc = m->forward(x, m->labels, cond, m->eps_buf, B)) return rc;           // :284
         const float c_x0a = 1.0f / sqrtf(a), c_x0b = sqrtf(1.0f - a);                    // :287
         float c0, c1, cn = 0.0f;
@@ -940,6 +959,8 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
     if (flags & MCVD_FLAG_DENOISE) {                                                      // :331-333, label L-1 (sic)
         if (int rc = launch_fill_labels(m->labels, L - 1, B, s)) return rc;
         set_cond_gamma(L - 1);
+        if (m->temb_row_live)
+            if (int rc = m->use_temb_row(fwd_no++, B)) return rc;
         if (int rc = m->forward(x, m->labels, cond, m->eps_buf, B)) return rc;
         if (int rc = launch_axpy_out(x, m->eps_buf, sqrtf(1.0f - al[L - 1]), n, s)) return rc;
     }

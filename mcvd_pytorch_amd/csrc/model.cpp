@@ -748,6 +748,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
     hipStream_t s = op_stream ? op_stream : ctx->stream;
     switch (op.kind) {
         case OP_TEMB: {
+            if (temb_row_live) return 0;      // this forward's row of the call's table is already in ops[1].dst (use_temb_row)
             const float* w0 = blob + params[find_param("unet.all_modules.0.weight")].off;
             const float* b0 = blob + params[find_param("unet.all_modules.0.bias")].off;
             const float* w1 = blob + params[find_param("unet.all_modules.1.weight")].off;
@@ -758,6 +759,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                                    (uniform_labels && !d.cond_emb) ? 1 : B, d.ngf, T, emb, cond_mask, s);
         }
         case OP_DENSE:
+            if (temb_row_live) return 0;
             return launch_dense_all(resolve(op.src0, x, cond, out, B), packed + dense_wt, packed + dense_bias,
                                     resolve(op.dst, x, cond, out, B), (uniform_labels && !d.cond_emb) ? 1 : B, T, NE, s);
         case OP_GN:
@@ -1330,7 +1332,7 @@ int mcvd_model::forward_unchecked(const float* x, const void* lab, const float* 
         // happens inside a capture), captured + instantiated the second time, replayed from then on.  The sampler loop
         // presents the same (x, labels, eps, cond, B) for every step of a call.
         GraphKey k;
-        k.x = x; k.lab = lab; k.cond = cond; k.out = out; k.B = B; k.labels_f32 = labels_f32 | (uniform_labels << 1); k.mask = cond_mask; k.epoch = epoch; k.ctx_epoch = ctx->epoch;
+        k.x = x; k.lab = lab; k.cond = cond; k.out = out; k.B = B; k.labels_f32 = labels_f32 | (uniform_labels << 1) | (temb_row_live << 2); k.mask = cond_mask; k.epoch = epoch; k.ctx_epoch = ctx->epoch;
         if (graph_exec && k == graph_key) {
             MCVD_HIP_CHECK(hipGraphLaunch(graph_exec, ctx->stream));
             ++graph_replays;
@@ -1373,6 +1375,44 @@ int mcvd_model::forward_unchecked(const float* x, const void* lab, const float* 
         graph_seen = k;
     }
     return forward_ops(x, lab, cond, out, B);
+}
+
+// silu(temb) and all Dense_0 projections for every label of a sampler call: the forward's own two kernels over `rows` rows (rows are independent;
+// dense_all's summation order does not depend on the row count: temb.cpp), into a table the forwards copy their row from.
+int mcvd_model::prepare_temb_table(const std::vector<int>& labels) {
+    hipStream_t s = ctx->stream;
+    const size_t rows = labels.size();
+    if (rows > temb_rows_cap) {
+        MCVD_HIP_CHECK(hipStreamSynchronize(s));
+        if (temb_tab) (void)hipFree(temb_tab);
+        if (temb_tmp) (void)hipFree(temb_tmp);
+        if (temb_lab) (void)hipFree(temb_lab);
+        temb_tab = nullptr; temb_tmp = nullptr; temb_lab = nullptr; temb_rows_cap = 0;
+        MCVD_HIP_CHECK(hipMalloc((void**)&temb_tab, rows * (size_t)NE * sizeof(float)));
+        MCVD_HIP_CHECK(hipMalloc((void**)&temb_tmp, rows * (size_t)T * sizeof(float)));
+        MCVD_HIP_CHECK(hipMalloc((void**)&temb_lab, rows * sizeof(int64_t)));
+        temb_rows_cap = rows;
+    }
+    std::vector<int64_t> h(labels.begin(), labels.end());
+    MCVD_HIP_CHECK(hipMemcpyAsync(temb_lab, h.data(), rows * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    MCVD_HIP_CHECK(hipStreamSynchronize(s));           // (h is a pageable temporary; once per sampler call)
+    const float* w0 = blob + params[find_param("unet.all_modules.0.weight")].off;
+    const float* b0 = blob + params[find_param("unet.all_modules.0.bias")].off;
+    const float* w1 = blob + params[find_param("unet.all_modules.1.weight")].off;
+    const float* b1 = blob + params[find_param("unet.all_modules.1.bias")].off;
+    if (int rc = launch_temb_mlp(temb_lab, 0, packed + freqs_off, w0, b0, w1, b1, temb_tmp, (int)rows, d.ngf, T, nullptr, nullptr, s)) return rc;
+    if (int rc = launch_dense_all(temb_tmp, packed + dense_wt, packed + dense_bias, temb_tab, (int)rows, T, NE, s)) return rc;
+    temb_row_live = 1;
+    return 0;
+}
+
+// the table's row `row` -> the Dense_0 output buffer of the forward about to run (the only thing of the two skipped ops a forward reads; the
+// time MLP's own output buffer keeps the values of the last forward that ran it)
+int mcvd_model::use_temb_row(int row, int B) {
+    MCVD_REQUIRE(temb_row_live && row >= 0 && (size_t)row < temb_rows_cap, "use_temb_row: row %d", row);
+    float* dense_dst = arena + ops[1].dst.off * (int64_t)B;
+    MCVD_HIP_CHECK(hipMemcpyAsync(dense_dst, temb_tab + (size_t)row * NE, (size_t)NE * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
 }
 
 void mcvd_model::drop_graph() {

@@ -28,6 +28,7 @@ struct mcvd_ctx {
                                    //    every 3x3 conv AND every 1x1 conv of a model on chosen kernels at once
     int winograd = 1;              // offer the Winograd F(2x2,3x3) kernel to the autotuner (3x3 convs, H%8==0, W%16==0)
     int persist_grid = 0;          // > 0: workgroups of the persistent Winograd kernel (tests); 0 = one per CU
+    int temb_table = 1;            // device-loop samplers: time MLP + Dense_0 projections once per call for all its labels (mcvd_model::prepare_temb_table)
     int im2col_lds = 1;            // shape id 23 (the stem as a GEMM): the im2col is staged in LDS by the GEMM kernel itself (conv1x1_h2.cpp IM) where its
                                    //    geometry applies; 0 = materialised in HBM by im2col3x3_kernel first (round 5's form; bit-identical results)
     int wino_selftest = 0;         // 0 not run yet, 1 passed, -1 FAILED: the hand-scheduled bf16 Winograd kernels disagree with the fp32-MFMA Winograd
@@ -263,6 +264,18 @@ struct mcvd_model {
     int find_param(const char* name) const;
     int ensure_workspace(int B);
     int ensure_ksplit(int B);                               // partial-output buffer of the K-split layers, for the deepest split selectable at B
+    // Time-embedding table of a device-loop sampler call (option "temb_table"): the labels of ALL its forwards are known before the first one
+    // (models/__init__.py:229-237, :283, :332), and the time MLP + every Dense_0 projection depend on nothing else -- so both run ONCE per call
+    // for all L + 1 labels (two launches instead of 2 (L + 1)), and each forward starts with a 46 KB device copy of its row instead of the two
+    // latency-bound launches at its head (34 + 13 us of a 12.2 ms forward on config 2, 36 + 20 us of 5.3 ms on config 4).  Same kernels, rows are
+    // independent: bit-identical.
+    float* temb_tab = nullptr;        // [rows][NE]   Dense_0 outputs per forward of the call
+    float* temb_tmp = nullptr;        // [rows][T]    silu(temb) per forward of the call
+    int64_t* temb_lab = nullptr;      // [rows]
+    size_t temb_rows_cap = 0;
+    int temb_row_live = 0;            // 1: OP_TEMB / OP_DENSE are skipped, ops[1].dst holds the row use_temb_row copied there
+    int prepare_temb_table(const std::vector<int>& labels);
+    int use_temb_row(int row, int B);
     int uniform_labels = 0;        // every row of the forward in flight carries the SAME label (the sampler loops): the time MLP and
                                    //    the Dense_0 projections are evaluated for one row and read with stride 0
     int labels_f32 = 0;            // the labels of the forward in flight are float [B] instead of int64 [B] (mcvd_unet_forward_ft)

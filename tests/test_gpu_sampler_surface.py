@@ -231,3 +231,36 @@ def test_three_edits_of_integration_md_against_the_real_runner(golden_dir, capsy
         for i in (3, 4, 5):
             va, vb = float(ma.group(i)), float(mb.group(i))
             assert abs(va - vb) <= 1e-3 * abs(vb), (a, b)
+
+
+@pytest.mark.parametrize("cfg,B,kind,kw", [
+    ("tiny", 3, "ddpm", dict(subsample_steps=10)),
+    ("tiny", 2, "ddpm", dict(subsample_steps=10, t_min=0.35)),                 # skipped steps: the table holds the executed ones only
+    ("tiny", 2, "ddim", dict(subsample_steps=10, denoise=False)),              # no denoise row
+    ("tiny_spade", 2, "ddpm", dict(subsample_steps=10)),                       # SPADE: coef2 tables derived from the row
+    ("smmnist_big5_ngf96", 2, "ddpm", dict(subsample_steps=20)),
+])
+@pytest.mark.parametrize("graph", [0, 1])
+def test_time_embedding_table_of_a_sampler_call_is_bit_identical(cfg, B, kind, kw, graph):
+    """Option temb_table (default on): a device-loop sampler call knows the labels of all its forwards before the first one
+    (models/__init__.py:229-237, :283, :332) and the time MLP + Dense_0 projections depend on nothing else (ncsnpp_more.py:273-280,
+    layerspp.py:521): they run once per call for all L (+ 1) labels and each forward copies its row.  Same kernels, independent rows: the
+    frames must be BIT-IDENTICAL to the per-forward form (temb_table = 0), with and without hipGraph replay."""
+    from mcvd_pytorch_amd.samplers import ddim_sampler, ddpm_sampler
+    config, sd, net = _net(cfg)
+    net.set_option("graph", graph)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    noise = synth.make_noise(config, B, 21, seed=2).cuda()
+    sampler = ddpm_sampler if kind == "ddpm" else ddim_sampler
+    outs = []
+    for tab in (1, 0, 1):
+        net.set_option("temb_table", tab)
+        outs.append(sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, verbose=False, log=False, noise=noise, **kw).clone())
+    assert torch.equal(outs[0], outs[1]), f"{float((outs[0] - outs[1]).abs().max()):.3e}"
+    assert torch.equal(outs[0], outs[2])
+    # and a plain forward after the call computes its own embedding again (the table is a property of the call)
+    t = torch.tensor([700, 20, 333][:B]).cuda()
+    a = net(x.cuda(), t, cond=cond.cuda()).clone()
+    net.set_option("temb_table", 0)
+    b = net(x.cuda(), t, cond=cond.cuda()).clone()
+    assert torch.equal(a, b)
