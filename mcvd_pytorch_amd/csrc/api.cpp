@@ -766,7 +766,9 @@ int mcvd_model_profile_read(mcvd_model* m, int* kinds, int* ks, double* ms, doub
         const Op& op = m->ops[i];
         float t = 0.f;
         // (the (1 + scale, shift) table ops behind the first one launch nothing: the first fills every table -- model.cpp OP_COEF2)
-        const bool noop = op.kind == OP_COEF2 && m->coef2_count > 1 && (int)i != m->coef2_first;
+        // ... and in a device-loop sampler call with the embedding table live the time MLP and the Dense_0 projections ran once, before the loop
+        const bool noop = (op.kind == OP_COEF2 && m->coef2_count > 1 && (int)i != m->coef2_first) ||
+                          (m->profile_temb_skipped && (op.kind == OP_TEMB || op.kind == OP_DENSE));
         if (!op.prep && !noop) MCVD_HIP_CHECK(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
         kinds[i] = (int)op.kind;
         ks[i] = op.kind == OP_CONV ? op.ks : 0;
@@ -930,7 +932,10 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
             ++draw;
         }
         started = true;
-        if (int rc = launch_fill_labels(m->labels, steps[i], B, s)) return rc;           // :283
+        // :283 (with the call's embedding table live nothing but a noise_in_cond net reads the labels: the fill is skipped)
+        const bool need_labels = !m->temb_row_live || m->d.noise_in_cond;
+        if (need_labels)
+            if (int rc = launch_fill_labels(m->labels, steps[i], B, s)) return rc;
         set_cond_gamma(steps[i]);
         if (m->temb_row_live)
             if (int rc = m->use_temb_row(fwd_no++, B)) return rc;
@@ -957,7 +962,8 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
         if (draws) ++draw;
     }
     if (flags & MCVD_FLAG_DENOISE) {                                                      // :331-333, label L-1 (sic)
-        if (int rc = launch_fill_labels(m->labels, L - 1, B, s)) return rc;
+        if (!m->temb_row_live || m->d.noise_in_cond)
+            if (int rc = launch_fill_labels(m->labels, L - 1, B, s)) return rc;
         set_cond_gamma(L - 1);
         if (m->temb_row_live)
             if (int rc = m->use_temb_row(fwd_no++, B)) return rc;

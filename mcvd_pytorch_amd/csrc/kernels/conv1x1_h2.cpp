@@ -169,9 +169,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
     // register sets with the reads behind the barrier (+5 %: the scheduler chains the MFMAs per accumulator), s_setprio around the MFMAs
     // (+3 %), three instead of two workgroups per CU (round 3: no gain).
     const int nchunks = Cin / CK;          // Cin % CK == 0 (launch check): the zero rows that pad the weights are never staged
-    // IM: the raw patch of this pixel tile and the K-row -> patch-offset table, through registers, IN FRONT of the weight DMAs (the compiler
-    // waits for these loads before it parks them; whatever it makes of the DMAs behind them is conservative).  The barrier of the first
-    // stage makes both visible.
+    Q1_DMA(0);
+    if (nchunks > 1) Q1_DMA(1);
+    if (nchunks > 2) Q1_DMA(2);
+    // IM: the raw patch of this pixel tile and the K-row -> patch-offset table, through registers, BEHIND the first weight DMAs so that the two
+    // latencies overlap (the compiler waits for the patch loads before it parks them; they are younger than the DMAs, so that wait covers
+    // the DMAs too and the counted waits of the first stages are trivially met).  The barrier of the first stage makes both visible.
     // Patch layout [Cc + 1 planes][PR = PT / W + 2 rows][PITCH = W + 8]: the W interior pixels of a row at columns 4 .. W + 3 (16-byte aligned:
     // float4 in, ds_write_b128 out), zero blocks at 0 .. 3 and W + 4 .. W + 7 -- a pixel tile is whole image rows, so the columns left and
     // right of the interior are ALWAYS outside the image; only the first / last patch row can be.  Plane Cc is all zeros (padding K rows).
@@ -214,9 +217,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h2_kernel(ConvArgs a, int ptil
         const int p = wave * 32 + l31;                              // the lane's pixel of the tile
         im_base = (p / im_W) * im_PITCH + (p % im_W);
     }
-    Q1_DMA(0);
-    if (nchunks > 1) Q1_DMA(1);
-    if (nchunks > 2) Q1_DMA(2);
     if (rec) tk1 = __builtin_amdgcn_s_memtime();
     /* chunk k becomes visible, chunk k + 3 is requested, the LDS reads of chunk k are issued: 8 pixel values, their coefficients, the
        NP * COT A operands */

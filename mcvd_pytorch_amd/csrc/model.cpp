@@ -1319,6 +1319,7 @@ int mcvd_model::forward_unchecked(const float* x, const void* lab, const float* 
             for (auto& e : ev) MCVD_HIP_CHECK(hipEventCreate(&e));
         }
         profile_B = B;
+        profile_temb_skipped = temb_row_live;
         for (size_t i = 0; i < ops.size(); ++i) {      // instrumented forward: everything on the main stream
             if (ops[i].prep) continue;
             MCVD_HIP_CHECK(hipEventRecord(ev[2 * i], ctx->stream));

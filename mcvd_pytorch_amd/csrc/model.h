@@ -274,6 +274,7 @@ struct mcvd_model {
     int64_t* temb_lab = nullptr;      // [rows]
     size_t temb_rows_cap = 0;
     int temb_row_live = 0;            // 1: OP_TEMB / OP_DENSE are skipped, ops[1].dst holds the row use_temb_row copied there
+    int profile_temb_skipped = 0;     // the instrumented forward mcvd_model_profile_read describes ran with temb_row_live
     int prepare_temb_table(const std::vector<int>& labels);
     int use_temb_row(int row, int B);
     int uniform_labels = 0;        // every row of the forward in flight carries the SAME label (the sampler loops): the time MLP and
