@@ -901,7 +901,8 @@ int mcvd_sampler_run(mcvd_model* m, int kind, float* x, const float* cond, const
             if (int rc = m->prepare_temb_table(fl)) return rc;
     }
     auto set_cond_gamma = [&](int label) {         // ncsnpp_more.py:761-765: k_cum[labels], theta_t[labels], alphas[labels]
-        if (!(gam && m->d.noise_in_cond)) return;
+        // (the NETWORK decides by its own config -- model.gamma -- whatever `gamma` the sampler was called with: a DDIM call, or gamma=False on a gamma net)
+        if (!(m->d.gamma && m->d.noise_in_cond && (int)m->k_cum.size() == T)) return;
         m->cond_gamma_k = m->k_cum[label];
         m->cond_gamma_theta = m->theta_t[label];
         m->cond_gamma_kt = m->k_cum[label] * m->theta_t[label];

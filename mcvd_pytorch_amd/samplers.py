@@ -70,11 +70,11 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
             same_noise=False, noise_val=None, frac_steps=None, verbose=False, log=False, clip_before=True, t_min=-1,
             gamma=False, noise=None, seed=None, sample_offset=0, cond_noise=None, **kwargs):
     net = _unwrap(scorenet)
-    if gamma:
-        if kind != _lib.SAMPLER_DDPM:
-            gamma = False                  # ddim_sampler accepts the kwarg and never reads it (models/__init__.py:102-203)
-        elif not getattr(net, "gamma", False):
-            raise AttributeError("'HipScoreNet' object has no attribute 'k_cum' (gamma=True needs a model.gamma net, models/__init__.py:224)")
+    if gamma and not getattr(net, "gamma", False):
+        raise AttributeError("'HipScoreNet' object has no attribute 'k_cum' (gamma=True needs a model.gamma net, models/__init__.py:224, :118)")
+    # ddim_sampler reads `gamma` in ONE place: the t_min re-noise of the first executed step draws a standardised Gamma variate (:144-151);
+    # it adds no step noise, so without t_min > 0 the kwarg changes nothing but the log prefix ("DDIM gamma")
+    gamma_device = gamma and kind == _lib.SAMPLER_DDPM
     net.sync_parameters(force=True)
     dev = net.device
     x = x_mod.to(device=dev, dtype=torch.float32).contiguous().clone()
@@ -86,7 +86,7 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
         noise = noise.to(device=dev, dtype=torch.float32).contiguous()
     if noise_val is not None:
         noise_val = noise_val.to(device=dev, dtype=torch.float32).contiguous()
-    name = ("DDPM gamma" if gamma else "DDPM") if kind == _lib.SAMPLER_DDPM else "DDIM"
+    name = ("DDPM" if kind == _lib.SAMPLER_DDPM else "DDIM") + (" gamma" if gamma else "")
     # The device loop hands raw pointers to the library, which sizes everything from the model description: check every
     # shape here (the same conditions HipScoreNet.__call__ enforces per forward), so a wrong-shaped tensor raises instead of
     # being read / written out of bounds.
@@ -128,9 +128,11 @@ def _sample(kind, x_mod, scorenet, cond=None, just_beta=False, final_only=False,
 
     _lib.check(_lib.lib.mcvd_ctx_clear_range(net._ctx), "clear_range")      # the f16x2 range verdict below is about THIS call's forwards
     fast = final_only and not verbose and not log and not same_noise and noise_val is None and frac_steps is None
+    if gamma and not gamma_device and t_min > 0 and n_exec > 0:
+        fast = False                   # DDIM with a gamma re-noise draw: the host loop (the device loop's gamma stream belongs to the DDPM sampler)
     if fast:
         flags = (_lib.FLAG_DENOISE if denoise else 0) | (_lib.FLAG_CLIP_BEFORE if clip_before else 0) \
-            | (_lib.FLAG_JUST_BETA if just_beta else 0) | (_lib.FLAG_GAMMA if gamma else 0)
+            | (_lib.FLAG_JUST_BETA if just_beta else 0) | (_lib.FLAG_GAMMA if gamma_device else 0)
         if seed is None and (noise is None or (nic and cond_noise is None)):
             seed = _draw_seed()
         with torch.cuda.device(dev):

@@ -482,6 +482,60 @@ def gen_f4():
     print("wrote tiny_allframes_err.pt:", msg[:100])
 
 
+def gen_gamma_ddim():
+    """Round 6: `ddim_sampler(..., gamma=True, t_min > 0)` on a model.gamma net -- the one place the DDIM sampler reads its `gamma` kwarg: the
+    re-noise of the first executed step draws a standardised Gamma variate instead of a normal one (models/__init__.py:144-151), and the runner
+    passes `gamma=config.model.gamma` to whichever sampler it bound (runners/ncsn_runner.py:1518).  Same deterministic stand-in for the Gamma
+    sampler as gen_f4 (the raw draws are recorded by call site: the sampler's own draw, and the noise_in_cond draws inside the network)."""
+    import models as ref_models
+    import torch.distributions.gamma as tdg
+    name, B = "tiny_gamma", 2
+    config = synth.make_config(name)
+    net = build_ref_net(config)
+    net.load_state_dict(synth.make_state_dict(config, seed=123), strict=False)
+    x, cond = synth.make_inputs(config, B, seed=0)
+    normals = torch.randn(24, *x.shape, generator=torch.Generator().manual_seed(92))
+    log_raw = []
+
+    class FakeGamma:
+        n = 0
+
+        def __init__(self, concentration, rate):
+            self.c, self.r = concentration, rate
+
+        def sample(self, shape=()):
+            c = self.c.expand(tuple(shape) + tuple(self.c.shape)) if len(shape) else self.c
+            r = self.r.expand(tuple(shape) + tuple(self.r.shape)) if len(shape) else self.r
+            g = c / r + c.sqrt() / r * normals[FakeGamma.n].reshape(c.shape)
+            site = "cond" if sys._getframe(1).f_code.co_filename.endswith("ncsnpp_more.py") else "step"
+            log_raw.append((site, g.clone()))
+            FakeGamma.n += 1
+            return g
+    o1, o2 = ref_models.Gamma, tdg.Gamma
+    ref_models.Gamma = FakeGamma
+    tdg.Gamma = FakeGamma
+    torch.distributions.gamma.Gamma = FakeGamma
+    try:
+        res = ref_models.ddim_sampler(x.clone(), net, cond=cond, final_only=True, denoise=True, subsample_steps=10, clip_before=True,
+                                      verbose=False, log=False, gamma=True, t_min=0.35)
+    finally:
+        ref_models.Gamma, tdg.Gamma = o1, o2
+        torch.distributions.gamma.Gamma = o2
+    steps10 = list(range(0, 1000, 100))
+    kept = [t for t in steps10 if not (t < 0.35 * len(steps10))]
+    step_raw = torch.stack([g for s_, g in log_raw if s_ == "step"])
+    conds = [g for s_, g in log_raw if s_ == "cond"]
+    labels = kept + [9]
+    assert len(step_raw) == 1 and len(conds) == len(labels), (len(step_raw), len(conds))
+    zc = []
+    for g, lab in zip(conds, labels):                                  # standardised as ncsnpp_more.py:761-765 does
+        k, th, a = net.k_cum[lab], net.theta_t[lab], net.alphas[lab]
+        zc.append((g - k * th) / (1 - a).sqrt())
+    torch.save(dict(config_name=name, batch=B, sampler_tmin=res.clone(), step_raw_tmin=step_raw, cond_z_tmin=torch.stack(zc),
+                    k_cum=net.k_cum.clone(), theta_t=net.theta_t.clone()), os.path.join(OUT, "tiny_gamma_ddim_b2.pt"))
+    print(f"wrote tiny_gamma_ddim_b2.pt  range [{res.min():.3f}, {res.max():.3f}]  draws: {len(step_raw)} step + {len(conds)} cond")
+
+
 def gen_init_moments():
     """Round 5: per-parameter moments of the REAL reference's construction-time initialisation
     (`UNetMore_DDPM(config)` untouched: models/better/layers.py:43-80 `default_init`, torch defaults elsewhere), for
@@ -665,6 +719,8 @@ def main_round2():
         gen_model_case("tiny", 3, [("ddpm", 10, {}), ("ddim", 10, {}), ("ddpm", 10, dict(t_min=0.35))])
     if "surface" in which:        # round 6: the un-subsampled schedule and the untested kwargs of the kept sampler surface
         gen_sampler_surface("tiny", 2)
+    if "gamma_ddim" in which:
+        gen_gamma_ddim()
     if "surface_add" in which:
         gen_sampler_surface("tiny", 2, only_missing=True)
     if "cfg4full" in which:       # round 6: BASELINE config 4 over its full 1000-step schedule

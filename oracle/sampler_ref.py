@@ -47,7 +47,7 @@ def sample(x_mod, scorenet, cond=None, kind="ddpm", just_beta=False, final_only=
         noise_fn = lambda i, like: torch.randn_like(like)
     steps, alphas, alphas_prev, betas = subsampled_schedule(
         scorenet.alphas, scorenet.alphas_prev, scorenet.betas, subsample_steps)
-    gamma = gamma and kind == "ddpm"
+    # (ddim_sampler reads `gamma` too -- for the t_min re-noise draw only, :144-151; it adds no step noise)
     if gamma:
         ks_cum, thetas = scorenet.k_cum, scorenet.theta_t
         if subsample_steps is not None and subsample_steps < len(scorenet.alphas):

@@ -264,3 +264,32 @@ def test_time_embedding_table_of_a_sampler_call_is_bit_identical(cfg, B, kind, k
     net.set_option("temb_table", 0)
     b = net(x.cuda(), t, cond=cond.cuda()).clone()
     assert torch.equal(a, b)
+
+
+def test_ddim_gamma_renoise_vs_reference_golden(golden_dir, capsys):
+    """`ddim_sampler(gamma=True, t_min > 0)` on a model.gamma net: the re-noise draw of the first executed step is a standardised Gamma variate
+    (models/__init__.py:144-151; the runner passes `gamma=config.model.gamma` to whichever sampler it bound, ncsn_runner.py:1518).  The
+    reference run's raw draws replayed (fixture from the REAL sampler); without t_min the kwarg changes nothing but the log prefix, and the
+    whole loop stays on the device."""
+    from mcvd_pytorch_amd.samplers import ddim_sampler
+    g = torch.load(os.path.join(golden_dir, "tiny_gamma_ddim_b2.pt"), weights_only=False)
+    config, sd, net = _net(g["config_name"])
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    for fo in (True, False):
+        with _RunSpy() as spy:
+            out = ddim_sampler(x.cuda(), net, cond=cond.cuda(), final_only=fo, subsample_steps=10, gamma=True, t_min=0.35, verbose=False, log=False,
+                               noise=g["step_raw_tmin"].cuda(), cond_noise=g["cond_z_tmin"].cuda())
+        assert not spy.calls                                   # a gamma re-noise draw: the host loop
+        err = (out[-1:].cpu() - g["sampler_tmin"]).abs().max().item()
+        assert err <= 3e-4, err                                # (the gate of the DDPM gamma fixture: test_gamma_sampler_vs_reference_golden has the reasons)
+    # no t_min: no draw at all -- device loop, same frames as gamma=False, log prefix "DDIM gamma"
+    cz = g["cond_z_tmin"]
+    cz11 = torch.cat([cz, cz[:1]], dim=0).cuda()               # 11 forwards without t_min
+    with _RunSpy() as spy:
+        a = ddim_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10, gamma=True, verbose=False, log=False, cond_noise=cz11)
+        b = ddim_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10, gamma=False, verbose=False, log=False, cond_noise=cz11)
+    assert len(spy.calls) == 2 and torch.equal(a, b)
+    capsys.readouterr()
+    ddim_sampler(x.cuda(), net, cond=cond.cuda(), final_only=True, subsample_steps=10, gamma=True, verbose=True, log=False, cond_noise=cz11)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("DDIM")]
+    assert len(lines) == 10 and all(ln.startswith("DDIM gamma: ") for ln in lines)

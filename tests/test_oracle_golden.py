@@ -374,3 +374,24 @@ def test_full_schedule_uses_the_table_betas(golden_dir):
     assert not torch.equal(recomputed, net.betas)
     steps, al, alp, be = sampler_ref.subsampled_schedule(net.alphas, net.alphas_prev, net.betas, 999)   # skip 1, but the branch IS taken
     assert len(steps) == 1000 and torch.equal(be, recomputed)
+
+
+def test_ddim_gamma_renoise_matches_reference(golden_dir):
+    """`ddim_sampler(..., gamma=True, t_min=0.35)` on a model.gamma + noise_in_cond net (models/__init__.py:118, :144-151): the one place the
+    DDIM sampler reads `gamma` is the re-noise draw of the first executed step; the raw Gamma draws of the reference run are replayed."""
+    g = load(golden_dir, "tiny_gamma_ddim_b2.pt")
+    config = synth.make_config(g["config_name"])
+    net = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123))
+    x, cond = synth.make_inputs(config, g["batch"], seed=0)
+    net.cond_noise_fn, kc = _seq(g["cond_z_tmin"])
+    fn, k = _seq(g["step_raw_tmin"])
+    out = sampler_ref.sample(x.clone(), net, cond=cond, kind="ddim", final_only=True, denoise=True, subsample_steps=10, noise_fn=fn, gamma=True,
+                             t_min=0.35)
+    assert k[0] == 1 and kc[0] == len(g["cond_z_tmin"]) == 10
+    assert (out - g["sampler_tmin"]).abs().max().item() <= 3e-4
+    # without the kwarg the re-noise draw would be a normal one: the gamma draw is what the fixture holds
+    fn2, _ = _seq(g["step_raw_tmin"])
+    net.cond_noise_fn, _ = _seq(g["cond_z_tmin"])
+    other = sampler_ref.sample(x.clone(), net, cond=cond, kind="ddim", final_only=True, denoise=True, subsample_steps=10, noise_fn=fn2, gamma=False,
+                               t_min=0.35)
+    assert (other - g["sampler_tmin"]).abs().max().item() > 1e-2
