@@ -587,9 +587,10 @@ def main():
         print(json.dumps(res), flush=True)
         if not res["valid"]:
             print("bench.py: INVALID RUN -- " + res["invalid_reason"], file=sys.stderr, flush=True)
-            if world > 1:
-                dist.destroy_process_group()
-            raise SystemExit(3)
+            if bad:                          # wrong frames: a failed run (exit code 3).  A straggler GPU marks the line valid: false but the
+                if world > 1:                # measurement itself is sound -- the line is printed and the process ends normally
+                    dist.destroy_process_group()
+                raise SystemExit(3)
     if world > 1:
         dist.destroy_process_group()
 
