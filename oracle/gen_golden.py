@@ -581,6 +581,10 @@ SURFACE_CASES = [
     ("ddpm_100_tmin0.1", "ddpm", dict(subsample_steps=100, t_min=0.1), 100),
     ("ddim_100_tmin0.3", "ddim", dict(subsample_steps=100, t_min=0.3), 2),
     ("ddpm_full1000_tmin0.998", "ddpm", dict(subsample_steps=1000, t_min=0.998), 3),
+    # subsample_steps that does not divide the table length: skip = 1000 // 7 = 142 -> EIGHT steps (0, 142, ..., 994), labels into the full table
+    ("ddpm_7", "ddpm", dict(subsample_steps=7), 9),
+    ("ddim_7", "ddim", dict(subsample_steps=7), 1),
+    ("ddpm_7_images_tmin", "ddpm", dict(subsample_steps=7, final_only=False, t_min=0.2), 9),     # skipped steps leave no image (:269-270 precede :292)
 ]
 
 

@@ -303,7 +303,7 @@ SURFACE_KEYS = [
     "ddpm_fullNone_tmin0.95", "ddpm_10_just_beta", "ddpm_tail_just_beta", "ddpm_10_same_noise", "ddpm_10_same_noise_val",
     "ddpm_10_noise_val_ignored", "ddpm_10_same_noise_tmin", "ddpm_frac0.2", "ddpm_frac0.1_tmin0.5", "ddpm_10_nodenoise",
     "ddim_10_nodenoise", "ddpm_10_noclip", "ddim_10_noclip", "ddpm_10_images", "ddim_10_images", "ddpm_10_images_nodenoise",
-    "ddpm_100_tmin0.1", "ddim_100_tmin0.3", "ddpm_full1000_tmin0.998",
+    "ddpm_100_tmin0.1", "ddim_100_tmin0.3", "ddpm_full1000_tmin0.998", "ddpm_7", "ddim_7", "ddpm_7_images_tmin",
 ]
 
 
@@ -332,15 +332,26 @@ def surface_case(golden_dir, key):
 def add_back_step_noise(images, kind, kw, noise, alphas_full, alphas_prev_full, betas_full):
     """`final_only=False` images with accelerator semantics (pre-noise copies) -> what a CPU run of the reference returns, where
     `x_mod.to('cpu')` aliases x_mod and the in-place `x_mod += c * noise` (models/__init__.py:326-328) shows through: image i of a DDPM
-    run gains the step's noise term for every step but the last (DDIM adds no noise; the denoise image is a new tensor)."""
+    run gains the step's noise term for every executed step but the last (DDIM adds no noise; the denoise image is a new tensor).  Steps the
+    t_min test skips (:269-270) leave no image; the re-noise of the first executed step consumes one draw (:272-279)."""
     if kind != "ddpm":
         return images
     steps, al, alp, be = sampler_ref.subsampled_schedule(alphas_full, alphas_prev_full, betas_full, kw["subsample_steps"])
+    t_min = kw.get("t_min", -1)
     out = images.clone()
     L = len(steps)
-    for i in range(L - 1):
-        cn = be[i].sqrt() if kw.get("just_beta", False) else ((1 - alp[i]) / (1 - al[i]) * be[i]).sqrt()
-        out[i] = out[i] + cn * noise[i]
+    img, draw, started = 0, 0, False
+    for i, step in enumerate(steps):
+        if step < t_min * len(al):
+            continue
+        if not started and t_min > 0:
+            draw += 1
+        started = True
+        if i + 1 != L:
+            cn = be[i].sqrt() if kw.get("just_beta", False) else ((1 - alp[i]) / (1 - al[i]) * be[i]).sqrt()
+            out[img] = out[img] + cn * noise[draw]
+            draw += 1
+        img += 1
     return out
 
 
