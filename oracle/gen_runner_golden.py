@@ -100,10 +100,14 @@ def runner_config(name, batch, nfp, subsample, version="DDPM"):
     return config
 
 
-def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny_runner_videogen"):
+def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny_runner_videogen", overrides=None):
+    """overrides: `sampling.*` switches of the block loop (init_prev_t: blocks restart from the previous block's frames and the sampler re-noises
+    them, :1513 + models/__init__.py:269-280; one_frame_at_a_time: one frame kept per block, :1501-1504, :1530-1531)."""
     R = import_real_runner()
     import models as ref_models
     config = runner_config(name, batch, nfp, subsample)
+    for k_, v_ in (overrides or {}).items():
+        setattr(config.sampling, k_, v_)
     C, nf, nc, S = config.data.channels, config.data.num_frames, config.data.num_frames_cond, config.data.image_size
     T = nc + nfp
     g = torch.Generator().manual_seed(31)
@@ -120,13 +124,17 @@ def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny
     bound = runner.get_sampler()                                              # :2702-2714
     assert bound.func is ref_models.ddpm_sampler and bound.keywords == {"config": config}
 
-    n_blocks = -(-nfp // nf)
+    n_blocks = nfp if getattr(config.sampling, "one_frame_at_a_time", False) else -(-nfp // nf)
+    t_min = getattr(config.sampling, "init_prev_t", -1)
+    # draws of one ddpm_sampler call: L - 1 step draws of the executed steps but the last, + 1 for the t_min re-noise (:272-279).  With
+    # subsample 10 the t_min test `step < t_min * 10` (:269) skips step 0 only (steps are 0, 100, ...): 8 + 1 = 9 draws, as without t_min.
+    per_call = (subsample - 1) if t_min <= 0 else (subsample - 2) + 1
     step_noise = torch.randn(n_blocks, subsample + 1, batch, C * nf, S, S, generator=torch.Generator().manual_seed(77))
     rec = dict(z=[], sampler_kwargs=[], real_t=None, cf=None)
     k = [0]
 
     def randn_like(like, *a, **kw):                                           # the sampler's step draws, in call order across the blocks
-        blk, i = divmod(k[0], subsample - 1)                                  # L - 1 draws per ddpm_sampler call
+        blk, i = divmod(k[0], per_call)
         k[0] += 1
         z = step_noise[blk, i].to(like)
         assert z.shape == like.shape
@@ -189,31 +197,35 @@ def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny
             raise RuntimeError("video_gen returned before :1570")
         except _Cut:
             pass
-    assert len(rec["z"]) == n_blocks and len(sampler_calls) == n_blocks and k[0] == n_blocks * (subsample - 1), (len(rec["z"]), k[0])
+    assert len(rec["z"]) == n_blocks and len(sampler_calls) == n_blocks and k[0] == n_blocks * per_call, (len(rec["z"]), k[0])
     real_t = rec["real_t"]
     # which dataset rows the shuffling loader served (clips are distinct): row r of the batch is clip order[r]
     order = [int(((real_dt(config, clips) - real_t[r]).flatten(1).abs().max(dim=1).values).argmin()) for r in range(batch)]
     real, cond, cond_mask = rec["cf"]
     log_lines = [ln for ln in printed.getvalue().splitlines() if ln.startswith("DDPM: ")]      # the sampler's `verbose` lines (:304-306)
-    assert len(log_lines) == n_blocks * 10
+    assert len(log_lines) == n_blocks * (10 if t_min <= 0 else 9)
     # the same chain in float64 on the restatement (same inits, same noise): the noise floor a tolerance on pred_raw stands on
     from oracle import sampler_ref, unet_ref
     net64 = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123), dtype=torch.float64)
     cond64, preds64 = cond.double(), []
+    one_at = bool(getattr(config.sampling, "one_frame_at_a_time", False))
+    g64 = None
     for b in range(n_blocks):
         kk = [0]
 
         def fn(i, like, b=b, kk=kk):
             kk[0] += 1
             return step_noise[b, kk[0] - 1].to(like.dtype)
-        g64 = sampler_ref.sample(rec["z"][b].double(), net64, cond=cond64, kind="ddpm", final_only=True, denoise=True, subsample_steps=subsample,
-                                 clip_before=True, noise_fn=fn)[-1]
+        x_in = rec["z"][b].double() if (b == 0 or t_min <= 0) else g64
+        g64 = sampler_ref.sample(x_in, net64, cond=cond64, kind="ddpm", final_only=True, denoise=True, subsample_steps=subsample,
+                                 clip_before=True, noise_fn=fn, t_min=t_min)[-1]
         preds64.append(g64)
         if b != n_blocks - 1:
-            cond64 = torch.cat([cond64[:, C * nf:], g64[:, C * max(0, nf - nc):]], dim=1)
+            cond64 = torch.cat([cond64[:, C:], g64[:, :C]], dim=1) if one_at else \
+                torch.cat([cond64[:, C * nf:], g64[:, C * max(0, nf - nc):]], dim=1)
     drift = float((rec["pred_raw"].double() - torch.cat(preds64, dim=1)[:, :C * nfp]).abs().max())
     print(f"  reference fp32 vs fp64 restatement of the {n_blocks}-block chain: {drift:.3e}")
-    out = dict(log_lines=log_lines, ref32_vs_ref64_max_abs=drift, config_name=name, batch=batch, nfp=nfp, subsample=subsample, clips=clips, order=order, real_t=real_t, real=real, cond=cond,
+    out = dict(log_lines=log_lines, ref32_vs_ref64_max_abs=drift, overrides=dict(overrides or {}), config_name=name, batch=batch, nfp=nfp, subsample=subsample, clips=clips, order=order, real_t=real_t, real=real, cond=cond,
                cond_mask=cond_mask, z_init=torch.stack(rec["z"]), step_noise=step_noise, pred_raw=rec["pred_raw"], pred01=rec["pred01"],
                real01=rec["real01"], cond01=rec["cond01"], sampler_kwargs=sampler_calls,
                stood_in=sorted(ABSENT))
@@ -225,4 +237,10 @@ def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny
 
 if __name__ == "__main__":
     torch.set_num_threads(2)
-    gen_videogen()
+    which = sys.argv[1:] or ["default", "prevt", "oneframe"]
+    if "default" in which:
+        gen_videogen()
+    if "prevt" in which:
+        gen_videogen(tag="tiny_runner_videogen_prevt", overrides=dict(init_prev_t=0.5))
+    if "oneframe" in which:
+        gen_videogen(nfp=3, tag="tiny_runner_videogen_oneframe", overrides=dict(one_frame_at_a_time=True))

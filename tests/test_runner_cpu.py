@@ -99,23 +99,34 @@ def test_save_video_pred_format(tmp_path):
 
 
 # ------------------------------------------------------------------ round 6: fixtures from the REAL NCSNRunner.video_gen
-def _runner_fixture(golden_dir):
+RUNNER_FIXTURES = ["tiny_runner_videogen.pt",               # prediction, three blocks of two frames cropped to five
+                   "tiny_runner_videogen_prevt.pt",         # sampling.init_prev_t = 0.5: blocks restart from the previous block's frames, re-noised
+                   "tiny_runner_videogen_oneframe.pt"]      # sampling.one_frame_at_a_time: cond shifts by one frame per block
+
+
+def _runner_fixture(golden_dir, name="tiny_runner_videogen.pt"):
     import os
-    return torch.load(os.path.join(golden_dir, "tiny_runner_videogen.pt"), weights_only=False)
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
 
 
 def _runner_config(g):
     cfg = synth.make_config(g["config_name"])
     cfg.sampling.num_frames_pred, cfg.sampling.subsample = g["nfp"], g["subsample"]
+    for k, v in g.get("overrides", {}).items():
+        setattr(cfg.sampling, k, v)
     return cfg
 
 
-def test_glue_matches_the_real_runner(golden_dir):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("fx", RUNNER_FIXTURES)
+def test_glue_matches_the_real_runner(golden_dir, fx):
     """data_transform / conditioning_fn / inverse_data_transform of mcvd_pytorch_amd.runner against what the REAL
     `runners.ncsn_runner.NCSNRunner.video_gen` computed on the same clips (oracle/gen_runner_golden.py: the real module, imported with
     stand-ins for the absent third-party packages, driven through :1304-1570): bit for bit -- these are pure index / affine maps."""
     r = _runner()
-    g = _runner_fixture(golden_dir)
+    g = _runner_fixture(golden_dir, fx)
     cfg = _runner_config(g)
     batch = g["clips"][g["order"]]                                       # the rows the shuffling DataLoader served
     real_t = r.data_transform(cfg, batch)
@@ -129,17 +140,19 @@ def test_glue_matches_the_real_runner(golden_dir):
     # what the runner hands the sampler (:1513-1520): exactly the kwargs the mirror's block loop passes on
     kw = g["sampler_kwargs"][0]
     assert kw == dict(cond_mask=None, n_steps_each=0, step_lr=0.0, verbose=True, final_only=True, denoise=True, subsample_steps=g["subsample"],
-                      clip_before=True, t_min=-1.0, log=True, gamma=False)
+                      clip_before=True, t_min=float(g.get("overrides", {}).get("init_prev_t", -1.0)), log=True, gamma=False)
 
 
-def test_block_loop_matches_the_real_runner(golden_dir):
+@pytest.mark.parametrize("fx", RUNNER_FIXTURES)
+def test_block_loop_matches_the_real_runner(golden_dir, fx):
     """The mirror's autoregressive block loop (runner.video_gen) around the CPU oracle net and the oracle sampler, fed the REAL runner's
     block inits and step noise: the frames `NCSNRunner.video_gen` had assembled at :1569 (3 blocks of 2 frames cropped to 5: cond shift
     :1532-1535, crop :1569)."""
     from oracle import sampler_ref, unet_ref
     r = _runner()
-    g = _runner_fixture(golden_dir)
+    g = _runner_fixture(golden_dir, fx)
     cfg = _runner_config(g)
+    t_min = float(g.get("overrides", {}).get("init_prev_t", -1.0))
     net = unet_ref.OracleScoreNet(cfg, synth.make_state_dict(cfg, seed=123))
     net.device = torch.device("cpu")
     blk = [0]
@@ -152,7 +165,7 @@ def test_block_loop_matches_the_real_runner(golden_dir):
         def fn(i, like):
             k[0] += 1
             return g["step_noise"][b, k[0] - 1]
-        assert kw["final_only"] and kw["denoise"] and kw["subsample_steps"] == g["subsample"] and kw["clip_before"] and kw["t_min"] == -1.0
+        assert kw["final_only"] and kw["denoise"] and kw["subsample_steps"] == g["subsample"] and kw["clip_before"] and kw["t_min"] == t_min
         return sampler_ref.sample(x, scorenet, cond=cond, kind="ddpm", final_only=True, denoise=True, subsample_steps=kw["subsample_steps"],
                                   clip_before=True, t_min=kw["t_min"], noise_fn=fn)
     pred = r.video_gen(cfg, net, g["cond"], num_frames_pred=g["nfp"], sampler=sampler, init_noise_fn=lambda i, shp, dev: g["z_init"][i])
