@@ -8,6 +8,19 @@
 
 namespace mcvd {
 
+// x * a + b as ONE scalar-lane fused multiply-add, never packed.  Over a float4 with (a, b) in a register pair hipcc writes
+//     v_pk_fma_f32 vD, vX, v[n:n+1], v[n:n+1] op_sel:[0,0,1] op_sel_hi:[1,0,1]
+// and on gfx950 that form -- ONE VGPR pair read as src1 and src2 -- returns x * a + 0 in its low half for one 16-lane pass while a wave of
+// ANOTHER kernel on the same SIMD executes a matrix instruction with 128-bit operands (v_mfma_f32_32x32x16_bf16 / _f16,
+// v_mfma_f32_16x16x32_bf16): the "co-residency corruption" of rounds 4-6 (profiles/r06_coresident_cause.txt; 60-line reproducer
+// tools/repro_pk_fma_beside_mfma.cpp).  Same rounding as the packed form (both fused).  tools/check_vop3p_dual_read.py fails the build if
+// any kernel of the library contains the form.
+__device__ __forceinline__ float fma_unpacked(float x, float a, float b) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(a), "v"(b));
+    return r;
+}
+
 void set_error(const char* fmt, ...);
 const char* get_error();
 

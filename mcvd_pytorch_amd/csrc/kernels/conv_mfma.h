@@ -19,6 +19,9 @@
 // transform is applied on the way from registers to LDS.
 #pragma once
 #include "../common.h"
+#ifdef MCVD_DIAG_LDS_PAD
+#include <stdlib.h>
+#endif
 
 namespace mcvd {
 
@@ -160,6 +163,11 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
             }                                                                                                        \
         }                                                                                                            \
     }
+#ifdef MCVD_DIAG_COEF_BRANCH      /* diagnostic builds: keep `if (a.coef)` a branch (hipcc turns it into v_cndmask under an SGPR mask) */
+#define MCVD_DIAG_BRANCH_HERE asm volatile("" ::: "memory");
+#else
+#define MCVD_DIAG_BRANCH_HERE
+#endif
 #define MCVD_WRITE_CHUNK(ch)                                                                                         \
     {                                                                                                                \
         const int cbase = (ch) * CK;                                                                                 \
@@ -178,8 +186,9 @@ __global__ __launch_bounds__(256, (COT * PXT >= 8 || (COT * PXT >= 6 && !SPLIT &
                 const bool live = (a_cb[s] & 1) && (cbase + (a_cb[s] >> 16) < Cin);                                  \
                 if (live) {                                                                                          \
                     if (a.coef) {                                                                                    \
-                        v.x = v.x * rc[s].x + rc[s].y; v.y = v.y * rc[s].x + rc[s].y;                                \
-                        v.z = v.z * rc[s].x + rc[s].y; v.w = v.w * rc[s].x + rc[s].y;                                \
+                        MCVD_DIAG_BRANCH_HERE                                                                        \
+                        v.x = fma_unpacked(v.x, rc[s].x, rc[s].y); v.y = fma_unpacked(v.y, rc[s].x, rc[s].y);        \
+                        v.z = fma_unpacked(v.z, rc[s].x, rc[s].y); v.w = fma_unpacked(v.w, rc[s].x, rc[s].y);        \
                     }                                                                                                \
                     if (a.act) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }       \
                 } else {                                                                                             \
@@ -479,6 +488,9 @@ int conv_mfma_launch(const ConvArgs& a, hipStream_t s) {
     constexpr bool WDB = WDMA && (Cfg::WDB || WDBF);
     size_t lds = (size_t)(CK * g.PS + (WDB ? 2 : 1) * Cfg::WSZ) * sizeof(float);
     if (SPLIT && lds < 3 * 1024 * sizeof(float)) lds = 3 * 1024 * sizeof(float);
+#ifdef MCVD_DIAG_LDS_PAD      // diagnostic builds only (tools/build_variant.sh): ask for more LDS than the kernel uses (co-residency experiments)
+    if (const char* pad = getenv("MCVD_DIAG_LDS_PAD")) lds += (size_t)atoi(pad);
+#endif
     MCVD_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu > 160KiB", lds);
     if (lds > 64 * 1024) {      // above the default dynamic-LDS limit: opt in once per instantiation
         static PerDeviceOnce raised;

@@ -506,10 +506,10 @@ __global__ __launch_bounds__(256) void spade_apply_kernel(SpadeArgs a) {
         float sA = 1.f, sB = 0.f;
         if (a.coef2) { sA = a.coef2[bc * 2]; sB = a.coef2[bc * 2 + 1]; }
         float4 o;
-        o.x = silu1(((v.x * cA + cB) * (1.0f + g.x) + be.x) * sA + sB);
-        o.y = silu1(((v.y * cA + cB) * (1.0f + g.y) + be.y) * sA + sB);
-        o.z = silu1(((v.z * cA + cB) * (1.0f + g.z) + be.z) * sA + sB);
-        o.w = silu1(((v.w * cA + cB) * (1.0f + g.w) + be.w) * sA + sB);
+        o.x = silu1(fma_unpacked(fma_unpacked(v.x, cA, cB) * (1.0f + g.x) + be.x, sA, sB));
+        o.y = silu1(fma_unpacked(fma_unpacked(v.y, cA, cB) * (1.0f + g.y) + be.y, sA, sB));
+        o.z = silu1(fma_unpacked(fma_unpacked(v.z, cA, cB) * (1.0f + g.z) + be.z, sA, sB));
+        o.w = silu1(fma_unpacked(fma_unpacked(v.w, cA, cB) * (1.0f + g.w) + be.w, sA, sB));
         reinterpret_cast<float4*>(a.y + bc * a.HW)[p4] = o;
     }
 }

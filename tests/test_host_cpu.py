@@ -147,6 +147,25 @@ def test_winograd_isa_checker_flags_violations():
     assert any("LDS-DMA" in p for p in c.check(head + spade_loop + others) if "ILi1ELi0ELb0" in p)   # ... and rejected elsewhere
 
 
+def test_no_kernel_of_the_library_holds_the_gfx950_coresidency_erratum_form():
+    """tools/check_vop3p_dual_read.py (run by every build after the link): a packed-fp32 instruction that reads ONE VGPR pair as src1 and src2
+    loses its low addend on gfx950 beside another kernel's 128-bit-operand MFMA (profiles/r06_coresident_cause.txt).  The scanner flags exactly
+    that form; the built library's 22 code objects hold none."""
+    import os
+    from tools import check_vop3p_dual_read as c
+    text = ("0000000000001900 <_ZN4mcvd1kE>:\n"
+            "\tv_pk_fma_f32 v[4:5], v[100:101], v[138:139], v[138:139] op_sel:[0,0,1] op_sel_hi:[1,0,1]// 000000001900: D3B06004 0E2B1564\n"
+            "\tv_pk_fma_f32 v[66:67], v[78:79], v[50:51], v[78:79] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n"          # src0 == src2: measured clean
+            "\tv_pk_fma_f32 v[4:5], v[100:101], v[138:139], v[142:143] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n"      # the addend from a copy: measured clean
+            "\tv_pk_add_f32 v[4:5], v[100:101], v[100:101] op_sel:[0,1] op_sel_hi:[1,0]\n"                      # two operands only: measured clean
+            "\tv_pk_mul_f32 v[2:3], v[2:3], v[22:23]\n")
+    hits = c.scan(text)
+    assert len(hits) == 1 and hits[0][0] == "_ZN4mcvd1kE" and hits[0][1].startswith("v_pk_fma_f32 v[4:5], v[100:101], v[138:139], v[138:139]")
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mcvd_pytorch_amd", "libmcvd_hip.so")
+    assert os.path.exists(lib), "build first (__graft_entry__.build())"
+    assert c.main(["check", lib]) == 0
+
+
 def test_product_never_touches_the_oracle():
     """The oracle is test infrastructure: nothing under mcvd_pytorch_amd/ (Python or native sources) may import, open or link it,
     and outside the package only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do."""

@@ -21,6 +21,7 @@
 //   (mcvd_op_attention, option naive_attn = 4) and the victim that still breaks today, the direct 3x3 conv (mcvd_op_conv2d, 96 -> 96 at 64 x 64 behind
 //   a GroupNorm + SiLU prologue, option conv_shape = 0: conv_mfma_kernel) -- every (aggressor, victim) pair of {stand-alone, library} is run.
 #include <dlfcn.h>
+#include <math.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -86,8 +87,105 @@ typedef int (*set_option_t)(void*, const char*, int);
 typedef int (*op_attention_t)(void*, const float*, float*, int, int, int, int);
 typedef int (*op_conv2d_t)(void*, const float*, int, const float*, int, const float*, const float*, int, int, const float*, int, const float*, float, float*, int, int, int);
 
+// DUMP=n: where the first n bad launches of the library victim differ from the clean result -- which images, rows, columns and output channels,
+// and what the wrong values look like (zero? the clean value of another place? off by how much?)
+static std::vector<float> g_hx, g_hw;      // the library victim's input [3][96][64][64] and weights [96][96][ks][ks] (host copies)
+static int g_act = 1, g_coef = 1, g_ks = 3;
+static float g_A = 1.0f, g_B = 1.0f;      // VICTIM_AB="A B": the affine of the victim's prologue (the same for every channel)
+static float silu_of(float v) { return g_act ? v / (1.0f + expf(-v)) : v; }
+static float act_of(float v) { if (g_coef) v = v * g_A + g_B; return silu_of(v); }
+
+// WHAT was wrong in the staged input?  The differences of a bad launch are whole image rows x all output channels x three of every four
+// columns: the signature of ONE input value per float4 of one staged row being wrong (its column c feeds the outputs c-1, c, c+1).  At an
+// output column c of the residue that all three taps see only through the centre tap, diff[co] = w[co][ci][ty][1] * delta for the culprit
+// (ci, ty): project on every candidate, report the best, and look the wrong staged value up among the values the kernel handles.
+static void analyze(const std::vector<float>& y, const std::vector<float>& r, int b, int row, int C, int H, int W) {
+    if (g_ks != 3 || g_hx.empty()) return;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int x = 0; x < W; ++x) { bool d = false; for (int c = 0; c < C && !d; ++c) { const long i = (((long)b * C + c) * H + row) * W + x; d = memcmp(&y[i], &r[i], 4) != 0; } cnt[x & 3] += d; }
+    int k = -1;      // the residue of the wrong INPUT columns: its neighbours k-1, k+1 differ too, k+2 does not
+    for (int q = 0; q < 4; ++q) if (cnt[q] && cnt[(q + 1) & 3] && cnt[(q + 3) & 3] && !cnt[(q + 2) & 3]) k = q;
+    printf("      analysis of row %d:%d: differing columns by residue mod 4 = %d %d %d %d -> wrong input columns = %d mod 4\n", b, row, cnt[0], cnt[1], cnt[2], cnt[3], k);
+    if (k < 0) return;
+    for (int x = k + 4; x < W; x += 20) {
+        std::vector<double> d(C);
+        double dd = 0;
+        for (int c = 0; c < C; ++c) { const long i = (((long)b * C + c) * H + row) * W + x; d[c] = (double)y[i] - (double)r[i]; dd += d[c] * d[c]; }
+        double best = 1e30, balpha = 0; int bci = -1, bty = -1;
+        for (int ci = 0; ci < 96; ++ci) for (int ty = 0; ty < 3; ++ty) {
+            double ww = 0, dw = 0;
+            for (int c = 0; c < C; ++c) { const double w = g_hw[(((long)c * 96 + ci) * 3 + ty) * 3 + 1]; ww += w * w; dw += w * d[c]; }
+            const double alpha = dw / ww, res = dd - alpha * dw;
+            if (res < best) { best = res; balpha = alpha; bci = ci; bty = ty; }
+        }
+        const int rin = row + bty - 1;
+        printf("        column %2d: input channel %2d, tap row %d (input row %d), delta %+.6f, unexplained %.2e of %.2e", x, bci, bty, rin, balpha, best, dd);
+        if (rin < 0 || rin >= H) { printf("  (padding row)\n"); continue; }
+        const float raw = g_hx[(((long)b * 96 + bci) * H + rin) * W + x], clean = act_of(raw), got = clean + (float)balpha;
+        printf("; staged value clean %.6f (raw %.6f) -> got %.6f;", clean, raw, got);
+        // candidates: the same position in another channel (a stale staging register holds the previous / next chunk's value), the raw value, zero
+        int shown = 0;
+        if (fabsf(silu_of(raw) - got) < 2e-5f) { printf(" = f(x): the affine had NO effect;"); ++shown; }
+        if (fabsf(silu_of(raw * g_A) - got) < 2e-5f && g_B != 0.0f) { printf(" = f(A x): B was lost;"); ++shown; }
+        if (fabsf(silu_of(raw + g_B) - got) < 2e-5f && g_A != 1.0f) { printf(" = f(x + B): A was lost;"); ++shown; }
+        if (fabsf(silu_of(raw * g_A + g_A) - got) < 2e-5f && g_A != g_B) { printf(" = f(A x + A): op_sel of the addend lost;"); ++shown; }
+        if (fabsf(silu_of(raw * g_B + g_B) - got) < 2e-5f && g_A != g_B) { printf(" = f(B x + B): op_sel of the factor wrong;"); ++shown; }
+        for (int cj = 0; cj < 96 && shown < 4; ++cj) {
+            const float rj = g_hx[(((long)b * 96 + cj) * H + rin) * W + x];
+            if (fabsf(act_of(rj) - got) < 2e-4f) { printf(" = staged value of channel %d at the same place;", cj); ++shown; }
+            if (fabsf(rj - got) < 2e-4f) { printf(" = RAW value of channel %d at the same place;", cj); ++shown; }
+        }
+        for (int bj = 0; bj < 3 && shown < 4; ++bj) for (int rj = 0; rj < H && shown < 4; ++rj) {
+            if (bj == b && rj == rin) continue;
+            const float v = g_hx[(((long)bj * 96 + bci) * H + rj) * W + x];
+            if (fabsf(act_of(v) - got) < 2e-5f) { printf(" = staged value of the same channel at image %d row %d;", bj, rj); ++shown; }
+        }
+        if (fabsf(got) < 2e-4f) printf(" = 0;");
+        if (!shown) printf(" no match among the candidates;");
+        printf("\n");
+    }
+}
+
+static void dump_diff(const float* dy, const float* dref, int B, int C, int H, int W) {
+    const long n = (long)B * C * H * W;
+    std::vector<float> y(n), r(n);
+    CK(hipMemcpy(y.data(), dy, n * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(r.data(), dref, n * 4, hipMemcpyDeviceToHost));
+    long bad = 0, zero = 0, nan = 0;
+    double maxd = 0, sumd = 0;
+    std::vector<long> per_b(B, 0), per_c(C, 0), per_row(B * H, 0), per_x(W, 0);
+    for (long i = 0; i < n; ++i) {
+        if (memcmp(&y[i], &r[i], 4) == 0) continue;
+        ++bad;
+        const int x = (int)(i % W), yy = (int)(i / W % H), c = (int)(i / ((long)W * H) % C), b = (int)(i / ((long)W * H * C));
+        ++per_b[b]; ++per_c[c]; ++per_row[b * H + yy]; ++per_x[x];
+        if (y[i] == 0.0f) ++zero;
+        if (y[i] != y[i]) ++nan;
+        const double d = fabs((double)y[i] - (double)r[i]);
+        if (d == d) { sumd += d; if (d > maxd) maxd = d; }
+    }
+    printf("    DUMP: %ld elements differ (zero %ld, nan %ld), |diff| max %.4g mean %.4g\n      per image:", bad, zero, nan, maxd, bad ? sumd / bad : 0.0);
+    for (int b = 0; b < B; ++b) printf(" %ld", per_b[b]);
+    printf("\n      rows (image:row=count):");
+    for (int i = 0; i < B * H; ++i) if (per_row[i]) printf(" %d:%d=%ld", i / H, i % H, per_row[i]);
+    printf("\n      columns with differences:");
+    for (int x = 0; x < W; ++x) if (per_x[x]) printf(" %d=%ld", x, per_x[x]);
+    printf("\n      output channels with differences:");
+    for (int c = 0; c < C; ++c) if (per_c[c]) printf(" %d=%ld", c, per_c[c]);
+    // a few samples
+    printf("\n      samples (b,c,y,x: got / clean):");
+    int shown = 0;
+    for (long i = 0; i < n && shown < 12; ++i) if (memcmp(&y[i], &r[i], 4)) {
+        printf(" (%d,%d,%d,%d: %.6g / %.6g)", (int)(i / ((long)W * H * C)), (int)(i / ((long)W * H) % C), (int)(i / W % H), (int)(i % W), y[i], r[i]);
+        ++shown; i += 997;
+    }
+    printf("\n");
+    for (int i = 0, done = 0; i < B * H && done < 3; ++i) if (per_row[i]) { analyze(y, r, i / H, i % H, C, H, W); ++done; }
+}
+
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 4.0;
+    const int dump_max = getenv("DUMP") ? atoi(getenv("DUMP")) : 0;
     void* lib = argc > 2 ? dlopen(argv[2], RTLD_NOW | RTLD_LOCAL) : nullptr;
     if (argc > 2 && !lib) { fprintf(stderr, "dlopen %s: %s\n", argv[2], dlerror()); return 2; }
     const int B = 3, heads = 2, C = 192, HW = 1024;
@@ -130,12 +228,20 @@ int main(int argc, char** argv) {
                                            getenv("VICTIM_WDMA") ? getenv("VICTIM_WDMA") : "1", getenv("VICTIM_KS") ? getenv("VICTIM_KS") : "3");
         setopt(ctx_a, "naive_attn", 4);          // the three-piece bf16 attention kernel, whatever the device fence would choose
         vks = getenv("VICTIM_KS") ? atoi(getenv("VICTIM_KS")) : 3;
+        g_ks = vks;
+        g_act = getenv("VICTIM_ACT") ? atoi(getenv("VICTIM_ACT")) : 1;          // 0: no SiLU in the victim's prologue
+        g_coef = getenv("VICTIM_COEF") ? atoi(getenv("VICTIM_COEF")) : 1;       // 0: raw input (no affine, no SiLU: the staging is load -> LDS)
+        if (!g_coef) g_act = 0;
+        if (getenv("VICTIM_AB")) { sscanf(getenv("VICTIM_AB"), "%f %f", &g_A, &g_B); printf("# library victim affine: A %g, B %g\n", g_A, g_B); }
+        if (getenv("VICTIM_ACT") || getenv("VICTIM_COEF")) printf("# library victim prologue: affine %d, SiLU %d\n", g_coef, g_act);
         std::vector<float> h(3L * 96 * 64 * 64), hw(96L * 96 * vks * vks), hc(3L * 96 * 2, 1.0f);
+        for (size_t i = 0; i < hc.size(); i += 2) { hc[i] = g_A; hc[i + 1] = g_B; }
         for (auto& v : h) v = 2.0f * frand(seed);
         for (auto& v : hw) v = frand(seed) / 29.0f;
         CK(hipMalloc(&cx, h.size() * 4)); CK(hipMalloc(&cw, hw.size() * 4)); CK(hipMalloc(&cb, 96 * 4)); CK(hipMalloc(&cco, hc.size() * 4));
         CK(hipMemcpy(cx, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(cw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemset(cb, 0, 96 * 4)); CK(hipMemcpy(cco, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+        g_hx = h; g_hw = hw;
     }
     int aggr_kind = 0;                           // 0 the stand-alone build of the aggressor, 1 the library's
     const bool pollute = getenv("AGGR") && !strcmp(getenv("AGGR"), "lds");
@@ -163,7 +269,7 @@ int main(int argc, char** argv) {
     for (aggr_kind = 0; aggr_kind <= (lib ? 1 : 0); ++aggr_kind)
     for (int pk = lib ? 4 : 3; pk >= (getenv("ONLY_LIB") ? 4 : 0); --pk) {
         auto victim = [&](float* dst) {
-            if (pk == 4) { if (lib_conv(ctx_v, cx, 96, nullptr, 0, cw, cb, 96, vks, cco, 1, nullptr, 1.0f, dst, 3, 64, 64)) { fprintf(stderr, "lib conv failed\n"); exit(2); } }
+            if (pk == 4) { if (lib_conv(ctx_v, cx, 96, nullptr, 0, cw, cb, 96, vks, g_coef ? cco : nullptr, g_act, nullptr, 1.0f, dst, 3, 64, 64)) { fprintf(stderr, "lib conv failed\n"); exit(2); } }
             else if (pk == 3) { if (mcvd::launch_fir2(fx, fcoef, 1, 1, dst, 3, 192, 32, 32, nullptr, nullptr, nullptr, nullptr, sv, 1)) { fprintf(stderr, "fir: %s\n", mcvd::get_error()); exit(2); } }
             else if (pk == 2) { if (mcvd::launch_fir2(fx, nullptr, 0, 1, dst, 3, 192, 32, 32, nullptr, nullptr, nullptr, nullptr, sv, 1)) { fprintf(stderr, "fir: %s\n", mcvd::get_error()); exit(2); } }
             else if (pk) hipLaunchKernelGGL(victim_kernel<true>, dim3(2048), dim3(256), 0, sv, (const f32x2*)x, (f32x2*)dst, nv / 2, 1.0009765625f, 0.99951171875f, 0.03125f, -0.0625f);
@@ -199,6 +305,7 @@ int main(int argc, char** argv) {
                 ++n;
                 if (hb) {
                     if (!n_bad) { nsig = hb < 32 ? (int)hb : 32; CK(hipMemcpy(sig, first, nsig * 4, hipMemcpyDeviceToHost)); }
+                    if (pk == 4 && n_bad < dump_max) dump_diff(y, ref, 3, 96, 64, 64);
                     ++n_bad; el_bad += hb;
                 }
             }
