@@ -1,6 +1,8 @@
 """Two STREAMS of ONE process on one MI355X: does a kernel that corrupts its neighbour across PROCESSES
 (attn_h2_kernel<3,3>, profiles/r04_two_process_corruption.txt) also do so across streams?  SURVEY 8b allows one context per stream from
 one thread each, so this is a supported configuration and must be clean -- or fenced.
+(Round 6: it IS clean since the cause was removed from the library's kernels -- profiles/r06_coresident_cause.txt; this script forces the
+aggressor kernel past the fence, and tests/test_gpu_parity.py::test_former_victims_are_clean_beside_the_bf16_attention_kernel runs it.)
 
 One process, two threads, each with its own HIP stream and its own mcvd context.  The VICTIM thread loops one op and compares every
 result bit for bit with its own reference (taken while the other thread is idle); the AGGRESSOR thread keeps launching its op without
@@ -103,6 +105,7 @@ def main():
     for victim, aggressor in plan:
         total += phase(victim, aggressor)
     print("TOTAL corrupted launches across streams of one process:", total, flush=True)
+    return total
 
 
 if __name__ == "__main__":

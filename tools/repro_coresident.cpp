@@ -183,6 +183,7 @@ static void dump_diff(const float* dy, const float* dref, int B, int C, int H, i
     for (int i = 0, done = 0; i < B * H && done < 3; ++i) if (per_row[i]) { analyze(y, r, i / H, i % H, C, H, W); ++done; }
 }
 
+// (The cause this program helped to find is in profiles/r06_coresident_cause.txt; tools/repro_pk_fma_beside_mfma.cpp is the 100-line version.)
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 4.0;
     const int dump_max = getenv("DUMP") ? atoi(getenv("DUMP")) : 0;
