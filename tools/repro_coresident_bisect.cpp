@@ -12,7 +12,7 @@
 // shows only the end of the chain is tools/repro_pk_fma_beside_mfma.cpp.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/repro_coresident_bisect.cpp -o tools/bin/repro_coresident_bisect -lpthread
-//   tools/bin/repro_coresident_bisect [seconds per phase]     env VARS ("0 1 ... 13"), AGGRS ("0"; 1..13 synthetic), AITER, AGRID, GRID (48), LDSKB (68), ITER (64)
+//   tools/bin/repro_coresident_bisect [seconds per phase]     env VARS ("0 1 ... 17"), AGGRS ("0"; 1..13 synthetic), AITER, AGRID, GRID (48), LDSKB (68), ITER (64)
 #include <math.h>
 #include <pthread.h>
 #include <stdarg.h>
@@ -73,7 +73,21 @@ __global__ __launch_bounds__(256) void seq_victim(const f32x4* __restrict__ x, c
                 else if (VAR == 10) MCVD_INWAVE("s_nop 3\n");
                 else if (VAR == 11) MCVD_INWAVE("s_nop 7\n");
                 else MCVD_INWAVE("s_nop 15\n");
-            } else if (VAR == 13)      // the other dual read hipcc generates (temb_mlp_kernel, gamma_noise_kernel): src0 == src1, halves swapped
+            } else if (VAR == 14)      // unpacked: ONE 32-bit register as src1 and src2 (x * c + c)
+                asm volatile("v_fma_f32 v4, v100, v138, v138\n v_fma_f32 v5, v101, v139, v139\n v_fma_f32 v2, v98, v138, v138\n v_fma_f32 v3, v99, v139, v139\n"
+                             ::: "v2", "v3", "v4", "v5");
+            else if (VAR == 15)        // packed, one pair as src1 and src2, NO op_sel (x * c + c per half)
+                asm volatile("v_pk_fma_f32 v[4:5], v[100:101], v[138:139], v[138:139]\n v_pk_fma_f32 v[2:3], v[98:99], v[138:139], v[138:139]\n"
+                             ::: "v2", "v3", "v4", "v5");
+            else if (VAR == 16)        // packed, one pair as src0 and src2 (the form hipcc gave the clean conv instantiations): A from src0, x src1, B src2
+                asm volatile("v_pk_fma_f32 v[4:5], v[138:139], v[100:101], v[138:139] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n"
+                             "v_pk_fma_f32 v[2:3], v[138:139], v[98:99], v[138:139] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n"
+                             ::: "v2", "v3", "v4", "v5");
+            else if (VAR == 17)        // packed multiply, one pair as src0 and src1, different halves broadcast (c.x * c.y in both halves) + add x
+                asm volatile("v_pk_mul_f32 v[4:5], v[138:139], v[138:139] op_sel:[0,1] op_sel_hi:[0,1]\n v_pk_mul_f32 v[2:3], v[138:139], v[138:139] op_sel:[0,1] op_sel_hi:[0,1]\n"
+                             "s_nop 1\n v_pk_add_f32 v[4:5], v[4:5], v[100:101]\n v_pk_add_f32 v[2:3], v[2:3], v[98:99]\n"
+                             ::: "v2", "v3", "v4", "v5");
+            else if (VAR == 13)      // the other dual read hipcc generates (temb_mlp_kernel, gamma_noise_kernel): src0 == src1, halves swapped
                 asm volatile("v_pk_add_f32 v[4:5], v[100:101], v[100:101] op_sel:[0,1] op_sel_hi:[1,0]\n v_pk_mul_f32 v[2:3], v[98:99], v[98:99] op_sel:[0,1] op_sel_hi:[1,0]\n"
                              ::: "v2", "v3", "v4", "v5");
             else if (VAR == 3)
@@ -242,10 +256,11 @@ int main(int argc, char** argv) {
     if (aggressor_once() != 0) { fprintf(stderr, "aggressor launch failed: %s\n", mcvd::get_error()); return 2; }
     CK(hipStreamSynchronize(sa));
     printf("# seq_victim: grid %d x 256 threads, %d KB dynamic LDS, %d repetitions of the sequence per element; %.1f s per phase\n", grid, ldskb, iters, secs);
-    static const char* vname[14] = {"as generated", "no SALU between the selects", "selects under VCC", "four v_fma_f32", "v_pk_fma_f32 without op_sel", "as generated + SiLU tail",
+    static const char* vname[18] = {"as generated", "no SALU between the selects", "selects under VCC", "four v_fma_f32", "v_pk_fma_f32 without op_sel", "as generated + SiLU tail",
                                    "the two v_pk_fma_f32 only", "same, addend from a copy",
                                    "MFMA in the wave, 0 wait", "MFMA in the wave, s_nop 0", "MFMA in the wave, s_nop 3", "MFMA in the wave, s_nop 7", "MFMA in the wave, s_nop 15",
-                                   "v_pk_add/mul x, x swapped"};
+                                   "v_pk_add/mul x, x swapped",
+                                   "v_fma_f32 d, x, c, c (32-bit)", "v_pk_fma d,x,c,c no op_sel", "v_pk_fma d,c,x,c (src0==src2)", "v_pk_mul d,c,c lo*hi"};
 #define FOR_VAR(V, ...) case V: { auto kern = seq_victim<V>; __VA_ARGS__; } break;
     for (const char* ap = aggrs; *ap;) {
     if (*ap < '0' || *ap > '9') { ++ap; continue; }
@@ -258,11 +273,11 @@ int main(int argc, char** argv) {
         char* vend;
         const int var = (int)strtol(p, &vend, 10);
         p = vend;
-        if (var > 13) continue;
+        if (var > 17) continue;
         auto victim = [&](float* dst) {
             switch (var) {
 #define LV(V) FOR_VAR(V, CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldskb * 1024, sv, (const f32x4*)x, (const f32x2*)coef, (f32x4*)dst, n4, iters, 0ull, ~0ull))
-                LV(0) LV(1) LV(2) LV(3) LV(4) LV(5) LV(6) LV(7) LV(8) LV(9) LV(10) LV(11) LV(12) LV(13)
+                LV(0) LV(1) LV(2) LV(3) LV(4) LV(5) LV(6) LV(7) LV(8) LV(9) LV(10) LV(11) LV(12) LV(13) LV(14) LV(15) LV(16) LV(17)
             }
             CK(hipGetLastError());
         };
