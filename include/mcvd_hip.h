@@ -146,7 +146,8 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         (The consumer-side reduction of those statistics, option "gn_inline" of rounds 3-5, measured 0.3-1 % slower on every config and was
  *         removed in round 6: profiles/r03_gn_inline_ab.txt.)  "spade_fuse" (0): 1 = the SPADE modulation inside the fp32 Winograd conv loader (gamma | beta by
  *         LDS-DMA; measured 3.5 % slower end to end than the materialising spade_apply kernel).  "side_stream" (0): ResBlock shortcut
- *         convs on a second HIP stream (measured slower; UNSAFE beside the split-operand attention kernel: INTEGRATION.md section 4).
+ *         convs on a second HIP stream (measured +- 0.1 % on configs 2 / 4 / 5, profiles/r06_side_stream_ab.txt; safe since round 6 removed the
+ *         instruction form that broke beside the bf16 matrix kernels from every kernel of the library: INTEGRATION.md section 4).
  *         "gn_producer" (1): the second pass of a K-split Winograd layer over 8 x 8 / 16 x 16 planes also writes the (A, B) table of the
  *         single-source norm over its output (one workgroup per (sample, group); bit-identical to gn_finalize), that norm's launch is
  *         skipped; 0 = two launches.
