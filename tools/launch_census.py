@@ -60,6 +60,14 @@ def main():
         e[0] += 1
         e[1] += ms[i] * 1e3
         e[2] += ms[i] * 1e3 < 20.0
+    if os.environ.get("PER_OP"):          # one line per conv: where inside a level the time goes
+        tab = dict(enumerate(net.get_tuning(B)))
+        print(f"# {name}, B = {B}: every conv of the instrumented forward (op, H, Cin -> Cout, ks, residual, kernel id / cout tile of the table, us, direct-form TFLOP/s)")
+        for i in range(n):
+            if kinds[i] != 3 or ms[i] == 0.0:
+                continue
+            _lib.lib.mcvd_model_op_info(net._model, i, info)
+            print(f"  op {i:3d}  H {info[3]:3d}  {info[4]:4d} -> {info[5]:4d}  k{kss[i]}  res {info[6]}  pro {info[7]}  kernel {tab.get(i)}  {ms[i] * 1e3:8.1f} us  {fl[i] / ms[i] / 1e9:7.1f} TF/s")
     tot_n = sum(e[0] for d in levels.values() for e in d.values())
     tot_us = sum(e[1] for d in levels.values() for e in d.values())
     tot_short = sum(e[2] for d in levels.values() for e in d.values())
