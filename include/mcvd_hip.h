@@ -148,6 +148,8 @@ int mcvd_ctx_set_stream(mcvd_ctx* ctx, void* hip_stream);
  *         LDS-DMA; measured 3.5 % slower end to end than the materialising spade_apply kernel).  "side_stream" (0): ResBlock shortcut
  *         convs on a second HIP stream (measured +- 0.1 % on configs 2 / 4 / 5, profiles/r06_side_stream_ab.txt; safe since round 6 removed the
  *         instruction form that broke beside the bf16 matrix kernels from every kernel of the library: INTEGRATION.md section 4).
+ *         "share_fence" (0): 1 = while the context shares its device (mcvd_ctx_device_shared) attention runs on the fp32 MFMA kernel -- the
+ *         round-5 workaround for the co-residency corruption, whose cause round 6 removed from the library's kernels.
  *         "gn_producer" (1): the second pass of a K-split Winograd layer over 8 x 8 / 16 x 16 planes also writes the (A, B) table of the
  *         single-source norm over its output (one workgroup per (sample, group); bit-identical to gn_finalize), that norm's launch is
  *         skipped; 0 = two launches.

@@ -125,7 +125,9 @@ void ctx_unregister(mcvd_ctx* c) {
 // (tools/diag_concurrent_streams.py, profiles/r05_two_stream_corruption.txt): two streams of ONE process corrupt each other exactly like two
 // processes do -- 55 % of the elementwise launches beside attn_h2_kernel<3,3> on the other stream came back with 16 lanes of one VALU
 // result wrong, none beside the fp32 attention kernel, none with the two sides on disjoint CU halves (HSA_CU_MASK).  Contexts that share
-// a stream are serialised by it and do not count.  The callers below keep the split-operand attention kernels off a shared device.
+// a stream are serialised by it and do not count.  Round 6 found the cause (one instruction form in the VICTIMS, profiles/r06_coresident_cause.txt)
+// and removed it from every kernel of the library, so sharing is REPORTED (mcvd_ctx_device_shared) but no longer changes which kernels run; the
+// round-5 workaround -- the split-operand attention kernels kept off a shared device -- is the option "share_fence" (default 0).
 bool mcvd_ctx_shares_device(const mcvd_ctx* c) {
     if (!c) return false;
     if (c->shared_device) return true;
@@ -349,6 +351,7 @@ int mcvd_ctx_set_option(mcvd_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "conv_wdma")) ctx->conv_wdma = value;
     else if (!strcmp(key, "autotune")) ctx->autotune = value;
     else if (!strcmp(key, "side_stream")) ctx->side_stream = value;
+    else if (!strcmp(key, "share_fence")) ctx->share_fence = value;
     else if (!strcmp(key, "winograd")) ctx->winograd = value;
     else if (!strcmp(key, "conv_dma1")) ctx->conv_dma1 = value;
     else if (!strcmp(key, "bf16x3")) ctx->bf16x3 = value;
@@ -1204,7 +1207,7 @@ int mcvd_op_gn_coef(mcvd_ctx* ctx, const float* x0, int C0, const float* x1, int
 
 int mcvd_op_attention(mcvd_ctx* ctx, const float* qkv, float* out, int B, int C, int heads, int HW) {
     MCVD_REQUIRE(ctx && qkv && out, "op_attention: NULL argument");
-    const bool shared = mcvd_ctx_shares_device(ctx);
+    const bool shared = ctx->share_fence && mcvd_ctx_shares_device(ctx);
     return launch_attention(ctx->naive_attn, shared ? 0 : ctx->f16x2, shared ? 0 : ctx->bf16x3, qkv, out, B, C, heads, HW, ctx->stream);
 }
 

@@ -872,7 +872,7 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                 kv_live[op.attn_op] = 0;
                 const Op& at = ops[op.attn_op];
                 const bool want = ctx->attn_presplit && !ctx->naive_conv && ctx->bf16x3 && !ctx->f16x2 && (ctx->naive_attn == 0 || ctx->naive_attn == 4) &&
-                                  !mcvd_ctx_shares_device(ctx) && attn_h2p_supported(at.Cout, at.heads, at.H * at.W) && a.shape_hint == 15;
+                                  !(ctx->share_fence && mcvd_ctx_shares_device(ctx)) && attn_h2p_supported(at.Cout, at.heads, at.H * at.W) && a.shape_hint == 15;
                 if (want) {
                     ConvArgs t = a;
                     t.kv_img = resolve(op.kv, x, cond, out, B);
@@ -970,9 +970,9 @@ int mcvd_model::launch_op(const Op& op, const float* x, const void* lab, const f
                                       resolve(op.dst, x, cond, out, B), B, op.H * op.W, s);
         case OP_ATTN:
         {
-            // (a context that shares its device -- another process, or another stream of this one -- keeps the split-operand attention
-            // kernels off it: api.cpp, mcvd_ctx_shares_device)
-            const bool shared = mcvd_ctx_shares_device(ctx);
+            // (option share_fence, off since round 6 found and removed the cause: a context that shares its device -- another process, or another
+            // stream of this one -- keeps the split-operand attention kernels off it: api.cpp, mcvd_ctx_shares_device)
+            const bool shared = ctx->share_fence && mcvd_ctx_shares_device(ctx);
             const size_t ai = (size_t)(&op - ops.data());
             if (ai < kv_live.size() && kv_live[ai]) {                     // K and V were written pre-split by the projection of this forward
                 kv_live[ai] = 0;

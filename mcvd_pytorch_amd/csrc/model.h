@@ -41,6 +41,7 @@ struct mcvd_ctx {
                                    //    Convs with a raw (not normalised) input never take them; see model.cpp "f16x2 range guard"
     int conv_dma1 = 1;             // offer the all-DMA 1x1 GEMM kernel (conv1x1_dma.cpp) to the autotuner
     int conv_wdma = 1;             // weight chunks by LDS-DMA (1) or register staging (0)
+    int share_fence = 0;           // 1: a context that shares its device keeps the split-operand attention kernels off it (the round-5 workaround; the cause is gone)
     int side_stream = 0;           // 1: run the ResBlock shortcut 1x1 convs on a second stream (measured -2 %: off by default)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
