@@ -396,7 +396,7 @@ def main():
     net.set_option("profile", 1)
     net.set_option("graph", args.graph)
     if world > 1 and os.environ.get("MCVD_BENCH_SERIALIZE", "0") == "1":
-        net.set_option("naive_attn", 4)      # a context that shares its device runs attention on the fp32 MFMA unless forced: every rank the same kernel
+        net.set_option("naive_attn", 4)      # every rank the same attention kernel, whatever a "share_fence" in MCVD_BENCH_OPTS would choose for a shared device
     for kv in os.environ.get("MCVD_BENCH_OPTS", "").split(","):      # diagnostics: context options, e.g. MCVD_BENCH_OPTS=conv_shape=10,naive_attn=2
         if kv:
             net.set_option(kv.split("=")[0], int(kv.split("=")[1]))

@@ -88,10 +88,11 @@ typedef struct mcvd_unet_desc {
 /* One context per (device, stream); replaces the reference's implicit "current CUDA device + current stream" (op/upfirdn2d_kernel.cu:213-215).
  * ONE PROCESS PER GPU is enforced: the first process to create a context on a device takes an advisory lock on it (a lock file keyed by
  * the PCI bus id, released when the process exits); a second process gets MCVD_EBUSY -- kernels of two processes sharing the CUs of one
- * MI355X corrupted each other's results (profiles/r04_two_process_corruption.txt).  MCVD_ALLOW_SHARED_DEVICE=1 in the second process's
- * environment lets it in for callers that take turns on the device; such a context reports 1 from mcvd_ctx_device_shared and runs
- * attention on the fp32 MFMA (the split-operand attention kernel was the aggressor in every observed corruption).  Several contexts
- * of ONE process (one per stream) are allowed: measured clean, INTEGRATION.md section 4. */
+ * MI355X corrupted each other's results (profiles/r04_two_process_corruption.txt; cause, round 6: a v_pk_fma_f32 that reads one VGPR pair as
+ * src1 and src2 loses its low addend beside another wave's 128-bit-operand MFMA, profiles/r06_coresident_cause.txt -- this library's kernels
+ * no longer hold that form, a co-tenant's may).  MCVD_ALLOW_SHARED_DEVICE=1 in the second process's environment lets it in for callers
+ * that take turns on the device; such a context reports 1 from mcvd_ctx_device_shared (and, with the option "share_fence", runs attention
+ * on the fp32 MFMA as rounds 5-6 did).  Several contexts of ONE process (one per stream) are allowed: measured clean, INTEGRATION.md section 4. */
 #define MCVD_EBUSY (-7)    /* mcvd_ctx_create: the device is held by another process of this library */
 int mcvd_ctx_create(int device, void* hip_stream, mcvd_ctx** out);
 int mcvd_ctx_device_shared(mcvd_ctx* ctx);
