@@ -217,8 +217,8 @@ def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny
             kk[0] += 1
             return step_noise[b, kk[0] - 1].to(like.dtype)
         x_in = rec["z"][b].double() if (b == 0 or t_min <= 0) else g64
-        g64 = sampler_ref.sample(x_in, net64, cond=cond64, kind="ddpm", final_only=True, denoise=True, subsample_steps=subsample,
-                                 clip_before=True, noise_fn=fn, t_min=t_min)[-1]
+        g64 = sampler_ref.sample(x_in, net64, cond=cond64, kind="ddpm", final_only=True, denoise=bool(getattr(config.sampling, "denoise", True)),
+                                 subsample_steps=subsample, clip_before=bool(getattr(config.sampling, "clip_before", True)), noise_fn=fn, t_min=t_min)[-1]
         preds64.append(g64)
         if b != n_blocks - 1:
             cond64 = torch.cat([cond64[:, C:], g64[:, :C]], dim=1) if one_at else \
@@ -242,5 +242,7 @@ if __name__ == "__main__":
         gen_videogen()
     if "prevt" in which:
         gen_videogen(tag="tiny_runner_videogen_prevt", overrides=dict(init_prev_t=0.5))
+    if "plain" in which:      # the config switches the block loop forwards to the sampler (:1515-1517): no final denoise forward, no clip of x0
+        gen_videogen(tag="tiny_runner_videogen_plain", overrides=dict(denoise=False, clip_before=False))
     if "oneframe" in which:
         gen_videogen(nfp=3, tag="tiny_runner_videogen_oneframe", overrides=dict(one_frame_at_a_time=True))

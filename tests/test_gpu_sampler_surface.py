@@ -189,7 +189,8 @@ def test_config4_full_schedule_at_the_benchmarked_batch(golden_dir):
     assert (d > 1e-3).all()
 
 
-@pytest.mark.parametrize("fx", ["tiny_runner_videogen.pt", "tiny_runner_videogen_prevt.pt", "tiny_runner_videogen_oneframe.pt"])
+@pytest.mark.parametrize("fx", ["tiny_runner_videogen.pt", "tiny_runner_videogen_prevt.pt", "tiny_runner_videogen_oneframe.pt",
+                                "tiny_runner_videogen_plain.pt"])
 def test_three_edits_of_integration_md_against_the_real_runner(golden_dir, capsys, fx):
     """INTEGRATION.md section 2 end to end, against frames the REAL `NCSNRunner.video_gen` produced (oracle/gen_runner_golden.py drove the
     real `runners/ncsn_runner.py` -- get_model, get_sampler, the block loop :1476-1569 -- on the CPU; the module cannot travel to the GPU
@@ -220,9 +221,11 @@ def test_three_edits_of_integration_md_against_the_real_runner(golden_dir, capsy
                        init_noise_fn=lambda i, shp, dev: g["z_init"][i].to(dev))                    # edit 3
     assert blk[0] == 3 and pred.is_cuda
     err = (pred.cpu() - g["pred_raw"]).abs().max().item()
-    assert 0.0 < g["ref32_vs_ref64_max_abs"] <= 1e-4 / 3
-    assert err <= 1e-4, f"three-edit integration vs the real runner's frames: {err:.3e}"
-    assert (r.inverse_data_transform(config, pred).cpu() - g["pred01"]).abs().max().item() <= 1e-4
+    # (the `plain` fixture: denoise = False, clip_before = False -- |frames| reach 1e3, the gate is 1e-5 of their range as for the surface cases)
+    tol = 1e-4 if g.get("overrides", {}).get("clip_before", True) else 1e-5 * float(g["pred_raw"].abs().max())
+    assert 0.0 < g["ref32_vs_ref64_max_abs"] <= tol / 3
+    assert err <= tol, f"three-edit integration vs the real runner's frames: {err:.3e} (gate {tol:.1e})"
+    assert (r.inverse_data_transform(config, pred).cpu() - g["pred01"]).abs().max().item() <= tol
     # the verbose lines: same text, same step counters, the three norms to 1e-3 relative
     mine = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("DDPM: ")]
     assert len(mine) == len(g["log_lines"]) and len(mine) in (27, 30)          # (t_min skips step 0 of every call: nine lines per block)

@@ -101,7 +101,13 @@ def test_save_video_pred_format(tmp_path):
 # ------------------------------------------------------------------ round 6: fixtures from the REAL NCSNRunner.video_gen
 RUNNER_FIXTURES = ["tiny_runner_videogen.pt",               # prediction, three blocks of two frames cropped to five
                    "tiny_runner_videogen_prevt.pt",         # sampling.init_prev_t = 0.5: blocks restart from the previous block's frames, re-noised
-                   "tiny_runner_videogen_oneframe.pt"]      # sampling.one_frame_at_a_time: cond shifts by one frame per block
+                   "tiny_runner_videogen_oneframe.pt",      # sampling.one_frame_at_a_time: cond shifts by one frame per block
+                   "tiny_runner_videogen_plain.pt"]         # sampling.denoise = False, clip_before = False: the switches the loop forwards (|frames| reach 1e3)
+
+
+def _runner_tol(g):
+    """1e-4 on [-1, 1] frames; where clip_before = False lets them reach 1e3, 1e-5 of their range (the fixtures' surface cases use the same rule)"""
+    return 1e-4 if g.get("overrides", {}).get("clip_before", True) else 1e-5 * float(g["pred_raw"].abs().max())
 
 
 def _runner_fixture(golden_dir, name="tiny_runner_videogen.pt"):
@@ -139,8 +145,10 @@ def test_glue_matches_the_real_runner(golden_dir, fx):
     assert torch.equal(r.inverse_data_transform(cfg, g["pred_raw"]), g["pred01"])
     # what the runner hands the sampler (:1513-1520): exactly the kwargs the mirror's block loop passes on
     kw = g["sampler_kwargs"][0]
-    assert kw == dict(cond_mask=None, n_steps_each=0, step_lr=0.0, verbose=True, final_only=True, denoise=True, subsample_steps=g["subsample"],
-                      clip_before=True, t_min=float(g.get("overrides", {}).get("init_prev_t", -1.0)), log=True, gamma=False)
+    ov = g.get("overrides", {})
+    assert kw == dict(cond_mask=None, n_steps_each=0, step_lr=0.0, verbose=True, final_only=True, denoise=ov.get("denoise", True),
+                      subsample_steps=g["subsample"], clip_before=ov.get("clip_before", True), t_min=float(ov.get("init_prev_t", -1.0)), log=True,
+                      gamma=False)
 
 
 @pytest.mark.parametrize("fx", RUNNER_FIXTURES)
@@ -165,11 +173,14 @@ def test_block_loop_matches_the_real_runner(golden_dir, fx):
         def fn(i, like):
             k[0] += 1
             return g["step_noise"][b, k[0] - 1]
-        assert kw["final_only"] and kw["denoise"] and kw["subsample_steps"] == g["subsample"] and kw["clip_before"] and kw["t_min"] == t_min
-        return sampler_ref.sample(x, scorenet, cond=cond, kind="ddpm", final_only=True, denoise=True, subsample_steps=kw["subsample_steps"],
-                                  clip_before=True, t_min=kw["t_min"], noise_fn=fn)
+        ov = g.get("overrides", {})
+        assert kw["final_only"] and kw["subsample_steps"] == g["subsample"] and kw["t_min"] == t_min
+        assert kw["denoise"] == ov.get("denoise", True) and kw["clip_before"] == ov.get("clip_before", True)      # the config switches reach the sampler
+        return sampler_ref.sample(x, scorenet, cond=cond, kind="ddpm", final_only=True, denoise=kw["denoise"], subsample_steps=kw["subsample_steps"],
+                                  clip_before=kw["clip_before"], t_min=kw["t_min"], noise_fn=fn)
     pred = r.video_gen(cfg, net, g["cond"], num_frames_pred=g["nfp"], sampler=sampler, init_noise_fn=lambda i, shp, dev: g["z_init"][i])
     assert blk[0] == 3 and pred.shape == g["pred_raw"].shape
-    assert 0.0 < g["ref32_vs_ref64_max_abs"] <= 1e-4 / 3
+    tol = _runner_tol(g)
+    assert 0.0 < g["ref32_vs_ref64_max_abs"] <= tol / 3
     err = (pred - g["pred_raw"]).abs().max().item()
-    assert err <= 1e-4, f"block loop vs the real runner: {err:.3e}"
+    assert err <= tol, f"block loop vs the real runner: {err:.3e} (gate {tol:.1e})"
