@@ -242,7 +242,7 @@ if __name__ == "__main__":
         gen_videogen()
     if "prevt" in which:
         gen_videogen(tag="tiny_runner_videogen_prevt", overrides=dict(init_prev_t=0.5))
-    if "plain" in which:      # the config switches the block loop forwards to the sampler (:1515-1517): no final denoise forward, no clip of x0
+    if "plain" in which:      # the config switches the block loop forwards to the sampler (:1516-1518): no final denoise forward, no clip of x0
         gen_videogen(tag="tiny_runner_videogen_plain", overrides=dict(denoise=False, clip_before=False))
     if "oneframe" in which:
         gen_videogen(nfp=3, tag="tiny_runner_videogen_oneframe", overrides=dict(one_frame_at_a_time=True))
