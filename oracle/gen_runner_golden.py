@@ -100,12 +100,12 @@ def runner_config(name, batch, nfp, subsample, version="DDPM"):
     return config
 
 
-def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny_runner_videogen", overrides=None):
+def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny_runner_videogen", overrides=None, version="DDPM"):
     """overrides: `sampling.*` switches of the block loop (init_prev_t: blocks restart from the previous block's frames and the sampler re-noises
     them, :1513 + models/__init__.py:269-280; one_frame_at_a_time: one frame kept per block, :1501-1504, :1530-1531)."""
     R = import_real_runner()
     import models as ref_models
-    config = runner_config(name, batch, nfp, subsample)
+    config = runner_config(name, batch, nfp, subsample, version=version)          # model.version picks the sampler (get_sampler :2702-2714)
     for k_, v_ in (overrides or {}).items():
         setattr(config.sampling, k_, v_)
     C, nf, nc, S = config.data.channels, config.data.num_frames, config.data.num_frames_cond, config.data.image_size
@@ -122,18 +122,23 @@ def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny
     net.eval()
     runner = R.NCSNRunner(args, config, None)
     bound = runner.get_sampler()                                              # :2702-2714
-    assert bound.func is ref_models.ddpm_sampler and bound.keywords == {"config": config}
+    sampler_name = {"DDPM": "ddpm_sampler", "DDIM": "ddim_sampler", "FPNDM": "FPNDM_sampler"}[version]
+    assert bound.func is getattr(ref_models, sampler_name) and bound.keywords == {"config": config}
 
     n_blocks = nfp if getattr(config.sampling, "one_frame_at_a_time", False) else -(-nfp // nf)
     t_min = getattr(config.sampling, "init_prev_t", -1)
     # draws of one ddpm_sampler call: L - 1 step draws of the executed steps but the last, + 1 for the t_min re-noise (:272-279).  With
     # subsample 10 the t_min test `step < t_min * 10` (:269) skips step 0 only (steps are 0, 100, ...): 8 + 1 = 9 draws, as without t_min.
     per_call = (subsample - 1) if t_min <= 0 else (subsample - 2) + 1
+    if version != "DDPM":
+        per_call = 0                                                          # DDIM / F-PNDM are deterministic (DDIM draws for the t_min re-noise only)
+        assert t_min <= 0
     step_noise = torch.randn(n_blocks, subsample + 1, batch, C * nf, S, S, generator=torch.Generator().manual_seed(77))
     rec = dict(z=[], sampler_kwargs=[], real_t=None, cf=None)
     k = [0]
 
     def randn_like(like, *a, **kw):                                           # the sampler's step draws, in call order across the blocks
+        assert per_call > 0, "a deterministic sampler drew noise"
         blk, i = divmod(k[0], per_call)
         k[0] += 1
         z = step_noise[blk, i].to(like)
@@ -174,7 +179,7 @@ def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny
         return out
 
     sampler_calls = []
-    real_sampler = ref_models.ddpm_sampler
+    real_sampler = getattr(ref_models, sampler_name)
 
     def spy_sampler(x_mod, scorenet, **kw):
         sampler_calls.append({kk: (vv if not torch.is_tensor(vv) else "tensor") for kk, vv in kw.items() if kk not in ("cond", "config")})
@@ -189,7 +194,7 @@ def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny
             mock.patch.object(R, "data_transform", data_transform), \
             mock.patch.object(R, "conditioning_fn", conditioning_fn), \
             mock.patch.object(R, "inverse_data_transform", inverse_data_transform), \
-            mock.patch.object(R, "ddpm_sampler", spy_sampler), \
+            mock.patch.object(R, sampler_name, spy_sampler), \
             mock.patch.object(torch, "randn", randn), \
             mock.patch.object(torch, "randn_like", randn_like):
         try:
@@ -202,8 +207,8 @@ def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny
     # which dataset rows the shuffling loader served (clips are distinct): row r of the batch is clip order[r]
     order = [int(((real_dt(config, clips) - real_t[r]).flatten(1).abs().max(dim=1).values).argmin()) for r in range(batch)]
     real, cond, cond_mask = rec["cf"]
-    log_lines = [ln for ln in printed.getvalue().splitlines() if ln.startswith("DDPM: ")]      # the sampler's `verbose` lines (:304-306)
-    assert len(log_lines) == n_blocks * (10 if t_min <= 0 else 9)
+    log_lines = [ln for ln in printed.getvalue().splitlines() if ln.startswith(version + ": ")]      # the sampler's `verbose` lines (:304-306, :181-183)
+    assert len(log_lines) == (0 if version == "FPNDM" else n_blocks * (10 if t_min <= 0 else 9)), len(log_lines)
     # the same chain in float64 on the restatement (same inits, same noise): the noise floor a tolerance on pred_raw stands on
     from oracle import sampler_ref, unet_ref
     net64 = unet_ref.OracleScoreNet(config, synth.make_state_dict(config, seed=123), dtype=torch.float64)
@@ -217,15 +222,19 @@ def gen_videogen(name="tiny", batch=3, nfp=5, subsample=10, n_clips=5, tag="tiny
             kk[0] += 1
             return step_noise[b, kk[0] - 1].to(like.dtype)
         x_in = rec["z"][b].double() if (b == 0 or t_min <= 0) else g64
-        g64 = sampler_ref.sample(x_in, net64, cond=cond64, kind="ddpm", final_only=True, denoise=bool(getattr(config.sampling, "denoise", True)),
-                                 subsample_steps=subsample, clip_before=bool(getattr(config.sampling, "clip_before", True)), noise_fn=fn, t_min=t_min)[-1]
+        if version == "FPNDM":
+            g64 = sampler_ref.fpndm_sample(x_in, net64, cond=cond64, final_only=True, subsample_steps=subsample,
+                                           clip_before=bool(getattr(config.sampling, "clip_before", True)))[-1]
+        else:
+            g64 = sampler_ref.sample(x_in, net64, cond=cond64, kind=version.lower(), final_only=True, denoise=bool(getattr(config.sampling, "denoise", True)),
+                                     subsample_steps=subsample, clip_before=bool(getattr(config.sampling, "clip_before", True)), noise_fn=fn, t_min=t_min)[-1]
         preds64.append(g64)
         if b != n_blocks - 1:
             cond64 = torch.cat([cond64[:, C:], g64[:, :C]], dim=1) if one_at else \
                 torch.cat([cond64[:, C * nf:], g64[:, C * max(0, nf - nc):]], dim=1)
     drift = float((rec["pred_raw"].double() - torch.cat(preds64, dim=1)[:, :C * nfp]).abs().max())
     print(f"  reference fp32 vs fp64 restatement of the {n_blocks}-block chain: {drift:.3e}")
-    out = dict(log_lines=log_lines, ref32_vs_ref64_max_abs=drift, overrides=dict(overrides or {}), config_name=name, batch=batch, nfp=nfp, subsample=subsample, clips=clips, order=order, real_t=real_t, real=real, cond=cond,
+    out = dict(version=version, log_lines=log_lines, ref32_vs_ref64_max_abs=drift, overrides=dict(overrides or {}), config_name=name, batch=batch, nfp=nfp, subsample=subsample, clips=clips, order=order, real_t=real_t, real=real, cond=cond,
                cond_mask=cond_mask, z_init=torch.stack(rec["z"]), step_noise=step_noise, pred_raw=rec["pred_raw"], pred01=rec["pred01"],
                real01=rec["real01"], cond01=rec["cond01"], sampler_kwargs=sampler_calls,
                stood_in=sorted(ABSENT))
@@ -244,5 +253,9 @@ if __name__ == "__main__":
         gen_videogen(tag="tiny_runner_videogen_prevt", overrides=dict(init_prev_t=0.5))
     if "plain" in which:      # the config switches the block loop forwards to the sampler (:1516-1518): no final denoise forward, no clip of x0
         gen_videogen(tag="tiny_runner_videogen_plain", overrides=dict(denoise=False, clip_before=False))
+    if "ddim" in which:       # model.version = "DDIM": get_sampler binds ddim_sampler, the same block loop
+        gen_videogen(tag="tiny_runner_videogen_ddim", version="DDIM")
+    if "fpndm" in which:
+        gen_videogen(tag="tiny_runner_videogen_fpndm", version="FPNDM")
     if "oneframe" in which:
         gen_videogen(nfp=3, tag="tiny_runner_videogen_oneframe", overrides=dict(one_frame_at_a_time=True))

@@ -190,7 +190,7 @@ def test_config4_full_schedule_at_the_benchmarked_batch(golden_dir):
 
 
 @pytest.mark.parametrize("fx", ["tiny_runner_videogen.pt", "tiny_runner_videogen_prevt.pt", "tiny_runner_videogen_oneframe.pt",
-                                "tiny_runner_videogen_plain.pt"])
+                                "tiny_runner_videogen_plain.pt", "tiny_runner_videogen_ddim.pt", "tiny_runner_videogen_fpndm.pt"])
 def test_three_edits_of_integration_md_against_the_real_runner(golden_dir, capsys, fx):
     """INTEGRATION.md section 2 end to end, against frames the REAL `NCSNRunner.video_gen` produced (oracle/gen_runner_golden.py drove the
     real `runners/ncsn_runner.py` -- get_model, get_sampler, the block loop :1476-1569 -- on the CPU; the module cannot travel to the GPU
@@ -199,14 +199,16 @@ def test_three_edits_of_integration_md_against_the_real_runner(golden_dir, capsy
     inits and step noise.  Frames at 1e-4; the `verbose` lines (models/__init__.py:304-306) are the reference's, number for number."""
     import re
     from mcvd_pytorch_amd import runner as r
-    from mcvd_pytorch_amd.samplers import ddpm_sampler, get_sampler
+    from mcvd_pytorch_amd.samplers import ddim_sampler, ddpm_sampler, fpndm_sampler, get_sampler
     g = torch.load(os.path.join(golden_dir, fx), weights_only=False)
     config, sd, net = _net(g["config_name"])                                  # edit 1
     config.sampling.num_frames_pred, config.sampling.subsample = g["nfp"], g["subsample"]
     for k_, v_ in g.get("overrides", {}).items():                             # init_prev_t (blocks restart from the previous frames, re-noised) / one_frame_at_a_time
         setattr(config.sampling, k_, v_)
+    version = g.get("version", "DDPM")                                        # model.version picks the sampler, as NCSNRunner.get_sampler does (:2702-2714)
+    config.model.version = version
     bound = get_sampler(config)                                               # edit 2
-    assert bound.func is ddpm_sampler and bound.keywords == {"config": config}
+    assert bound.func is {"DDPM": ddpm_sampler, "DDIM": ddim_sampler, "FPNDM": fpndm_sampler}[version] and bound.keywords == {"config": config}
     batch = g["clips"][g["order"]]
     real_t = r.data_transform(config, batch)
     real, cond, cond_mask = r.conditioning_fn(config, real_t, num_frames_pred=g["nfp"], prob_mask_cond=0.0, prob_mask_future=0.0)
@@ -215,7 +217,8 @@ def test_three_edits_of_integration_md_against_the_real_runner(golden_dir, capsy
     def sampler(x, scorenet, **kw):
         b = blk[0]
         blk[0] += 1
-        return bound(x, scorenet, noise=g["step_noise"][b].cuda(), n_steps_each=0, step_lr=0.0, **kw)
+        extra = dict(noise=g["step_noise"][b].cuda()) if version == "DDPM" else {}          # (DDIM / F-PNDM draw nothing here)
+        return bound(x, scorenet, n_steps_each=0, step_lr=0.0, **extra, **kw)
     kw = g["sampler_kwargs"][0]
     pred = r.video_gen(config, net, cond, num_frames_pred=g["nfp"], sampler=sampler, verbose=kw["verbose"], log=kw["log"],
                        init_noise_fn=lambda i, shp, dev: g["z_init"][i].to(dev))                    # edit 3
@@ -223,13 +226,15 @@ def test_three_edits_of_integration_md_against_the_real_runner(golden_dir, capsy
     err = (pred.cpu() - g["pred_raw"]).abs().max().item()
     # (the `plain` fixture: denoise = False, clip_before = False -- |frames| reach 1e3, the gate is 1e-5 of their range as for the surface cases)
     tol = 1e-4 if g.get("overrides", {}).get("clip_before", True) else 1e-5 * float(g["pred_raw"].abs().max())
-    assert 0.0 < g["ref32_vs_ref64_max_abs"] <= tol / 3
+    if version != "DDPM":      # deterministic samplers: no clip of the last iterate, no noise -- the three-block chain amplifies fp32 rounding; 3 x the reference's own drift
+        tol = 3.0 * g["ref32_vs_ref64_max_abs"]
+    assert 0.0 < g["ref32_vs_ref64_max_abs"] <= tol / 3 * (1 + 1e-6)
     assert err <= tol, f"three-edit integration vs the real runner's frames: {err:.3e} (gate {tol:.1e})"
     assert (r.inverse_data_transform(config, pred).cpu() - g["pred01"]).abs().max().item() <= tol
     # the verbose lines: same text, same step counters, the three norms to 1e-3 relative
-    mine = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("DDPM: ")]
-    assert len(mine) == len(g["log_lines"]) and len(mine) in (27, 30)          # (t_min skips step 0 of every call: nine lines per block)
-    num = re.compile(r"DDPM: (\d+)/(\d+), grad_norm: ([-0-9.e+]+), image_norm: ([-0-9.e+]+), grad_mean_norm: ([-0-9.e+]+)$")
+    mine = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith(version + ": ")]
+    assert len(mine) == len(g["log_lines"]) and len(mine) in (0, 27, 30)       # (t_min skips step 0 of every call: nine lines per block; F-PNDM prints none)
+    num = re.compile(version + r": (\d+)/(\d+), grad_norm: ([-0-9.e+]+), image_norm: ([-0-9.e+]+), grad_mean_norm: ([-0-9.e+]+)$")
     for a, b in zip(mine, g["log_lines"]):
         ma, mb = num.match(a), num.match(b)
         assert ma and mb, (a, b)

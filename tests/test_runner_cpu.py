@@ -102,11 +102,18 @@ def test_save_video_pred_format(tmp_path):
 RUNNER_FIXTURES = ["tiny_runner_videogen.pt",               # prediction, three blocks of two frames cropped to five
                    "tiny_runner_videogen_prevt.pt",         # sampling.init_prev_t = 0.5: blocks restart from the previous block's frames, re-noised
                    "tiny_runner_videogen_oneframe.pt",      # sampling.one_frame_at_a_time: cond shifts by one frame per block
-                   "tiny_runner_videogen_plain.pt"]         # sampling.denoise = False, clip_before = False: the switches the loop forwards (|frames| reach 1e3)
+                   "tiny_runner_videogen_plain.pt",         # sampling.denoise = False, clip_before = False: the switches the loop forwards (|frames| reach 1e3)
+                   "tiny_runner_videogen_ddim.pt",          # model.version = "DDIM": NCSNRunner.get_sampler binds ddim_sampler (:2702-2714), the same block loop
+                   "tiny_runner_videogen_fpndm.pt"]         # model.version = "FPNDM"
 
 
 def _runner_tol(g):
-    """1e-4 on [-1, 1] frames; where clip_before = False lets them reach 1e3, 1e-5 of their range (the fixtures' surface cases use the same rule)"""
+    """1e-4 on [-1, 1] frames; where clip_before = False lets them reach 1e3, 1e-5 of their range (the fixtures' surface cases use the same rule).
+    The deterministic samplers (DDIM, F-PNDM) neither clip the last iterate nor inject noise: their three-block chains amplify fp32 rounding
+    (the reference's own fp32 chain is 2.7e-3 / 1.2e-3 from its fp64 restatement, recorded in the fixture) -- the gate is 3 x that drift, as for
+    the DDIM sampler fixtures; a wrong cond shift or crop is an O(1) error."""
+    if g.get("version", "DDPM") != "DDPM":
+        return 3.0 * g["ref32_vs_ref64_max_abs"]
     return 1e-4 if g.get("overrides", {}).get("clip_before", True) else 1e-5 * float(g["pred_raw"].abs().max())
 
 
@@ -118,6 +125,7 @@ def _runner_fixture(golden_dir, name="tiny_runner_videogen.pt"):
 def _runner_config(g):
     cfg = synth.make_config(g["config_name"])
     cfg.sampling.num_frames_pred, cfg.sampling.subsample = g["nfp"], g["subsample"]
+    cfg.model.version = g.get("version", "DDPM")
     for k, v in g.get("overrides", {}).items():
         setattr(cfg.sampling, k, v)
     return cfg
@@ -176,11 +184,14 @@ def test_block_loop_matches_the_real_runner(golden_dir, fx):
         ov = g.get("overrides", {})
         assert kw["final_only"] and kw["subsample_steps"] == g["subsample"] and kw["t_min"] == t_min
         assert kw["denoise"] == ov.get("denoise", True) and kw["clip_before"] == ov.get("clip_before", True)      # the config switches reach the sampler
-        return sampler_ref.sample(x, scorenet, cond=cond, kind="ddpm", final_only=True, denoise=kw["denoise"], subsample_steps=kw["subsample_steps"],
+        version = g.get("version", "DDPM")
+        if version == "FPNDM":
+            return sampler_ref.fpndm_sample(x, scorenet, cond=cond, final_only=True, subsample_steps=kw["subsample_steps"], clip_before=kw["clip_before"])
+        return sampler_ref.sample(x, scorenet, cond=cond, kind=version.lower(), final_only=True, denoise=kw["denoise"], subsample_steps=kw["subsample_steps"],
                                   clip_before=kw["clip_before"], t_min=kw["t_min"], noise_fn=fn)
     pred = r.video_gen(cfg, net, g["cond"], num_frames_pred=g["nfp"], sampler=sampler, init_noise_fn=lambda i, shp, dev: g["z_init"][i])
     assert blk[0] == 3 and pred.shape == g["pred_raw"].shape
     tol = _runner_tol(g)
-    assert 0.0 < g["ref32_vs_ref64_max_abs"] <= tol / 3
+    assert 0.0 < g["ref32_vs_ref64_max_abs"] <= tol / 3 * (1 + 1e-6)
     err = (pred - g["pred_raw"]).abs().max().item()
     assert err <= tol, f"block loop vs the real runner: {err:.3e} (gate {tol:.1e})"
